@@ -1,0 +1,64 @@
+// Shared declarations for the POCO MI355X (gfx950) HIP library.
+// Everything here is internal; the public surface is include/poco_hip.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define POCO_HIP_CHECK(expr)                                                        \
+  do {                                                                              \
+    hipError_t _e = (expr);                                                         \
+    if (_e != hipSuccess) {                                                         \
+      poco_set_error(std::string(#expr) + ": " + hipGetErrorString(_e));            \
+      return POCO_ERR_HIP;                                                          \
+    }                                                                               \
+  } while (0)
+
+enum { POCO_OK = 0, POCO_ERR_ARG = 1, POCO_ERR_HIP = 2, POCO_ERR_STATE = 3, POCO_ERR_MISSING = 4,
+       POCO_ERR_SHAPE = 5 };
+
+void poco_set_error(const std::string& msg);
+
+// ---------------------------------------------------------------------------------------------
+// Convolution (implicit GEMM on v_mfma_f32_16x16x4_f32), NHWC activations.
+// ---------------------------------------------------------------------------------------------
+
+// Tile configuration for one conv launch.  MT/NT select the template instantiation (register
+// tile of 16x16 MFMA blocks per wave: MT along pixels, NT along output channels); the rest are
+// runtime parameters of the block decomposition.
+struct ConvCfg {
+  int MT;      // 16-pixel sub-tiles per wave            (4, 7 or 13)
+  int NT;      // 16-channel sub-tiles per wave          (1..4)
+  int WM;      // waves along pixels
+  int WN;      // waves along output channels  (block = WM*WN waves)
+  int R;       // output rows per slab
+  int NI;      // slabs (row bands / whole images) per block
+};
+
+struct ConvDesc {
+  // activations: NHWC, each buffer may be a channel slice of a wider buffer
+  const float* in;  int in_cs,  in_co;    // channel stride (channels per pixel of the buffer), offset
+  const float* res; int res_cs, res_co;   // optional residual (same spatial shape as the output)
+  float*       out; int out_cs, out_co;
+  const float* wfrag;                     // weights in MFMA fragment order (see conv_pack_weights)
+  const float* bias;                      // [Cout_padded] folded BN shift / conv bias
+  int B, H, W, Cin, Cout;                 // Cout = padded to a multiple of 16
+  int ks, stride;                         // ks in {1,3}; pad = (ks-1)/2; stride in {1,2}
+  int relu;
+};
+
+// Size (floats) of the packed weight buffer for a conv.
+size_t conv_packed_weight_floats(int Cin, int Cout16, int ks);
+// Pack OIHW weights (host) * per-output-channel scale into fragment order (host buffer).
+// Cout16 >= Cout is Cout rounded up to a multiple of 16 (extra channels are zero).
+void conv_pack_weights(const float* w_oihw, const float* scale /*nullable*/, int Cout, int Cin,
+                       int ks, int Cout16, float* dst);
+// Heuristic tile choice.
+ConvCfg conv_default_cfg(const ConvDesc& d);
+// Validate + launch.  Returns POCO_OK or an error code (message via poco_set_error).
+int conv_launch(const ConvDesc& d, const ConvCfg& cfg, hipStream_t stream);
+// LDS bytes a configuration needs (0 if invalid).
+size_t conv_lds_bytes(const ConvDesc& d, const ConvCfg& cfg);

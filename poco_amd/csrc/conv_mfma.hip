@@ -1,0 +1,413 @@
+// Fused conv (1x1 / 3x3, stride 1 / 2) + folded-BN shift + residual + ReLU for gfx950 (CDNA4).
+//
+// Replaces the torch call sites  conv -> bn -> relu (+ "out += residual")  of the reference:
+//   pocolib/models/backbone/hrnet.py:45-47,82-88,96-97,467-472 ; hrnet_cls.py:439-444 ;
+//   resnet.py:104-118 ; head/pare_head.py:468-491.
+//
+// Design (MI355X-first, not a translation of a cuDNN call):
+//   * activations NHWC fp32; the conv is an implicit GEMM  D[co][pix] = sum_k W[co][k] X[k][pix]
+//     executed on v_mfma_f32_16x16x4_f32 (exact fp32, 157 TF peak).  The *weights* are the MFMA
+//     A operand and the *pixels* the B operand, so every lane ends up with 4 consecutive output
+//     channels of one pixel -> 16-byte NHWC stores and 16-byte bias/residual loads.
+//   * a block owns NI slabs of R output rows.  For each 16-channel slice of Cin the input halo
+//     patch of those slabs is staged once in LDS (zero padded) and re-used by all ks*ks taps and
+//     all output-channel tiles: HBM/L2 sees each input element ~(R+2)/R times instead of 9.
+//   * LDS layout: 4 planes (one per channel quad) of [patch position][4 floats].  Lane l of an
+//     MFMA needs pixel (l&15) / channel group (l>>4); ds_read_b128 services lanes in groups that
+//     mix channel groups but never repeat a pixel, so with the plane stride a multiple of 256 B
+//     the bank slot depends only on the pixel position -> conflict free for consecutive pixels.
+//   * one ds_read_b128 yields the operands of 4 MFMAs (K is permuted: MFMA j contracts channels
+//     {4g+j}); the weight fragments are pre-packed on the host in exactly that order so a wave
+//     reads them from global/L2 with one fully coalesced 1 KiB load per (tap, n-tile).
+//   * epilogue: + shift[co] (+ residual) (ReLU), written into a channel slice of the destination
+//     (makes torch.cat free, hrnet.py:519).
+#include "common.h"
+
+namespace {
+
+struct FastDiv {
+  uint32_t magic, d;
+};
+__host__ inline FastDiv make_fastdiv(uint32_t d) {
+  FastDiv f;
+  f.d = d;
+  f.magic = (uint32_t)(((1ull << 32) + d - 1) / d);
+  return f;
+}
+// exact for n*d < 2^32 (all uses here have n, d < 65536)
+__device__ __forceinline__ uint32_t fdiv(uint32_t n, FastDiv f) {
+  return f.d == 1 ? n : __umulhi(n, f.magic);
+}
+
+struct ConvKParams {
+  const float* in;
+  const float* res;
+  float* out;
+  const float4* wfrag;
+  const float* bias;
+  int in_cs, in_co, res_cs, res_co, out_cs, out_co;
+  int H, W, Ho, Wo;
+  int nC16;    // Cin / 16
+  int nT16;    // Cout16 / 16
+  int R, NI, S;          // rows per slab, slabs per block, total slabs (= B * nbands)
+  int PR, PW;            // patch rows / cols per slab
+  int npos;              // NI * PR * PW
+  int planeF4;           // float4 elements per LDS plane (multiple of 16)
+  int WM, WN;
+  int relu;
+  FastDiv dPW, dSlab /*PR*PW*/, dBands, dWo, dRWo;
+};
+
+template <int KS, int STRIDE, int MT, int NT>
+__global__ void __launch_bounds__(512)
+conv_mfma_kernel(const ConvKParams p) {
+  extern __shared__ float4 patch[];
+  constexpr int PAD = (KS - 1) / 2;
+  const int tid = threadIdx.x;
+  const int nthreads = blockDim.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave % p.WM;
+  const int wn = wave / p.WM;
+  const int idx = lane & 15;
+  const int g = lane >> 4;
+  const int s0 = blockIdx.x * p.NI;
+  const int nt0 = (blockIdx.y * p.WN + wn) * NT;   // first 16-channel tile of this wave
+
+  // ---- per-lane pixel decode for the MT sub-tiles of this wave -------------------------------
+  int base[MT];   // patch position of tap (0,0) for this lane's pixel
+  int ooff[MT];   // output pixel index (b*Ho + y)*Wo + x, or -1
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    const uint32_t pix = (uint32_t)((wm * MT + m) * 16 + idx);
+    const uint32_t sl = fdiv(pix, p.dRWo);
+    const uint32_t rem = pix - sl * p.dRWo.d;
+    const uint32_t yl = fdiv(rem, p.dWo);
+    const uint32_t x = rem - yl * p.dWo.d;
+    const uint32_t s = s0 + sl;
+    const uint32_t b = fdiv(s, p.dBands);
+    const uint32_t band = s - b * p.dBands.d;
+    const uint32_t y = band * p.R + yl;
+    const bool valid = (sl < (uint32_t)p.NI) && (s < (uint32_t)p.S) && (y < (uint32_t)p.Ho);
+    base[m] = valid ? (int)((sl * p.PR + yl * STRIDE) * p.PW + x * STRIDE) : 0;
+    ooff[m] = valid ? (int)((b * p.Ho + y) * p.Wo + x) : -1;
+  }
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const bool nvalid = nt0 < p.nT16;   // wave-uniform (grid.y may overshoot when WN does not divide)
+  const int total_units = ((p.npos + 7) >> 3) << 5;   // (pos rounded to 8) * 4 quads
+
+  for (int c = 0; c < p.nC16; ++c) {
+    if (c > 0) __syncthreads();
+    // ---- stage the 16-channel slice c of the halo patch ------------------------------------
+#pragma unroll 4
+    for (int u = tid; u < total_units; u += nthreads) {
+      const int w = u & 31;
+      const int q = w >> 3;
+      const uint32_t pos = (uint32_t)(((u >> 5) << 3) + (w & 7));
+      if (pos < (uint32_t)p.npos) {
+        const uint32_t sl = fdiv(pos, p.dSlab);
+        const uint32_t rem = pos - sl * p.dSlab.d;
+        const uint32_t prow = fdiv(rem, p.dPW);
+        const uint32_t pcol = rem - prow * p.dPW.d;
+        const uint32_t s = s0 + sl;
+        const uint32_t b = fdiv(s, p.dBands);
+        const uint32_t band = s - b * p.dBands.d;
+        const int iy = (int)(band * p.R) * STRIDE - PAD + (int)prow;
+        const int ix = (int)pcol - PAD;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (s < (uint32_t)p.S && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) {
+          const size_t off = ((size_t)(b * p.H + iy) * p.W + ix) * p.in_cs + p.in_co + c * 16 + q * 4;
+          v = *reinterpret_cast<const float4*>(p.in + off);
+        }
+        patch[q * p.planeF4 + pos] = v;
+      }
+    }
+    __syncthreads();
+
+    if (nvalid) {
+      const float4* wc = p.wfrag + ((size_t)c * p.nT16 + nt0) * 64 + lane;
+      const size_t wtap = (size_t)p.nC16 * p.nT16 * 64;   // stride between taps
+      const float4* pl = patch + g * p.planeF4;
+      float4 wv[NT];
+#pragma unroll
+      for (int n = 0; n < NT; ++n) wv[n] = wc[n * 64];
+      int tr = 0, ts = 0;
+#pragma unroll 1
+      for (int tap = 0; tap < KS * KS; ++tap) {
+        const int toff = tr * p.PW + ts;
+        if (++ts == KS) { ts = 0; ++tr; }
+        // prefetch the next tap's weight fragments (L2-resident, 1 KiB per n-tile per wave)
+        float4 wnx[NT];
+        const int tnext = (tap + 1 < KS * KS) ? tap + 1 : tap;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) wnx[n] = wc[tnext * wtap + n * 64];
+#pragma unroll
+        for (int m0 = 0; m0 < MT; m0 += 2) {
+          const float4 a0 = pl[base[m0] + toff];
+          const float4 a1 = pl[base[(m0 + 1 < MT) ? m0 + 1 : m0] + toff];
+          const float a0v[4] = {a0.x, a0.y, a0.z, a0.w};
+          const float a1v[4] = {a1.x, a1.y, a1.z, a1.w};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+              const float wj = (j == 0) ? wv[n].x : (j == 1) ? wv[n].y : (j == 2) ? wv[n].z : wv[n].w;
+              acc[m0][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wj, a0v[j], acc[m0][n], 0, 0, 0);
+              if (m0 + 1 < MT)
+                acc[m0 + 1][n] =
+                    __builtin_amdgcn_mfma_f32_16x16x4f32(wj, a1v[j], acc[m0 + 1][n], 0, 0, 0);
+            }
+          }
+        }
+#pragma unroll
+        for (int n = 0; n < NT; ++n) wv[n] = wnx[n];
+      }
+    }
+  }
+
+  // ---- epilogue: shift (+ residual) (ReLU) -> NHWC channel slice -----------------------------
+  if (!nvalid) return;
+#pragma unroll
+  for (int n = 0; n < NT; ++n) {
+    const int co = (nt0 + n) * 16 + g * 4;
+    const float4 sh = *reinterpret_cast<const float4*>(p.bias + co);
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      if (ooff[m] >= 0) {
+        f32x4 v = acc[m][n];
+        v[0] += sh.x; v[1] += sh.y; v[2] += sh.z; v[3] += sh.w;
+        if (p.res) {
+          const float4 r = *reinterpret_cast<const float4*>(p.res + (size_t)ooff[m] * p.res_cs + p.res_co + co);
+          v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
+        }
+        if (p.relu) {
+          v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f);
+          v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+        }
+        *reinterpret_cast<float4*>(p.out + (size_t)ooff[m] * p.out_cs + p.out_co + co) =
+            make_float4(v[0], v[1], v[2], v[3]);
+      }
+    }
+  }
+}
+
+template <int KS, int STRIDE, int MT, int NT>
+int launch_inst(const ConvKParams& kp, dim3 grid, int nthreads, size_t lds, hipStream_t stream) {
+  auto fn = conv_mfma_kernel<KS, STRIDE, MT, NT>;
+  if (lds > 64 * 1024) {
+    static thread_local size_t configured = 0;
+    if (lds > configured) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
+      if (e != hipSuccess) {
+        poco_set_error(std::string("hipFuncSetAttribute: ") + hipGetErrorString(e));
+        return POCO_ERR_HIP;
+      }
+      configured = 160 * 1024;
+    }
+  }
+  hipLaunchKernelGGL(fn, grid, dim3(nthreads), lds, stream, kp);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    poco_set_error(std::string("conv launch: ") + hipGetErrorString(e));
+    return POCO_ERR_HIP;
+  }
+  return POCO_OK;
+}
+
+template <int KS, int STRIDE>
+int launch_mtnt(int MT, int NT, const ConvKParams& kp, dim3 grid, int nthreads, size_t lds,
+                hipStream_t stream) {
+#define POCO_CASE(mt, nt) \
+  if (MT == mt && NT == nt) return launch_inst<KS, STRIDE, mt, nt>(kp, grid, nthreads, lds, stream);
+  POCO_CASE(4, 1) POCO_CASE(4, 2) POCO_CASE(4, 3) POCO_CASE(4, 4)
+  POCO_CASE(7, 1) POCO_CASE(7, 2) POCO_CASE(7, 3) POCO_CASE(7, 4)
+  POCO_CASE(13, 1) POCO_CASE(13, 2) POCO_CASE(13, 3)
+#undef POCO_CASE
+  poco_set_error("conv: unsupported (MT,NT) = (" + std::to_string(MT) + "," + std::to_string(NT) + ")");
+  return POCO_ERR_ARG;
+}
+
+struct Geometry {
+  int Ho, Wo, nbands, S, PR, PW, npos, planeF4, nblocks_m;
+};
+
+bool geometry(const ConvDesc& d, const ConvCfg& c, Geometry* g) {
+  const int pad = (d.ks - 1) / 2;
+  g->Ho = (d.H + 2 * pad - d.ks) / d.stride + 1;
+  g->Wo = (d.W + 2 * pad - d.ks) / d.stride + 1;
+  if (c.R < 1 || c.NI < 1 || c.WM < 1 || c.WN < 1) return false;
+  if (c.R > g->Ho) return false;
+  g->nbands = (g->Ho + c.R - 1) / c.R;
+  g->S = d.B * g->nbands;
+  g->PR = (c.R - 1) * d.stride + d.ks;
+  g->PW = (g->Wo - 1) * d.stride + d.ks;
+  g->npos = c.NI * g->PR * g->PW;
+  g->planeF4 = ((g->npos + 15) / 16) * 16;
+  g->nblocks_m = (g->S + c.NI - 1) / c.NI;
+  return true;
+}
+
+}  // namespace
+
+size_t conv_packed_weight_floats(int Cin, int Cout16, int ks) {
+  return (size_t)ks * ks * Cin * Cout16;
+}
+
+// dst layout: [tap][cin/16][cout16/16][lane 0..63][j 0..3]
+//   lane = g*16 + co_l ;  value = W[co = nt*16 + co_l][cin = c16*16 + 4*g + j][tap] * scale[co]
+void conv_pack_weights(const float* w, const float* scale, int Cout, int Cin, int ks, int Cout16,
+                       float* dst) {
+  const int nC16 = Cin / 16, nT16 = Cout16 / 16, taps = ks * ks;
+  for (int tap = 0; tap < taps; ++tap)
+    for (int c16 = 0; c16 < nC16; ++c16)
+      for (int nt = 0; nt < nT16; ++nt)
+        for (int lane = 0; lane < 64; ++lane) {
+          const int g = lane >> 4, col = lane & 15;
+          const int co = nt * 16 + col;
+          float* o = dst + ((((size_t)tap * nC16 + c16) * nT16 + nt) * 64 + lane) * 4;
+          for (int j = 0; j < 4; ++j) {
+            const int ci = c16 * 16 + 4 * g + j;
+            float v = 0.f;
+            if (co < Cout) {
+              v = w[((size_t)co * Cin + ci) * taps + tap];
+              if (scale) v *= scale[co];
+            }
+            o[j] = v;
+          }
+        }
+}
+
+size_t conv_lds_bytes(const ConvDesc& d, const ConvCfg& cfg) {
+  Geometry g;
+  if (!geometry(d, cfg, &g)) return 0;
+  return (size_t)4 * g.planeF4 * sizeof(float4);
+}
+
+ConvCfg conv_default_cfg(const ConvDesc& d) {
+  const int pad = (d.ks - 1) / 2;
+  const int Ho = (d.H + 2 * pad - d.ks) / d.stride + 1;
+  const int Wo = (d.W + 2 * pad - d.ks) / d.stride + 1;
+  const int nT16 = d.Cout / 16;
+  ConvCfg best{};
+  double best_cost = 1e300;
+  const int mts[3] = {4, 7, 13};
+  for (int mi = 0; mi < 3; ++mi) {
+    const int MT = mts[mi];
+    for (int NT = 1; NT <= (MT == 13 ? (d.ks == 3 ? 2 : 3) : 4); ++NT) {
+      for (int WN = 1; WN <= 8; WN *= 2) {
+        for (int WM = 1; WM * WN <= 8; WM *= 2) {
+          if (WM * WN < 2 && d.B * Ho * Wo > 4096) continue;   // keep >= 2 waves for staging
+          const int mcap = WM * MT * 16;
+          // candidate slab shapes: bands of R rows of one image, or NI whole images
+          for (int mode = 0; mode < 2; ++mode) {
+            int R, NI;
+            if (mode == 0) {
+              R = mcap / Wo;
+              if (R < 1) continue;
+              if (R > Ho) R = Ho;
+              NI = 1;
+              // allow several bands per block when one band underfills the wave rows
+              if (R < Ho) NI = mcap / (R * Wo);
+              if (NI < 1) NI = 1;
+            } else {
+              R = Ho;
+              NI = mcap / (Ho * Wo);
+              if (NI < 1) continue;
+              if (NI > d.B) NI = d.B;
+            }
+            ConvCfg c{MT, NT, WM, WN, R, NI};
+            Geometry g;
+            if (!geometry(d, c, &g)) continue;
+            const size_t lds = (size_t)4 * g.planeF4 * 16;
+            if (lds > 72 * 1024) continue;
+            const int nb_n = (nT16 + WN * NT - 1) / (WN * NT);
+            const long blocks = (long)g.nblocks_m * nb_n;
+            // MFMA slots issued vs useful
+            const double issued = (double)blocks * WM * WN * MT * NT;
+            const double useful = (double)d.B * Ho * Wo / 16.0 * nT16;
+            const double eff = useful / issued;
+            // waves available to fill 1024 SIMDs
+            const double waves = (double)blocks * WM * WN;
+            const double fill = waves >= 2048 ? 1.0 : (waves >= 1024 ? 0.9 : waves / 1024.0 * 0.85);
+            // staging redundancy: halo rows + re-staging per n-block
+            const double halo = (double)g.PR / (c.R * d.stride) * nb_n;
+            const double stage_pen = 1.0 + 0.03 * halo * (d.ks == 1 ? 3.0 : 1.0);
+            const double reg_pen = (MT * NT * 4 > 128) ? 1.08 : 1.0;
+            const double cost = stage_pen * reg_pen / (eff * fill);
+            if (cost < best_cost) {
+              best_cost = cost;
+              best = c;
+            }
+          }
+        }
+      }
+    }
+  }
+  return best;
+}
+
+int conv_launch(const ConvDesc& d, const ConvCfg& cfg, hipStream_t stream) {
+  if (!(d.ks == 1 || d.ks == 3) || !(d.stride == 1 || d.stride == 2)) {
+    poco_set_error("conv: ks must be 1|3 and stride 1|2");
+    return POCO_ERR_ARG;
+  }
+  if (d.Cin % 16 || d.Cout % 16) {
+    poco_set_error("conv: Cin and (padded) Cout must be multiples of 16");
+    return POCO_ERR_ARG;
+  }
+  if ((d.in_cs | d.in_co | d.out_cs | d.out_co | d.res_cs | d.res_co) & 3) {
+    poco_set_error("conv: channel strides/offsets must be multiples of 4");
+    return POCO_ERR_ARG;
+  }
+  Geometry g;
+  if (!geometry(d, cfg, &g)) {
+    poco_set_error("conv: invalid tile configuration");
+    return POCO_ERR_ARG;
+  }
+  const int nwaves = cfg.WM * cfg.WN;
+  if (nwaves < 1 || nwaves > 8) {
+    poco_set_error("conv: WM*WN must be in 1..8");
+    return POCO_ERR_ARG;
+  }
+  if (cfg.NI * cfg.R * g.Wo > cfg.WM * cfg.MT * 16) {
+    poco_set_error("conv: block pixel count exceeds WM*MT*16");
+    return POCO_ERR_ARG;
+  }
+  const size_t lds = (size_t)4 * g.planeF4 * sizeof(float4);
+  if (lds > 160 * 1024) {
+    poco_set_error("conv: halo patch does not fit in LDS");
+    return POCO_ERR_ARG;
+  }
+  ConvKParams kp;
+  kp.in = d.in; kp.res = d.res; kp.out = d.out;
+  kp.wfrag = reinterpret_cast<const float4*>(d.wfrag);
+  kp.bias = d.bias;
+  kp.in_cs = d.in_cs; kp.in_co = d.in_co;
+  kp.res_cs = d.res_cs; kp.res_co = d.res_co;
+  kp.out_cs = d.out_cs; kp.out_co = d.out_co;
+  kp.H = d.H; kp.W = d.W; kp.Ho = g.Ho; kp.Wo = g.Wo;
+  kp.nC16 = d.Cin / 16; kp.nT16 = d.Cout / 16;
+  kp.R = cfg.R; kp.NI = cfg.NI; kp.S = g.S;
+  kp.PR = g.PR; kp.PW = g.PW; kp.npos = g.npos; kp.planeF4 = g.planeF4;
+  kp.WM = cfg.WM; kp.WN = cfg.WN;
+  kp.relu = d.relu;
+  kp.dPW = make_fastdiv(g.PW);
+  kp.dSlab = make_fastdiv(g.PR * g.PW);
+  kp.dBands = make_fastdiv(g.nbands);
+  kp.dWo = make_fastdiv(g.Wo);
+  kp.dRWo = make_fastdiv(cfg.R * g.Wo);
+  const int nb_n = (kp.nT16 + cfg.WN * cfg.NT - 1) / (cfg.WN * cfg.NT);
+  dim3 grid(g.nblocks_m, nb_n);
+  const int nthreads = nwaves * 64;
+  if (d.ks == 1 && d.stride == 1) return launch_mtnt<1, 1>(cfg.MT, cfg.NT, kp, grid, nthreads, lds, stream);
+  if (d.ks == 1 && d.stride == 2) return launch_mtnt<1, 2>(cfg.MT, cfg.NT, kp, grid, nthreads, lds, stream);
+  if (d.ks == 3 && d.stride == 1) return launch_mtnt<3, 1>(cfg.MT, cfg.NT, kp, grid, nthreads, lds, stream);
+  return launch_mtnt<3, 2>(cfg.MT, cfg.NT, kp, grid, nthreads, lds, stream);
+}

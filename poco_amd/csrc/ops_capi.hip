@@ -1,0 +1,100 @@
+// C-ABI entry points for the stand-alone operators (used by tests, the tuner and bench.py).
+// Declarations + reference citations: include/poco_hip.h.
+#include "../../include/poco_hip.h"
+#include "common.h"
+
+#include <mutex>
+#include <vector>
+
+static thread_local std::string g_last_error;
+void poco_set_error(const std::string& msg) { g_last_error = msg; }
+
+extern "C" const char* poco_last_error(void) { return g_last_error.c_str(); }
+
+namespace {
+struct DevBuf {
+  float* p = nullptr;
+  ~DevBuf() {
+    if (p) (void)hipFree(p);
+  }
+  hipError_t upload(const std::vector<float>& h) {
+    hipError_t e = hipMalloc(&p, h.size() * sizeof(float));
+    if (e != hipSuccess) return e;
+    return hipMemcpy(p, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice);
+  }
+};
+}  // namespace
+
+static int conv_common(const float* d_in, int B, int H, int W, int Cin, const float* h_w,
+                       const float* h_scale, const float* h_shift, int Cout, int ks, int stride,
+                       const float* d_res, int relu, float* d_out, const int* cfg6, int iters,
+                       float* ms_out, hipStream_t stream) {
+  if (!d_in || !h_w || !d_out) {
+    poco_set_error("conv2d: null pointer");
+    return POCO_ERR_ARG;
+  }
+  const int Cout16 = (Cout + 15) / 16 * 16;
+  if (Cout16 != Cout) {
+    poco_set_error("conv2d op: Cout must be a multiple of 16 (the engine pads; the bare op does not)");
+    return POCO_ERR_ARG;
+  }
+  std::vector<float> packed(conv_packed_weight_floats(Cin, Cout16, ks));
+  conv_pack_weights(h_w, h_scale, Cout, Cin, ks, Cout16, packed.data());
+  std::vector<float> shift(Cout16, 0.f);
+  if (h_shift)
+    for (int i = 0; i < Cout; ++i) shift[i] = h_shift[i];
+  DevBuf dw, db;
+  POCO_HIP_CHECK(dw.upload(packed));
+  POCO_HIP_CHECK(db.upload(shift));
+  ConvDesc d{};
+  d.in = d_in; d.in_cs = Cin; d.in_co = 0;
+  d.res = d_res; d.res_cs = Cout; d.res_co = 0;
+  d.out = d_out; d.out_cs = Cout; d.out_co = 0;
+  d.wfrag = dw.p; d.bias = db.p;
+  d.B = B; d.H = H; d.W = W; d.Cin = Cin; d.Cout = Cout16;
+  d.ks = ks; d.stride = stride; d.relu = relu;
+  ConvCfg cfg = conv_default_cfg(d);
+  if (cfg6 && cfg6[0] > 0) cfg = ConvCfg{cfg6[0], cfg6[1], cfg6[2], cfg6[3], cfg6[4], cfg6[5]};
+  int rc = conv_launch(d, cfg, stream);
+  if (rc != POCO_OK) return rc;
+  if (iters > 0 && ms_out) {
+    hipEvent_t e0, e1;
+    POCO_HIP_CHECK(hipEventCreate(&e0));
+    POCO_HIP_CHECK(hipEventCreate(&e1));
+    for (int i = 0; i < 3; ++i) conv_launch(d, cfg, stream);
+    POCO_HIP_CHECK(hipEventRecord(e0, stream));
+    for (int i = 0; i < iters; ++i) conv_launch(d, cfg, stream);
+    POCO_HIP_CHECK(hipEventRecord(e1, stream));
+    POCO_HIP_CHECK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    POCO_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    *ms_out = ms / iters;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+  }
+  POCO_HIP_CHECK(hipStreamSynchronize(stream));
+  return POCO_OK;
+}
+
+extern "C" int poco_op_conv2d(const float* d_in, int B, int H, int W, int Cin, const float* h_weight,
+                              const float* h_scale, const float* h_shift, int Cout, int ks, int stride,
+                              const float* d_res, int relu, float* d_out, const int* cfg6,
+                              void* stream) {
+  return conv_common(d_in, B, H, W, Cin, h_weight, h_scale, h_shift, Cout, ks, stride, d_res, relu,
+                     d_out, cfg6, 0, nullptr, (hipStream_t)stream);
+}
+
+extern "C" int poco_bench_conv2d(const float* d_in, int B, int H, int W, int Cin, const float* h_weight,
+                                 int Cout, int ks, int stride, float* d_out, const int* cfg6, int iters,
+                                 float* ms_out, int* cfg_used6, void* stream) {
+  if (cfg_used6) {
+    ConvDesc d{};
+    d.B = B; d.H = H; d.W = W; d.Cin = Cin; d.Cout = Cout; d.ks = ks; d.stride = stride;
+    ConvCfg c = (cfg6 && cfg6[0] > 0) ? ConvCfg{cfg6[0], cfg6[1], cfg6[2], cfg6[3], cfg6[4], cfg6[5]}
+                                      : conv_default_cfg(d);
+    cfg_used6[0] = c.MT; cfg_used6[1] = c.NT; cfg_used6[2] = c.WM;
+    cfg_used6[3] = c.WN; cfg_used6[4] = c.R;  cfg_used6[5] = c.NI;
+  }
+  return conv_common(d_in, B, H, W, Cin, h_weight, nullptr, nullptr, Cout, ks, stride, nullptr, 1, d_out,
+                     cfg6, iters, ms_out, (hipStream_t)stream);
+}
