@@ -136,7 +136,7 @@ conv_mfma_kernel(const ConvKParams p) {
       const float4* pl = patch + g * p.planeF4;
       float4 wv[NT];
 #pragma unroll
-      for (int n = 0; n < NT; ++n) wv[n] = wc[n * 64];
+      for (int n = 0; n < NT; ++n) wv[n] = wc[(nt0 + n < p.nT16) ? n * 64 : 0];
       int tr = 0, ts = 0;
 #pragma unroll 1
       for (int tap = 0; tap < KS * KS; ++tap) {
@@ -146,7 +146,7 @@ conv_mfma_kernel(const ConvKParams p) {
         float4 wnx[NT];
         const int tnext = (tap + 1 < KS * KS) ? tap + 1 : tap;
 #pragma unroll
-        for (int n = 0; n < NT; ++n) wnx[n] = wc[tnext * wtap + n * 64];
+        for (int n = 0; n < NT; ++n) wnx[n] = wc[tnext * wtap + ((nt0 + n < p.nT16) ? n * 64 : 0)];
 #pragma unroll
         for (int m0 = 0; m0 < MT; m0 += 2) {
           const float4 a0 = pl[base[m0] + toff];
@@ -175,6 +175,7 @@ conv_mfma_kernel(const ConvKParams p) {
   if (!nvalid) return;
 #pragma unroll
   for (int n = 0; n < NT; ++n) {
+    if (nt0 + n >= p.nT16) break;   // partial n-tile group (wave-uniform)
     const int co = (nt0 + n) * 16 + g * 4;
     const float4 sh = *reinterpret_cast<const float4*>(p.bias + co);
 #pragma unroll
@@ -301,6 +302,7 @@ ConvCfg conv_default_cfg(const ConvDesc& d) {
   for (int mi = 0; mi < 3; ++mi) {
     const int MT = mts[mi];
     for (int NT = 1; NT <= (MT == 13 ? (d.ks == 3 ? 2 : 3) : 4); ++NT) {
+      if (nT16 % NT) continue;
       for (int WN = 1; WN <= 8; WN *= 2) {
         for (int WM = 1; WM * WN <= 8; WM *= 2) {
           if (WM * WN < 2 && d.B * Ho * Wo > 4096) continue;   // keep >= 2 waves for staging
