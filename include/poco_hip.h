@@ -28,6 +28,83 @@ extern "C" {
 /* Message of the last error on this thread ("" if none). */
 const char* poco_last_error(void);
 
+/* ---- the engine: POCO(backbone=..., pretrained=ckpt) + model(batch) ---------------------------
+ * replaces pocolib/models/poco.py:13-154 (ctor :13-97, forward :99-129, load_pretrained :131-154)
+ * as called from pocolib/core/tester.py:75-98 (build) and :213,:408 (output = self.model(batch)). */
+
+typedef struct poco_engine* poco_handle_t;
+
+/* batch dict of pocolib/core/tester.py:205-212 (device pointers, fp32).  bbox_info/focal_length/
+ * scale/center/orig_shape are only read by the *-cliff variants (poco.py:102-111). */
+typedef struct {
+  const float* img;          /* [B,3,224,224] NCHW, ImageNet-normalised crop            */
+  const float* bbox_info;    /* [B,3]   image_utils.py:171-183                           */
+  const float* focal_length; /* [B]     image_utils.py:185-187                           */
+  const float* scale;        /* [B]     bbox size / 200                                  */
+  const float* center;       /* [B,2]   bbox centre (x,y) in full-image pixels           */
+  const float* orig_shape;   /* [B,2]   (img_h, img_w)                                   */
+} poco_inputs_t;
+
+/* output dict of POCO.forward.  Any pointer may be NULL = not wanted
+ * (pred_cam_t / smpl_joints2d / pred_fullimg_cam_t are computed into scratch then). */
+typedef struct {
+  float* pred_pose;          /* [B,24,3,3] rotation matrices                             */
+  float* pred_pose6d;        /* [B,144]    ('pred_pose6d' pare / 'pred_pose_6d' cliff)   */
+  float* pred_shape;         /* [B,10]                                                   */
+  float* pred_cam;           /* [B,3]  weak-perspective (s,tx,ty)                        */
+  float* pred_cam_t;         /* [B,3]  crop camera translation                           */
+  float* pred_fullimg_cam_t; /* [B,3]  cliff only                                        */
+  float* smpl_vertices;      /* [B,6890,3]                                               */
+  float* smpl_joints3d;      /* [B,49,3]                                                 */
+  float* smpl_joints2d;      /* [B,49,2]  pare: crop-normalised, cliff: full-image px    */
+  float* var_pose;           /* [B,24]  per-joint uncertainty (poco_head.py:144-148)     */
+  float* uncert_feat;        /* [B,3072] pare / [B,2048] cliff                           */
+  float* pred_segm_mask;     /* [B,25,56,56] NCHW, pare only                             */
+  float* body_feat2;         /* [B,1024] cliff only                                      */
+} poco_outputs_t;
+
+/* variant = "<backbone>-<head>" exactly as POCO.BACKBONE in the yaml (poco.py:41):
+ * "hrnet_w32-pare", "hrnet_w48_cls-cliff", "resnet50-cliff".  num_flow_layers = POCO.NUM_FLOW_LAYERS.
+ * Host only (no GPU needed): builds the list of tensors the variant expects. */
+int poco_create(const char* variant, int max_batch, int num_flow_layers, poco_handle_t* out);
+void poco_destroy(poco_handle_t h);
+
+/* Expected tensors: names are the reference state_dict keys after the prefix stripping of
+ * pocolib/utils/train_utils.py:69-90 ("backbone.", "head.", "uncert_head.", "flow_head.") plus
+ * "smpl." for the body model (smpl_head.py:40).  required=0: tolerated but unused by forward. */
+int poco_num_tensors(poco_handle_t h);
+int poco_tensor_info(poco_handle_t h, int i, char* name, size_t name_cap, int64_t* shape6, int* rank,
+                     int* required);
+/* Copy one tensor (host fp32) into the engine.  Strict: unknown names and wrong element counts are
+ * errors (the reference's silent strict->non-strict fallback, train_utils.py:118-124, is not kept). */
+int poco_load_tensor(poco_handle_t h, const char* name, const float* host_data, const int64_t* shape,
+                     int rank);
+/* BN folding, MFMA weight packing, upload, workspace planning + allocation.  Needs the GPU. */
+int poco_finalize(poco_handle_t h);
+/* Enqueue one forward pass for B <= max_batch crops on `stream`.  No allocation, no sync. */
+int poco_forward(poco_handle_t h, int B, const poco_inputs_t* in, const poco_outputs_t* out, void* stream);
+
+/* Introspection / tuning. */
+int poco_num_ops(poco_handle_t h);
+int poco_op_info(poco_handle_t h, int i, char* name, size_t name_cap, double* flops_per_crop, int* type);
+int poco_profile_ops(poco_handle_t h, int B, const poco_inputs_t* in, const poco_outputs_t* out, int iters,
+                     float* ms_per_op, int cap, void* stream);
+size_t poco_workspace_bytes(poco_handle_t h);
+int poco_uncert_feat_dim(poco_handle_t h);
+int poco_set_conv_cfg(poco_handle_t h, int op_index, int B, const int* cfg6);
+int poco_get_conv_desc(poco_handle_t h, int op_index, int* desc8);
+
+/* SMPL linear blend skinning with the engine's loaded body model: replaces
+ * smplx.SMPL.forward(pose2rot=False) as wrapped by pocolib/models/head/smpl_head.py:22-34.
+ * d_betas [B,10], d_rotmat [B,24,3,3] -> d_verts [B,6890,3], d_joints49 [B,49,3]. */
+int poco_smpl_lbs(poco_handle_t h, int B, const float* d_betas, const float* d_rotmat, float* d_verts,
+                  float* d_joints49, void* stream);
+/* RealNVP with the engine's flow_head.flow.* weights (pocolib/models/layers/real_nvp.py):
+ * forward=0: log_prob(x[N,9] | ctx[N,512]) -> out[N]   (:55-65)
+ * forward=1: forward_p(z[N,9], ctx)        -> out[N,9] (:25-38) */
+int poco_realnvp(poco_handle_t h, int N, const float* d_x, const float* d_ctx, float* d_out, int forward,
+                 void* stream);
+
 /* ---- stand-alone operators (parity tests, tuner, micro-benchmarks) -------------------------- */
 
 /* conv(ks x ks, stride, pad=(ks-1)/2, no groups/dilation) * scale[co] + shift[co] (+ residual) (ReLU)

@@ -54,7 +54,8 @@ struct ConvKParams {
   int npos;              // NI * PR * PW
   int planeF4;           // float4 elements per LDS plane (multiple of 16)
   int WM, WN;
-  int relu;
+  int act;            // 0 none, 1 ReLU, 2 sigmoid
+  int res_after_act;  // add the residual after the activation (hrnet_cls.py:475-477)
   FastDiv dPW, dSlab /*PR*PW*/, dBands, dWo, dRWo;
 };
 
@@ -183,14 +184,17 @@ conv_mfma_kernel(const ConvKParams p) {
       if (ooff[m] >= 0) {
         f32x4 v = acc[m][n];
         v[0] += sh.x; v[1] += sh.y; v[2] += sh.z; v[3] += sh.w;
-        if (p.res) {
-          const float4 r = *reinterpret_cast<const float4*>(p.res + (size_t)ooff[m] * p.res_cs + p.res_co + co);
-          v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
-        }
-        if (p.relu) {
+        float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p.res) r = *reinterpret_cast<const float4*>(p.res + (size_t)ooff[m] * p.res_cs + p.res_co + co);
+        if (!p.res_after_act) { v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w; }
+        if (p.act == 1) {
           v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f);
           v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+        } else if (p.act == 2) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = 1.f / (1.f + __expf(-v[e]));
         }
+        if (p.res_after_act) { v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w; }
         *reinterpret_cast<float4*>(p.out + (size_t)ooff[m] * p.out_cs + p.out_co + co) =
             make_float4(v[0], v[1], v[2], v[3]);
       }
@@ -399,7 +403,7 @@ int conv_launch(const ConvDesc& d, const ConvCfg& cfg, hipStream_t stream) {
   kp.R = cfg.R; kp.NI = cfg.NI; kp.S = g.S;
   kp.PR = g.PR; kp.PW = g.PW; kp.npos = g.npos; kp.planeF4 = g.planeF4;
   kp.WM = cfg.WM; kp.WN = cfg.WN;
-  kp.relu = d.relu;
+  kp.act = d.act; kp.res_after_act = d.res_after_act;
   kp.dPW = make_fastdiv(g.PW);
   kp.dSlab = make_fastdiv(g.PR * g.PW);
   kp.dBands = make_fastdiv(g.nbands);

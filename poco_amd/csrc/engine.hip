@@ -1,0 +1,1080 @@
+// The POCO engine: builds the per-crop regressor (backbone -> head -> SMPL -> confidence MLP) as a
+// linear program of HIP kernel launches over a statically planned HBM workspace.
+//
+// Replaces  POCO.__init__/forward/load_pretrained  (pocolib/models/poco.py:13-154).  Tensors are
+// addressed by the reference's own state_dict keys (after the prefix stripping of
+// pocolib/utils/train_utils.py:69-90):  backbone.*, head.*, uncert_head.*, flow_head.*  plus the
+// SMPL body model as smpl.* (the reference loads that from data/smpl, smpl_head.py:40).
+//
+// Life cycle (include/poco_hip.h): create (host only; declares every tensor the variant needs) ->
+// load_tensor* (host copies) -> finalize (strict key check, BN folding, MFMA weight packing,
+// upload, workspace planning/allocation) -> forward* (kernel launches only: no allocation, no sync,
+// everything on the caller's stream, hipGraph-capturable) -> destroy.
+#include "../../include/poco_hip.h"
+#include "kernels.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <set>
+#include <vector>
+
+namespace {
+
+constexpr float BN_EPS = 1e-5f;
+
+struct HostParam {
+  std::vector<int64_t> shape;
+  std::vector<float> data;
+};
+struct ParamDecl {
+  std::string name;
+  std::vector<int64_t> shape;
+  int required;   // 1 = used by forward; 0 = tolerated (present in reference checkpoints, unused)
+};
+
+enum OpType {
+  OP_STEM, OP_CONV, OP_MAXPOOL, OP_BILINEAR, OP_FUSE, OP_AVGPOOL, OP_ATTN, OP_LC2D, OP_ROT6D, OP_COPY,
+  OP_BCAST, OP_SMPL, OP_CAMERA, OP_NCHW_OUT
+};
+
+// external buffer slots (inputs / outputs of poco_forward)
+enum Ext {
+  X_NONE = 0, X_IMG, X_BBOX, X_FOCAL, X_SCALE, X_CENTER, X_ORIG,
+  Y_POSE, Y_POSE6D, Y_SHAPE, Y_CAM, Y_CAM_T, Y_FULL_CAM_T, Y_VERTS, Y_J3D, Y_J2D, Y_VAR, Y_UFEAT, Y_SEGM,
+  Y_BODY2
+};
+
+struct Act {
+  int C = 0, H = 1, W = 1;
+  size_t off = 0;       // floats from workspace base
+  int first = 1 << 30, last = -1;
+  bool persistent = false;
+  size_t per_crop() const { return (size_t)C * H * W; }
+};
+
+struct Ref {            // a (possibly strided) view: activation + channel offset, or external slot
+  int act = -1;
+  int co = 0;
+  int ext = X_NONE;
+};
+
+struct Op {
+  int type = 0;
+  std::string name;
+  double flops = 0;     // per crop
+  Ref in, in2, res, out, out2;
+  // conv
+  int Cin = 0, Cout = 0, ks = 1, stride = 1, actfn = 0, res_after = 0;
+  float* wdev = nullptr;
+  float* bdev = nullptr;
+  // fuse
+  Ref fsrc[4];
+  int fshift[4] = {0, 0, 0, 0};
+  int fn = 0, frelu = 1;
+  // misc ints
+  int n = 0, C = 0;
+  std::map<int, ConvCfg> cfg;   // per batch size
+};
+
+struct Engine {
+  std::string backbone, head;
+  int max_batch = 0;
+  int flow_layers = 0;
+  bool finalized = false;
+  std::vector<ParamDecl> decls;
+  std::map<std::string, size_t> decl_index;
+  std::map<std::string, HostParam> params;
+  // graph
+  std::vector<Act> acts;
+  std::vector<Op> ops;
+  float* ws = nullptr;
+  size_t ws_floats = 0;
+  std::vector<void*> dev_allocs;
+  // SMPL / flow device models
+  SmplDev smpl{};
+  int a_A = -1, a_j24 = -1, a_verts = -1, a_j49 = -1, a_attn_scratch = -1, a_camt = -1, a_fullt = -1, a_j2d = -1;
+  Ref smpl_betas, smpl_rot, cam_ref;
+  FlowDev flow{};
+  bool has_flow = false;
+  int uncert_feat_dim = 0;
+  std::string err;
+
+  ~Engine() {
+    for (void* p : dev_allocs) (void)hipFree(p);
+    if (ws) (void)hipFree(ws);
+  }
+};
+
+// ------------------------------------------------------------------------------------------------
+// Builder: the same code path declares the tensors (declare=true, host only) and builds the
+// launch program (declare=false, uploads packed weights).
+// ------------------------------------------------------------------------------------------------
+struct Builder {
+  Engine& e;
+  bool declare;
+  bool ok = true;
+
+  explicit Builder(Engine& eng, bool decl) : e(eng), declare(decl) {}
+
+  const HostParam* P(const std::string& name, std::vector<int64_t> shape, int required = 1) {
+    if (declare) {
+      if (!e.decl_index.count(name)) {
+        e.decl_index[name] = e.decls.size();
+        e.decls.push_back({name, shape, required});
+      }
+      return nullptr;
+    }
+    auto it = e.params.find(name);
+    if (it == e.params.end()) {
+      if (required) { ok = false; e.err += "missing tensor " + name + "; "; }
+      return nullptr;
+    }
+    return &it->second;
+  }
+
+  float* upload(const std::vector<float>& h) {
+    float* d = nullptr;
+    if (hipMalloc(&d, std::max<size_t>(h.size(), 4) * sizeof(float)) != hipSuccess) { ok = false; e.err += "hipMalloc failed; "; return nullptr; }
+    if (hipMemcpy(d, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) { ok = false; e.err += "H2D failed; "; }
+    e.dev_allocs.push_back(d);
+    return d;
+  }
+  int* upload_i(const std::vector<int>& h) {
+    int* d = nullptr;
+    if (hipMalloc(&d, std::max<size_t>(h.size(), 4) * sizeof(int)) != hipSuccess) { ok = false; return nullptr; }
+    if (hipMemcpy(d, h.data(), h.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) ok = false;
+    e.dev_allocs.push_back(d);
+    return d;
+  }
+
+  int new_act(int C, int H, int W, bool persistent = false) {
+    Act a; a.C = C; a.H = H; a.W = W; a.persistent = persistent;
+    e.acts.push_back(a);
+    return (int)e.acts.size() - 1;
+  }
+  static Ref R(int act, int co = 0) { Ref r; r.act = act; r.co = co; return r; }
+  static Ref X(int ext) { Ref r; r.ext = ext; return r; }
+
+  void push(Op&& op) { e.ops.push_back(std::move(op)); }
+
+  // BN(eval) folded into per-channel scale/shift:  y = conv*scale + shift
+  void bn_fold(const std::string& bn, const HostParam* conv_bias, int Cout, std::vector<float>& scale,
+               std::vector<float>& shift) {
+    scale.assign(Cout, 1.f);
+    shift.assign(Cout, 0.f);
+    if (!bn.empty()) {
+      const HostParam* g = P(bn + ".weight", {Cout});
+      const HostParam* b = P(bn + ".bias", {Cout});
+      const HostParam* m = P(bn + ".running_mean", {Cout});
+      const HostParam* v = P(bn + ".running_var", {Cout});
+      P(bn + ".num_batches_tracked", {}, 0);
+      if (declare || !g || !b || !m || !v) return;
+      for (int c = 0; c < Cout; ++c) {
+        const double s = (double)g->data[c] / std::sqrt((double)v->data[c] + (double)BN_EPS);
+        scale[c] = (float)s;
+        shift[c] = (float)((double)b->data[c] - (double)m->data[c] * s);
+        if (conv_bias) shift[c] = (float)((double)shift[c] + (double)conv_bias->data[c] * s);
+      }
+    } else if (conv_bias && !declare) {
+      for (int c = 0; c < Cout; ++c) shift[c] = conv_bias->data[c];
+    }
+  }
+
+  // conv (+bias) + BN + act (+ residual).  `in` may be a channel slice; returns the output act
+  // (or writes into `into` at channel offset).  kperm: optional K-column permutation for Linear
+  // layers whose input vector is laid out differently from the reference's torch.cat.
+  int conv(const std::string& name, const std::string& convp, const std::string& bnp, Ref in, int Cin_real,
+           int Cout, int ks, int stride, int actfn, bool has_bias, Ref res = Ref(), int res_after = 0,
+           Ref into = Ref(), const std::vector<int>* kperm = nullptr, int Cin_padded = 0, bool is_linear = false,
+           bool direct = false, const HostParam* w_direct = nullptr, const HostParam* b_direct = nullptr) {
+    const Act ain = e.acts[in.act];
+    const int Cin = Cin_padded ? Cin_padded : Cin_real;
+    const int pad = (ks - 1) / 2;
+    const int Ho = (ain.H + 2 * pad - ks) / stride + 1, Wo = (ain.W + 2 * pad - ks) / stride + 1;
+    const int Cout16 = (Cout + 15) / 16 * 16;
+    std::vector<int64_t> wshape = is_linear ? std::vector<int64_t>{Cout, Cin_real}
+                                            : std::vector<int64_t>{Cout, Cin_real, ks, ks};
+    const HostParam* w = direct ? w_direct : P(convp + ".weight", wshape);
+    const HostParam* cb = direct ? b_direct : (has_bias ? P(convp + ".bias", {Cout}) : nullptr);
+    std::vector<float> scale, shift;
+    bn_fold(bnp, cb, Cout, scale, shift);
+    Op op;
+    op.type = OP_CONV; op.name = name;
+    op.in = in; op.res = res; op.res_after = res_after;
+    op.Cin = Cin; op.Cout = Cout16; op.ks = ks; op.stride = stride; op.actfn = actfn;
+    op.flops = 2.0 * Ho * Wo * (double)Cout * Cin_real * ks * ks;
+    int out_act;
+    if (into.act >= 0) { out_act = into.act; op.out = into; }
+    else { out_act = new_act(Cout16, Ho, Wo); op.out = R(out_act); }
+    if (!declare && w) {
+      std::vector<float> wsrc;
+      const float* wp = w->data.data();
+      if (kperm || Cin != Cin_real) {        // re-lay the K columns (Linear layers only: ks == 1)
+        wsrc.assign((size_t)Cout * Cin, 0.f);
+        for (int o = 0; o < Cout; ++o)
+          for (int k = 0; k < Cin_real; ++k) {
+            const int dst = kperm ? (*kperm)[k] : k;
+            wsrc[(size_t)o * Cin + dst] = wp[(size_t)o * Cin_real + k];
+          }
+        wp = wsrc.data();
+      }
+      std::vector<float> packed(conv_packed_weight_floats(Cin, Cout16, ks));
+      conv_pack_weights(wp, scale.data(), Cout, Cin, ks, Cout16, packed.data());
+      std::vector<float> sh(Cout16, 0.f);
+      std::copy(shift.begin(), shift.end(), sh.begin());
+      op.wdev = upload(packed);
+      op.bdev = upload(sh);
+    }
+    push(std::move(op));
+    return out_act;
+  }
+
+  int conv_bn(const std::string& pfx_conv, const std::string& pfx_bn, int in, int Cin, int Cout, int ks, int stride,
+              int relu, int res = -1, bool bias = false, int res_after = 0, Ref into = Ref()) {
+    return conv(pfx_conv, pfx_conv, pfx_bn, R(in), Cin, Cout, ks, stride, relu ? 1 : 0, bias,
+                res >= 0 ? R(res) : Ref(), res_after, into);
+  }
+
+  // ---- blocks --------------------------------------------------------------------------------
+  int basic_block(const std::string& p, int x, int C) {           // hrnet.py:42-58
+    int y = conv_bn(p + ".conv1", p + ".bn1", x, C, C, 3, 1, 1);
+    return conv_bn(p + ".conv2", p + ".bn2", y, C, C, 3, 1, 1, x);
+  }
+  int bottleneck(const std::string& p, int x, int Cin, int planes, int stride, bool down) {   // :79-99
+    int y = conv_bn(p + ".conv1", p + ".bn1", x, Cin, planes, 1, 1, 1);
+    y = conv_bn(p + ".conv2", p + ".bn2", y, planes, planes, 3, stride, 1);
+    int r = x;
+    if (down) r = conv_bn(p + ".downsample.0", p + ".downsample.1", x, Cin, planes * 4, 1, stride, 0);
+    return conv_bn(p + ".conv3", p + ".bn3", y, planes, planes * 4, 1, 1, 1, r);
+  }
+
+  int stem(const std::string& p, int ks, int H) {                   // conv1+bn1+relu from the NCHW image
+    const HostParam* w = P(p + "conv1.weight", {64, 3, ks, ks});
+    std::vector<float> scale, shift;
+    bn_fold(p + "bn1", nullptr, 64, scale, shift);
+    const int pad = (ks - 1) / 2;
+    const int Ho = (H + 2 * pad - ks) / 2 + 1;
+    Op op; op.type = OP_STEM; op.name = p + "conv1"; op.ks = ks; op.n = H;
+    op.in = X(X_IMG);
+    op.flops = 2.0 * Ho * Ho * 64 * 3 * ks * ks;
+    int out = new_act(64, Ho, Ho);
+    op.out = R(out);
+    if (!declare && w) {
+      std::vector<float> wt((size_t)ks * ks * 3 * 64);
+      for (int co = 0; co < 64; ++co)
+        for (int c = 0; c < 3; ++c)
+          for (int t = 0; t < ks * ks; ++t)
+            wt[((size_t)t * 3 + c) * 64 + co] = w->data[((size_t)co * 3 + c) * ks * ks + t] * scale[co];
+      op.wdev = upload(wt);
+      op.bdev = upload(shift);
+    }
+    push(std::move(op));
+    return out;
+  }
+
+  void fuse_sum(const std::string& name, const std::vector<std::pair<int, int>>& terms, Ref out, int relu) {
+    Op op; op.type = OP_FUSE; op.name = name; op.fn = (int)terms.size(); op.frelu = relu;
+    for (size_t k = 0; k < terms.size(); ++k) { op.fsrc[k] = R(terms[k].first); op.fshift[k] = terms[k].second; }
+    op.out = out;
+    push(std::move(op));
+  }
+
+  // HighResolutionModule.forward, hrnet.py:248-266.  last_into: write branch-0 output into a wider
+  // concat buffer (POCO-PARE's 480-channel feature map) instead of a fresh tensor.
+  std::vector<int> hr_module(const std::string& p, std::vector<int> xs, const std::vector<int>& ch, Ref out0 = Ref()) {
+    const int nb = (int)xs.size();
+    for (int i = 0; i < nb; ++i)
+      for (int k = 0; k < 4; ++k) xs[i] = basic_block(p + ".branches." + std::to_string(i) + "." + std::to_string(k), xs[i], ch[i]);
+    std::vector<int> outs(nb);
+    for (int i = 0; i < nb; ++i) {
+      std::vector<std::pair<int, int>> terms;
+      for (int j = 0; j < nb; ++j) {
+        const std::string q = p + ".fuse_layers." + std::to_string(i) + "." + std::to_string(j);
+        if (j == i) terms.push_back({xs[j], 0});
+        else if (j > i) terms.push_back({conv_bn(q + ".0", q + ".1", xs[j], ch[j], ch[i], 1, 1, 0), j - i});
+        else {
+          int t = xs[j];
+          for (int k = 0; k < i - j; ++k) {
+            const bool lastk = (k == i - j - 1);
+            const std::string qq = q + "." + std::to_string(k);
+            t = conv_bn(qq + ".0", qq + ".1", t, ch[j], lastk ? ch[i] : ch[j], 3, 2, lastk ? 0 : 1);
+          }
+          terms.push_back({t, 0});
+        }
+      }
+      const Act a = e.acts[xs[i]];
+      if (i == 0 && out0.act >= 0) { outs[i] = out0.act; fuse_sum(p + ".fuse" + std::to_string(i), terms, out0, 1); }
+      else { outs[i] = new_act(a.C, a.H, a.W); fuse_sum(p + ".fuse" + std::to_string(i), terms, R(outs[i]), 1); }
+    }
+    return outs;
+  }
+
+  // stem + layer1 + transitions + stages 2-4 (hrnet.py:466-497 / hrnet_cls.py:438-469)
+  std::vector<int> hrnet_trunk(const std::string& p, int w, Ref final_out0 = Ref()) {
+    int x = stem(p, 3, 224);
+    x = conv_bn(p + "conv2", p + "bn2", x, 64, 64, 3, 2, 1);
+    for (int k = 0; k < 4; ++k) x = bottleneck(p + "layer1." + std::to_string(k), x, k == 0 ? 64 : 256, 64, 1, k == 0);
+    std::vector<int> ys = {x};
+    std::vector<int> prev_ch = {256};
+    const int nmod[3] = {1, 4, 3};
+    for (int s = 0; s < 3; ++s) {
+      const int nb = s + 2;
+      std::vector<int> ch(nb);
+      for (int i = 0; i < nb; ++i) ch[i] = w << i;
+      const std::string t = p + "transition" + std::to_string(s + 1);
+      std::vector<int> xs(nb);
+      for (int i = 0; i < nb; ++i) {
+        const std::string ti = t + "." + std::to_string(i);
+        if (i < (int)ys.size()) {
+          if (prev_ch[i] != ch[i]) xs[i] = conv_bn(ti + ".0", ti + ".1", ys[i], prev_ch[i], ch[i], 3, 1, 1);
+          else xs[i] = ys[i];
+        } else {
+          // hrnet.py:402-418: new branch = stride-2 conv chain from the last previous branch
+          xs[i] = conv_bn(ti + ".0.0", ti + ".0.1", ys.back(), prev_ch.back(), ch[i], 3, 2, 1);
+        }
+      }
+      for (int m = 0; m < nmod[s]; ++m) {
+        const bool last = (s == 2 && m == nmod[s] - 1);
+        xs = hr_module(p + "stage" + std::to_string(s + 2) + "." + std::to_string(m), xs, ch, last ? final_out0 : Ref());
+      }
+      ys = xs;
+      prev_ch = ch;
+    }
+    return ys;
+  }
+};
+
+// ------------------------------------------------------------------------------------------------
+// Variant assembly
+// ------------------------------------------------------------------------------------------------
+constexpr int XC_BBOX = 2048, XC_STATE = 2052, XC_DIM = 2224;   // CLIFF fc1 input layout
+constexpr int XU_DIM = 3296;                                   // PARE uncert input: 3072 feat + 216 rot + pad
+
+void build_smpl(Builder& b) {
+  Engine& e = b.e;
+  const int V = 6890;
+  const HostParam* vt = b.P("smpl.v_template", {V, 3});
+  const HostParam* sd = b.P("smpl.shapedirs", {V, 3, 10});
+  const HostParam* pd = b.P("smpl.posedirs", {207, V * 3});
+  const HostParam* jr = b.P("smpl.J_regressor", {24, V});
+  const HostParam* lw = b.P("smpl.lbs_weights", {V, 24});
+  const HostParam* je = b.P("smpl.J_regressor_extra", {9, V});
+  const HostParam* par = b.P("smpl.parents", {24});
+  const HostParam* ev = b.P("smpl.extra_vertex_ids", {21});
+  const HostParam* jm = b.P("smpl.joint_map", {49});
+  e.a_A = b.new_act(288, 1, 1, true);
+  e.a_j24 = b.new_act(72, 1, 1, true);
+  e.a_verts = b.new_act(V * 3, 1, 1, true);
+  e.a_j49 = b.new_act(147, 1, 1, true);
+  e.a_camt = b.new_act(4, 1, 1, true);
+  e.a_fullt = b.new_act(4, 1, 1, true);
+  e.a_j2d = b.new_act(100, 1, 1, true);
+  if (b.declare || !vt || !sd || !pd || !jr || !lw || !je || !par || !ev || !jm) return;
+  // J = J_regressor . (v_template + shapedirs . betas)  ->  fold the regressor (float64 on the host)
+  std::vector<float> Jt(72), Js(720), sdt((size_t)10 * V * 3);
+  for (int j = 0; j < 24; ++j)
+    for (int k = 0; k < 3; ++k) {
+      double acc = 0;
+      for (int v = 0; v < V; ++v) acc += (double)jr->data[(size_t)j * V + v] * vt->data[(size_t)v * 3 + k];
+      Jt[j * 3 + k] = (float)acc;
+      for (int l = 0; l < 10; ++l) {
+        double a2 = 0;
+        for (int v = 0; v < V; ++v) a2 += (double)jr->data[(size_t)j * V + v] * sd->data[((size_t)v * 3 + k) * 10 + l];
+        Js[(j * 3 + k) * 10 + l] = (float)a2;
+      }
+    }
+  for (int v = 0; v < V; ++v)
+    for (int k = 0; k < 3; ++k)
+      for (int l = 0; l < 10; ++l) sdt[(size_t)l * V * 3 + v * 3 + k] = sd->data[((size_t)v * 3 + k) * 10 + l];
+  auto to_int = [](const HostParam* p) { std::vector<int> r(p->data.size()); for (size_t i = 0; i < r.size(); ++i) r[i] = (int)std::lround(p->data[i]); return r; };
+  e.smpl.V = V;
+  e.smpl.v_template = b.upload(vt->data);
+  e.smpl.shapedirs = b.upload(sdt);
+  e.smpl.posedirs = b.upload(pd->data);
+  e.smpl.lbs_weights = b.upload(lw->data);
+  e.smpl.J_template = b.upload(Jt);
+  e.smpl.J_shapedirs = b.upload(Js);
+  e.smpl.J_regressor_extra = b.upload(je->data);
+  e.smpl.parents = b.upload_i(to_int(par));
+  e.smpl.extra_vertex_ids = b.upload_i(to_int(ev));
+  e.smpl.joint_map = b.upload_i(to_int(jm));
+}
+
+void build_flow(Builder& b, int in_ctx) {
+  Engine& e = b.e;
+  const int L = 2 * e.flow_layers, D = 9, H = 64, ctx = 512, K0 = D + ctx;
+  // cond_layer is evaluated and discarded by the reference at inference (nf_head.py:82,129-136):
+  // declared (so checkpoints load strictly) but never launched in forward.
+  b.P("flow_head.cond_layer.weight", {ctx, in_ctx}, 0);
+  b.P("flow_head.cond_layer.bias", {ctx}, 0);
+  const HostParam* mask = b.P("flow_head.flow.mask", {L, D}, 0);
+  std::vector<float> w0[2], b0[2], w1[2], b1[2], w2[2], b2[2];
+  bool all = mask != nullptr;
+  for (int net = 0; net < 2; ++net) {
+    const std::string nn = net == 0 ? "s" : "t";
+    for (int l = 0; l < L; ++l) {
+      const std::string q = "flow_head.flow." + nn + "." + std::to_string(l);
+      const HostParam* W0 = b.P(q + ".0.weight", {H, K0}, 0);
+      const HostParam* B0 = b.P(q + ".0.bias", {H}, 0);
+      const HostParam* W1 = b.P(q + ".2.weight", {H, H}, 0);
+      const HostParam* B1 = b.P(q + ".2.bias", {H}, 0);
+      const HostParam* W2 = b.P(q + ".4.weight", {D, H}, 0);
+      const HostParam* B2 = b.P(q + ".4.bias", {D}, 0);
+      if (b.declare) continue;
+      if (!W0 || !B0 || !W1 || !B1 || !W2 || !B2) { all = false; continue; }
+      for (int i = 0; i < K0; ++i) for (int h = 0; h < H; ++h) w0[net].push_back(W0->data[(size_t)h * K0 + i]);
+      for (int k = 0; k < H; ++k) for (int h = 0; h < H; ++h) w1[net].push_back(W1->data[(size_t)h * H + k]);
+      w2[net].insert(w2[net].end(), W2->data.begin(), W2->data.end());
+      b0[net].insert(b0[net].end(), B0->data.begin(), B0->data.end());
+      b1[net].insert(b1[net].end(), B1->data.begin(), B1->data.end());
+      b2[net].insert(b2[net].end(), B2->data.begin(), B2->data.end());
+    }
+  }
+  if (b.declare || !all) return;
+  e.flow.L = L; e.flow.ctx = ctx;
+  e.flow.mask = b.upload(mask->data);
+  for (int net = 0; net < 2; ++net) {
+    e.flow.w0t[net] = b.upload(w0[net]); e.flow.b0[net] = b.upload(b0[net]);
+    e.flow.w1t[net] = b.upload(w1[net]); e.flow.b1[net] = b.upload(b1[net]);
+    e.flow.w2[net] = b.upload(w2[net]);  e.flow.b2[net] = b.upload(b2[net]);
+  }
+  e.has_flow = true;
+}
+
+void add_copy(Builder& b, const std::string& name, Ref src, Ref dst, int n) {
+  Op op; op.type = OP_COPY; op.name = name; op.in = src; op.out = dst; op.n = n;
+  b.push(std::move(op));
+}
+
+void build_tail(Builder& b, Ref betas, Ref rot, Ref cam, bool cliff) {
+  Engine& e = b.e;
+  build_smpl(b);
+  e.smpl_betas = betas; e.smpl_rot = rot; e.cam_ref = cam;
+  { Op op; op.type = OP_SMPL; op.name = "smpl.lbs"; op.flops = 2.0 * 7.9e6; b.push(std::move(op)); }
+  { Op op; op.type = OP_CAMERA; op.name = "smpl.camera"; op.n = cliff; b.push(std::move(op)); }
+}
+
+bool build_graph(Engine& e, bool declare) {
+  Builder b(e, declare);
+  e.acts.clear();
+  e.ops.clear();
+  const bool cliff = e.head == "cliff";
+  const std::string bp = "backbone.";
+  int xc = -1;          // CLIFF fc1 input vector [XC_DIM]
+  int feat480 = -1;
+  if (cliff) xc = b.new_act(XC_DIM, 1, 1, true);
+
+  // ---- backbone ------------------------------------------------------------------------------
+  if (e.backbone == "hrnet_w32") {
+    feat480 = b.new_act(480, 56, 56);
+    std::vector<int> ys = b.hrnet_trunk(bp, 32, Builder::R(feat480, 0));
+    // hrnet.py:515-519: bilinear x2 (align_corners) + conv3x3 + BN + ReLU chains, channel concat
+    const int chs[4] = {32, 64, 128, 256};
+    const int offs[4] = {0, 32, 96, 224};
+    for (int br = 1; br < 4; ++br) {
+      int y = ys[br];
+      for (int t = 0; t < br; ++t) {
+        const Act a = e.acts[y];
+        Op up; up.type = OP_BILINEAR; up.name = bp + "upsample_stage_" + std::to_string(br + 1) + "." + std::to_string(4 * t);
+        up.in = Builder::R(y);
+        int u = b.new_act(a.C, a.H * 2, a.W * 2);
+        up.out = Builder::R(u);
+        b.push(std::move(up));
+        const std::string q = bp + "upsample_stage_" + std::to_string(br + 1) + ".";
+        const bool lastt = (t == br - 1);
+        y = b.conv(q + std::to_string(1 + 4 * t), q + std::to_string(1 + 4 * t), q + std::to_string(2 + 4 * t),
+                   Builder::R(u), chs[br], chs[br], 3, 1, 1, false, Ref(), 0,
+                   lastt ? Builder::R(feat480, offs[br]) : Ref());
+      }
+    }
+    // present in reference checkpoints, unused by forward (hrnet.py:326-332)
+    b.P(bp + "final_layer.weight", {24, 32, 1, 1}, 0);
+    b.P(bp + "final_layer.bias", {24}, 0);
+  } else if (e.backbone == "hrnet_w48_cls") {
+    std::vector<int> ys = b.hrnet_trunk(bp, 48);
+    const int hc[4] = {32, 64, 128, 256};
+    int y = b.bottleneck(bp + "incre_modules.0.0", ys[0], 48, hc[0], 1, true);
+    for (int i = 0; i < 3; ++i) {
+      int inc = b.bottleneck(bp + "incre_modules." + std::to_string(i + 1) + ".0", ys[i + 1], 48 << (i + 1), hc[i + 1], 1, true);
+      const std::string q = bp + "downsamp_modules." + std::to_string(i);
+      // hrnet_cls.py:475-477:  incre(y_{i+1}) + ReLU(BN(conv_s2(y)))   -> residual added after the ReLU
+      y = b.conv_bn(q + ".0", q + ".1", y, hc[i] * 4, hc[i + 1] * 4, 3, 2, 1, inc, true, 1);
+    }
+    y = b.conv_bn(bp + "final_layer.0", bp + "final_layer.1", y, 1024, 2048, 1, 1, 1, -1, true);
+    Op ap; ap.type = OP_AVGPOOL; ap.name = bp + "avgpool"; ap.in = Builder::R(y); ap.out = Builder::R(xc, 0);
+    b.push(std::move(ap));
+    b.P(bp + "classifier.weight", {1000, 2048}, 0);
+    b.P(bp + "classifier.bias", {1000}, 0);
+  } else if (e.backbone == "resnet50") {
+    int x = b.stem(bp, 7, 224);
+    const Act a = e.acts[x];
+    Op mp; mp.type = OP_MAXPOOL; mp.name = bp + "maxpool"; mp.in = Builder::R(x);
+    int p = b.new_act(64, (a.H + 2 - 3) / 2 + 1, (a.W + 2 - 3) / 2 + 1);
+    mp.out = Builder::R(p);
+    b.push(std::move(mp));
+    x = p;
+    const int nblk[4] = {3, 4, 6, 3};
+    int cin = 64;
+    for (int li = 0; li < 4; ++li) {
+      const int planes = 64 << li;
+      for (int k = 0; k < nblk[li]; ++k) {
+        const int stride = (k == 0 && li > 0) ? 2 : 1;
+        x = b.bottleneck(bp + "layer" + std::to_string(li + 1) + "." + std::to_string(k), x, cin, planes, stride, k == 0);
+        cin = planes * 4;
+      }
+    }
+    if (!cliff) { e.err = "resnet50 is only wired to the cliff head"; return false; }
+    Op ap; ap.type = OP_AVGPOOL; ap.name = "head.avgpool"; ap.in = Builder::R(x); ap.out = Builder::R(xc, 0);
+    b.push(std::move(ap));
+  } else {
+    e.err = "unknown backbone " + e.backbone;
+    return false;
+  }
+
+  // ---- head + uncertainty MLP ------------------------------------------------------------------
+  const std::string hp = "head.", up = "uncert_head.";
+  if (cliff) {
+    if (xc < 0) { e.err = "cliff head needs a pooled 2048-d feature"; return false; }
+    // state = [pose6d(144) | shape(10) | cam(3)] lives inside the fc1 input vector (cliff_head.py:103-113)
+    const HostParam* ip = b.P(hp + "init_pose", {1, 144});
+    const HostParam* is = b.P(hp + "init_shape", {1, 10});
+    const HostParam* ic = b.P(hp + "init_cam", {1, 3});
+    Op bc; bc.type = OP_BCAST; bc.name = hp + "init_state"; bc.out = Builder::R(xc, XC_STATE); bc.n = 157;
+    if (!declare && ip && is && ic) {
+      std::vector<float> st(ip->data);
+      st.insert(st.end(), is->data.begin(), is->data.end());
+      st.insert(st.end(), ic->data.begin(), ic->data.end());
+      bc.wdev = b.upload(st);
+    }
+    b.push(std::move(bc));
+    add_copy(b, hp + "bbox_info", Builder::X(X_BBOX), Builder::R(xc, XC_BBOX), 3);
+    std::vector<int> perm(2208);
+    for (int k = 0; k < 2048; ++k) perm[k] = k;
+    for (int k = 0; k < 3; ++k) perm[2048 + k] = XC_BBOX + k;
+    for (int k = 0; k < 157; ++k) perm[2051 + k] = XC_STATE + k;
+    // decpose/decshape/deccam fused into one [157,1024] matrix: declared separately, stacked here
+    const HostParam* dp = b.P(hp + "decpose.weight", {144, 1024});
+    const HostParam* dpb = b.P(hp + "decpose.bias", {144});
+    const HostParam* ds = b.P(hp + "decshape.weight", {10, 1024});
+    const HostParam* dsb = b.P(hp + "decshape.bias", {10});
+    const HostParam* dc = b.P(hp + "deccam.weight", {3, 1024});
+    const HostParam* dcb = b.P(hp + "deccam.bias", {3});
+    HostParam decW, decB;
+    const bool have_dec = !declare && dp && ds && dc && dpb && dsb && dcb;
+    if (have_dec) {
+      decW.shape = {157, 1024}; decB.shape = {157};
+      decW.data = dp->data; decW.data.insert(decW.data.end(), ds->data.begin(), ds->data.end());
+      decW.data.insert(decW.data.end(), dc->data.begin(), dc->data.end());
+      decB.data = dpb->data; decB.data.insert(decB.data.end(), dsb->data.begin(), dsb->data.end());
+      decB.data.insert(decB.data.end(), dcb->data.begin(), dcb->data.end());
+    }
+    int h2 = -1;
+    for (int it = 0; it < 3; ++it) {
+      const std::string sfx = "#" + std::to_string(it);
+      int h1 = b.conv(hp + "fc1" + sfx, hp + "fc1", "", Builder::R(xc), 2208, 1024, 1, 1, 0, true, Ref(), 0, Ref(),
+                      &perm, XC_DIM, true);
+      h2 = b.conv(hp + "fc2" + sfx, hp + "fc2", "", Builder::R(h1), 1024, 1024, 1, 1, 0, true, Ref(), 0, Ref(),
+                  nullptr, 0, true);
+      // fused decoder: state += dec(h2)  (in place on the state slice of xc)
+      b.conv(hp + "dec" + sfx, "", "", Builder::R(h2), 1024, 157, 1, 1, 0, true, Builder::R(xc, XC_STATE), 0,
+             Builder::R(xc, XC_STATE), nullptr, 0, true, true, have_dec ? &decW : nullptr, have_dec ? &decB : nullptr);
+    }
+    int rot = b.new_act(224, 1, 1, true);
+    { Op op; op.type = OP_ROT6D; op.name = hp + "rot6d"; op.in = Builder::R(xc, XC_STATE); op.out = Builder::R(rot);
+      op.out2 = Builder::X(Y_POSE); b.push(std::move(op)); }
+    add_copy(b, "out.pred_pose6d", Builder::R(xc, XC_STATE), Builder::X(Y_POSE6D), 144);
+    add_copy(b, "out.pred_shape", Builder::R(xc, XC_STATE + 144), Builder::X(Y_SHAPE), 10);
+    add_copy(b, "out.pred_cam", Builder::R(xc, XC_STATE + 154), Builder::X(Y_CAM), 3);
+    add_copy(b, "out.uncert_feat", Builder::R(xc, 0), Builder::X(Y_UFEAT), 2048);
+    add_copy(b, "out.body_feat2", Builder::R(h2), Builder::X(Y_BODY2), 1024);
+    e.uncert_feat_dim = 2048;
+    build_tail(b, Builder::R(xc, XC_STATE + 144), Builder::R(rot), Builder::R(xc, XC_STATE + 154), true);
+    // poco_head 'feat-pose-net' (poco_head.py:122-141): sigmoid(featNet(feat)) || sigmoid(poseNet(R)) -> fc1 -> sigmoid
+    int u = b.new_act(448, 1, 1, true);
+    b.conv(up + "uncert_fc_featNet", up + "uncert_fc_featNet", "", Builder::R(xc, 0), 2048, 216, 1, 1, 2, true, Ref(), 0,
+           Builder::R(u, 0), nullptr, 0, true);
+    b.conv(up + "uncert_fc_poseNet", up + "uncert_fc_poseNet", "", Builder::R(rot), 216, 216, 1, 1, 2, true, Ref(), 0,
+           Builder::R(u, 216), nullptr, 224, true);
+    int var = b.conv(up + "uncert_fc1", up + "uncert_fc1", "", Builder::R(u), 432, 24, 1, 1, 2, true, Ref(), 0, Ref(),
+                     nullptr, 448, true);
+    add_copy(b, "out.var_pose", Builder::R(var), Builder::X(Y_VAR), 24);
+    build_flow(b, 2048);
+  } else if (e.head == "pare") {
+    if (feat480 < 0) { e.err = "pare head needs the hrnet_w32 backbone"; return false; }
+    auto branch = [&](const std::string& nm) {
+      int y = b.conv_bn(hp + nm + ".0", hp + nm + ".1", feat480, 480, 128, 3, 1, 1);
+      return b.conv_bn(hp + nm + ".3", hp + nm + ".4", y, 128, 128, 3, 1, 1);
+    };
+    int kp = branch("keypoint_deconv_layers");
+    int heat = b.conv(hp + "keypoint_final_layer", hp + "keypoint_final_layer", "", Builder::R(kp), 128, 25, 1, 1, 0, true);
+    int sm = branch("smpl_deconv_layers");
+    int cs = b.conv(hp + "smpl_final_layer", hp + "smpl_final_layer", "", Builder::R(sm), 128, 64, 1, 1, 0, true);
+    int xu = b.new_act(XU_DIM, 1, 1, true);
+    int flat = b.new_act(1536, 1, 1, true);
+    e.a_attn_scratch = b.new_act((int)(part_attention_scratch_floats(1, 128)), 1, 1, true);
+    { Op op; op.type = OP_ATTN; op.name = hp + "attn_pool_pose"; op.in = Builder::R(heat); op.in2 = Builder::R(sm);
+      op.C = 128; op.out = Builder::R(xu, 0); op.flops = 2.0 * 24 * 3136 * 128; b.push(std::move(op)); }
+    { Op op; op.type = OP_ATTN; op.name = hp + "attn_pool_camshape"; op.in = Builder::R(heat); op.in2 = Builder::R(cs);
+      op.C = 64; op.out = Builder::R(flat, 0); op.flops = 2.0 * 24 * 3136 * 64; b.push(std::move(op)); }
+    int pose6d = b.new_act(144, 1, 1, true);
+    { const HostParam* w = b.P(hp + "pose_mlp.weight", {1, 6, 128, 24, 1, 1});
+      Op op; op.type = OP_LC2D; op.name = hp + "pose_mlp"; op.in = Builder::R(xu, 0); op.out = Builder::R(pose6d);
+      op.flops = 2.0 * 6 * 128 * 24;
+      if (!declare && w) op.wdev = b.upload(w->data);
+      b.push(std::move(op)); }
+    // shape_mlp (10) and cam_mlp (3) stacked into one [13,1536] matrix (pare_head.py:902-906)
+    const HostParam* sw = b.P(hp + "shape_mlp.weight", {10, 1536});
+    const HostParam* sb = b.P(hp + "shape_mlp.bias", {10});
+    const HostParam* cw = b.P(hp + "cam_mlp.weight", {3, 1536});
+    const HostParam* cb = b.P(hp + "cam_mlp.bias", {3});
+    HostParam scW, scB;
+    const bool have_sc = !declare && sw && sb && cw && cb;
+    if (have_sc) {
+      scW.shape = {13, 1536}; scB.shape = {13};
+      scW.data = sw->data; scW.data.insert(scW.data.end(), cw->data.begin(), cw->data.end());
+      scB.data = sb->data; scB.data.insert(scB.data.end(), cb->data.begin(), cb->data.end());
+    }
+    int sc13 = b.conv(hp + "shape_cam_mlp", "", "", Builder::R(flat), 1536, 13, 1, 1, 0, true, Ref(), 0, Ref(), nullptr, 0,
+                      true, true, have_sc ? &scW : nullptr, have_sc ? &scB : nullptr);
+    e.acts[sc13].persistent = true;
+    { Op op; op.type = OP_ROT6D; op.name = hp + "rot6d"; op.in = Builder::R(pose6d); op.out = Builder::R(xu, 3072);
+      op.out2 = Builder::X(Y_POSE); b.push(std::move(op)); }
+    for (const char* nm : {"temperature"}) b.P(hp + nm, {}, 0);
+    b.P(hp + "init_pose", {1, 144}, 0);
+    b.P(hp + "init_shape", {1, 10}, 0);
+    b.P(hp + "init_cam", {1, 3}, 0);
+    add_copy(b, "out.pred_pose6d", Builder::R(pose6d), Builder::X(Y_POSE6D), 144);
+    add_copy(b, "out.pred_shape", Builder::R(sc13, 0), Builder::X(Y_SHAPE), 10);
+    add_copy(b, "out.pred_cam", Builder::R(sc13, 10), Builder::X(Y_CAM), 3);
+    add_copy(b, "out.uncert_feat", Builder::R(xu, 0), Builder::X(Y_UFEAT), 3072);
+    { Op op; op.type = OP_NCHW_OUT; op.name = "out.pred_segm_mask"; op.in = Builder::R(heat); op.out = Builder::X(Y_SEGM);
+      op.C = 25; b.push(std::move(op)); }
+    e.uncert_feat_dim = 3072;
+    // rotmat for SMPL is read from the xu vector (channel 3072.., stride XU_DIM)
+    build_tail(b, Builder::R(sc13, 0), Builder::R(xu, 3072), Builder::R(sc13, 10), false);
+    // poco_head 'feat-pose' (poco_head.py:134-141): sigmoid(fc2(sigmoid(fc1([feat; R]))))
+    int h = b.conv(up + "uncert_fc1", up + "uncert_fc1", "", Builder::R(xu), 3288, 512, 1, 1, 2, true, Ref(), 0, Ref(),
+                   nullptr, XU_DIM, true);
+    int var = b.conv(up + "uncert_fc2", up + "uncert_fc2", "", Builder::R(h), 512, 24, 1, 1, 2, true, Ref(), 0, Ref(),
+                     nullptr, 0, true);
+    add_copy(b, "out.var_pose", Builder::R(var), Builder::X(Y_VAR), 24);
+    build_flow(b, 3072);
+  } else {
+    e.err = "unknown head " + e.head;
+    return false;
+  }
+  if (!b.ok) return false;
+  return true;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Workspace planning: big NHWC activations share memory by liveness; vectors are persistent.
+// ------------------------------------------------------------------------------------------------
+void touch(Engine& e, const Ref& r, int i) {
+  if (r.act < 0) return;
+  Act& a = e.acts[r.act];
+  a.first = std::min(a.first, i);
+  a.last = std::max(a.last, i);
+}
+
+void plan_workspace(Engine& e) {
+  for (int i = 0; i < (int)e.ops.size(); ++i) {
+    Op& op = e.ops[i];
+    touch(e, op.in, i); touch(e, op.in2, i); touch(e, op.res, i); touch(e, op.out, i); touch(e, op.out2, i);
+    for (int k = 0; k < op.fn; ++k) touch(e, op.fsrc[k], i);
+    if (op.type == OP_SMPL || op.type == OP_CAMERA) {
+      touch(e, e.smpl_betas, i); touch(e, e.smpl_rot, i); touch(e, e.cam_ref, i);
+    }
+  }
+  struct Blk { size_t off, size; };
+  std::vector<Blk> freelist;
+  size_t top = 0;
+  const size_t B = (size_t)e.max_batch;
+  auto align = [](size_t n) { return (n + 63) / 64 * 64; };
+  // persistent first
+  for (Act& a : e.acts)
+    if (a.persistent) { a.off = top; top += align(a.per_crop() * B); }
+  // events ordered by op index
+  std::vector<std::vector<int>> born(e.ops.size() + 1), dies(e.ops.size() + 1);
+  for (int k = 0; k < (int)e.acts.size(); ++k) {
+    const Act& a = e.acts[k];
+    if (a.persistent || a.last < 0) continue;
+    born[a.first].push_back(k);
+    dies[a.last].push_back(k);
+  }
+  for (int i = 0; i < (int)e.ops.size(); ++i) {
+    for (int k : born[i]) {
+      Act& a = e.acts[k];
+      const size_t need = align(a.per_crop() * B);
+      int best = -1;
+      for (int f = 0; f < (int)freelist.size(); ++f)
+        if (freelist[f].size >= need && (best < 0 || freelist[f].size < freelist[best].size)) best = f;
+      if (best >= 0) {
+        a.off = freelist[best].off;
+        if (freelist[best].size > need) { freelist[best].off += need; freelist[best].size -= need; }
+        else freelist.erase(freelist.begin() + best);
+      } else { a.off = top; top += need; }
+    }
+    for (int k : dies[i]) {
+      const Act& a = e.acts[k];
+      Blk nb{a.off, align(a.per_crop() * B)};
+      // coalesce with neighbours
+      for (int f = 0; f < (int)freelist.size();) {
+        if (freelist[f].off + freelist[f].size == nb.off) { nb.off = freelist[f].off; nb.size += freelist[f].size; freelist.erase(freelist.begin() + f); }
+        else if (nb.off + nb.size == freelist[f].off) { nb.size += freelist[f].size; freelist.erase(freelist.begin() + f); }
+        else ++f;
+      }
+      freelist.push_back(nb);
+    }
+  }
+  e.ws_floats = top;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Execution
+// ------------------------------------------------------------------------------------------------
+struct IO {
+  const poco_inputs_t* in;
+  const poco_outputs_t* out;
+};
+
+const float* ext_in(const IO& io, int slot) {
+  switch (slot) {
+    case X_IMG: return io.in->img;
+    case X_BBOX: return io.in->bbox_info;
+    case X_FOCAL: return io.in->focal_length;
+    case X_SCALE: return io.in->scale;
+    case X_CENTER: return io.in->center;
+    case X_ORIG: return io.in->orig_shape;
+    default: return nullptr;
+  }
+}
+float* ext_out(const IO& io, int slot) {
+  switch (slot) {
+    case Y_POSE: return io.out->pred_pose;
+    case Y_POSE6D: return io.out->pred_pose6d;
+    case Y_SHAPE: return io.out->pred_shape;
+    case Y_CAM: return io.out->pred_cam;
+    case Y_CAM_T: return io.out->pred_cam_t;
+    case Y_FULL_CAM_T: return io.out->pred_fullimg_cam_t;
+    case Y_VERTS: return io.out->smpl_vertices;
+    case Y_J3D: return io.out->smpl_joints3d;
+    case Y_J2D: return io.out->smpl_joints2d;
+    case Y_VAR: return io.out->var_pose;
+    case Y_UFEAT: return io.out->uncert_feat;
+    case Y_SEGM: return io.out->pred_segm_mask;
+    case Y_BODY2: return io.out->body_feat2;
+    default: return nullptr;
+  }
+}
+
+inline float* aptr(Engine& e, const Ref& r) { return e.ws + e.acts[r.act].off + r.co; }
+inline int astride(Engine& e, const Ref& r) { return e.acts[r.act].C; }   // valid for vector acts (H=W=1)
+
+int run_op(Engine& e, Op& op, int B, const IO& io, hipStream_t s) {
+  switch (op.type) {
+    case OP_STEM: {
+      const float* img = ext_in(io, X_IMG);
+      if (!img) { poco_set_error("forward: img is NULL"); return POCO_ERR_ARG; }
+      launch_stem_conv(img, op.wdev, op.bdev, aptr(e, op.out), B, op.n, op.n, op.ks, s);
+      return POCO_OK;
+    }
+    case OP_CONV: {
+      const Act& ai = e.acts[op.in.act];
+      const Act& ao = e.acts[op.out.act];
+      ConvDesc d{};
+      d.in = aptr(e, op.in); d.in_cs = ai.C; d.in_co = 0;
+      if (op.res.act >= 0) { d.res = aptr(e, op.res); d.res_cs = e.acts[op.res.act].C; }
+      d.out = aptr(e, op.out); d.out_cs = ao.C; d.out_co = 0;
+      d.wfrag = op.wdev; d.bias = op.bdev;
+      d.B = B; d.H = ai.H; d.W = ai.W; d.Cin = op.Cin; d.Cout = op.Cout; d.ks = op.ks; d.stride = op.stride;
+      d.act = op.actfn; d.res_after_act = op.res_after;
+      auto it = op.cfg.find(B);
+      if (it == op.cfg.end()) it = op.cfg.emplace(B, conv_default_cfg(d)).first;
+      return conv_launch(d, it->second, s);
+    }
+    case OP_MAXPOOL: {
+      const Act& a = e.acts[op.in.act];
+      launch_maxpool3x3s2(aptr(e, op.in), aptr(e, op.out), B, a.H, a.W, a.C, s);
+      return POCO_OK;
+    }
+    case OP_BILINEAR: {
+      const Act& a = e.acts[op.in.act];
+      launch_bilinear_up2x(aptr(e, op.in), aptr(e, op.out), B, a.H, a.W, a.C, s);
+      return POCO_OK;
+    }
+    case OP_FUSE: {
+      FuseArgs fa{};
+      fa.n = op.fn;
+      for (int k = 0; k < op.fn; ++k) { fa.src[k] = aptr(e, op.fsrc[k]); fa.shift[k] = op.fshift[k]; }
+      const Act& ao = e.acts[op.out.act];
+      // the i-th term (shift 0, identity branch) defines the output geometry
+      int H = 0, W = 0, C = 0;
+      for (int k = 0; k < op.fn; ++k)
+        if (op.fshift[k] == 0) { const Act& a = e.acts[op.fsrc[k].act]; H = a.H; W = a.W; C = a.C; }
+      launch_fuse_sum(fa, aptr(e, op.out), B, H, W, C, ao.C, op.frelu, s);
+      return POCO_OK;
+    }
+    case OP_AVGPOOL: {
+      const Act& a = e.acts[op.in.act];
+      launch_avgpool(aptr(e, op.in), aptr(e, op.out), B, a.H * a.W, a.C, astride(e, op.out), s);
+      return POCO_OK;
+    }
+    case OP_ATTN: {
+      const Act& ah = e.acts[op.in.act];
+      // scratch act was sized for one crop of C=128; its buffer is max_batch x that
+      launch_part_attention_pool_ws(aptr(e, op.in), ah.C, aptr(e, op.in2), op.C, aptr(e, op.out), astride(e, op.out), B,
+                                    ah.H * ah.W, e.ws + e.acts[e.a_attn_scratch].off, s);
+      return POCO_OK;
+    }
+    case OP_LC2D:
+      launch_lc2d_pose(aptr(e, op.in), astride(e, op.in), op.wdev, aptr(e, op.out), B, s);
+      return POCO_OK;
+    case OP_ROT6D: {
+      float* y = ext_out(io, op.out2.ext);
+      launch_rot6d(aptr(e, op.in), astride(e, op.in), aptr(e, op.out), astride(e, op.out), y, 216, B, s);
+      return POCO_OK;
+    }
+    case OP_COPY: {
+      const float* src; int sstride;
+      if (op.in.ext) { src = ext_in(io, op.in.ext); sstride = op.n; if (!src) { poco_set_error("forward: missing input for " + op.name); return POCO_ERR_ARG; } }
+      else { src = aptr(e, op.in); sstride = astride(e, op.in); }
+      float* dst; int dstride;
+      if (op.out.ext) { dst = ext_out(io, op.out.ext); dstride = op.n; if (!dst) return POCO_OK; }   // output not requested
+      else { dst = aptr(e, op.out); dstride = astride(e, op.out); }
+      launch_copy_rows(src, sstride, dst, dstride, op.n, B, s);
+      return POCO_OK;
+    }
+    case OP_BCAST:
+      launch_broadcast_rows(op.wdev, aptr(e, op.out), astride(e, op.out), op.n, B, s);
+      return POCO_OK;
+    case OP_SMPL: {
+      SmplIO sio{};
+      sio.betas = aptr(e, e.smpl_betas); sio.betas_stride = astride(e, e.smpl_betas);
+      sio.rotmat = aptr(e, e.smpl_rot); sio.rot_stride = astride(e, e.smpl_rot);
+      sio.A = e.ws + e.acts[e.a_A].off;
+      sio.joints24 = e.ws + e.acts[e.a_j24].off;
+      float* yv = io.out->smpl_vertices;
+      sio.verts = yv ? yv : e.ws + e.acts[e.a_verts].off;
+      float* yj = io.out->smpl_joints3d;
+      sio.joints49 = e.ws + e.acts[e.a_j49].off;
+      launch_smpl_lbs(e.smpl, sio, B, s);
+      if (yj) launch_copy_rows(sio.joints49, 147, yj, 147, 147, B, s);
+      return POCO_OK;
+    }
+    case OP_CAMERA: {
+      CamArgs c{};
+      c.cam = aptr(e, e.cam_ref); c.cam_stride = astride(e, e.cam_ref);
+      c.joints49 = e.ws + e.acts[e.a_j49].off;
+      c.cliff = op.n;
+      if (c.cliff) {
+        c.focal = io.in->focal_length; c.scale = io.in->scale; c.center = io.in->center; c.orig_shape = io.in->orig_shape;
+        if (!c.focal || !c.scale || !c.center || !c.orig_shape) { poco_set_error("forward: cliff variant needs focal_length/scale/center/orig_shape"); return POCO_ERR_ARG; }
+      }
+      // outputs the caller did not ask for go to scratch rows (the kernel writes them densely)
+      c.cam_t = io.out->pred_cam_t ? io.out->pred_cam_t : e.ws + e.acts[e.a_camt].off;
+      c.fullimg_cam_t = io.out->pred_fullimg_cam_t ? io.out->pred_fullimg_cam_t : e.ws + e.acts[e.a_fullt].off;
+      c.joints2d = io.out->smpl_joints2d ? io.out->smpl_joints2d : e.ws + e.acts[e.a_j2d].off;
+      launch_camera(c, B, s);
+      return POCO_OK;
+    }
+    case OP_NCHW_OUT: {
+      float* y = ext_out(io, op.out.ext);
+      if (!y) return POCO_OK;
+      const Act& a = e.acts[op.in.act];
+      launch_nhwc_to_nchw(aptr(e, op.in), a.C, y, B, a.H * a.W, op.C, s);
+      return POCO_OK;
+    }
+  }
+  return POCO_ERR_STATE;
+}
+
+Engine* H(poco_handle_t h) { return reinterpret_cast<Engine*>(h); }
+
+}  // namespace
+
+// ================================================================================================
+// C ABI
+// ================================================================================================
+extern "C" int poco_create(const char* variant, int max_batch, int num_flow_layers, poco_handle_t* out) {
+  if (!variant || !out || max_batch < 1) { poco_set_error("poco_create: bad arguments"); return POCO_ERR_ARG; }
+  std::string v(variant);
+  const size_t dash = v.find('-');
+  if (dash == std::string::npos) { poco_set_error("variant must be '<backbone>-<head>' (poco.py:41)"); return POCO_ERR_ARG; }
+  auto e = std::make_unique<Engine>();
+  e->backbone = v.substr(0, dash);
+  e->head = v.substr(dash + 1);
+  e->max_batch = max_batch;
+  e->flow_layers = num_flow_layers;
+  if (!build_graph(*e, /*declare=*/true)) { poco_set_error("poco_create: " + e->err); return POCO_ERR_ARG; }
+  *out = reinterpret_cast<poco_handle_t>(e.release());
+  return POCO_OK;
+}
+
+extern "C" void poco_destroy(poco_handle_t h) { delete H(h); }
+
+extern "C" int poco_num_tensors(poco_handle_t h) { return h ? (int)H(h)->decls.size() : -1; }
+
+extern "C" int poco_tensor_info(poco_handle_t h, int i, char* name, size_t name_cap, int64_t* shape, int* rank,
+                                int* required) {
+  Engine* e = H(h);
+  if (!e || i < 0 || i >= (int)e->decls.size()) { poco_set_error("poco_tensor_info: index out of range"); return POCO_ERR_ARG; }
+  const ParamDecl& d = e->decls[i];
+  if (name && name_cap) { std::strncpy(name, d.name.c_str(), name_cap - 1); name[name_cap - 1] = 0; }
+  if (rank) *rank = (int)d.shape.size();
+  if (shape) for (size_t k = 0; k < d.shape.size() && k < 6; ++k) shape[k] = d.shape[k];
+  if (required) *required = d.required;
+  return POCO_OK;
+}
+
+extern "C" int poco_load_tensor(poco_handle_t h, const char* name, const float* host_data, const int64_t* shape, int rank) {
+  Engine* e = H(h);
+  if (!e || !name || (!host_data && rank >= 0)) { poco_set_error("poco_load_tensor: bad arguments"); return POCO_ERR_ARG; }
+  if (e->finalized) { poco_set_error("poco_load_tensor: engine already finalized"); return POCO_ERR_STATE; }
+  auto it = e->decl_index.find(name);
+  if (it == e->decl_index.end()) { poco_set_error(std::string("unexpected tensor: ") + name); return POCO_ERR_MISSING; }
+  const ParamDecl& d = e->decls[it->second];
+  size_t n = 1, nd = 1;
+  for (int k = 0; k < rank; ++k) n *= (size_t)shape[k];
+  for (int64_t s : d.shape) nd *= (size_t)s;
+  if (n != nd) {
+    poco_set_error(std::string("shape mismatch for ") + name + ": got " + std::to_string(n) + " elements, expected " + std::to_string(nd));
+    return POCO_ERR_SHAPE;
+  }
+  HostParam p;
+  p.shape.assign(shape, shape + rank);
+  p.data.assign(host_data, host_data + n);
+  e->params[name] = std::move(p);
+  return POCO_OK;
+}
+
+extern "C" int poco_finalize(poco_handle_t h) {
+  Engine* e = H(h);
+  if (!e) return POCO_ERR_ARG;
+  if (e->finalized) return POCO_OK;
+  std::string missing;
+  for (const ParamDecl& d : e->decls)
+    if (d.required && !e->params.count(d.name)) missing += d.name + " ";
+  if (!missing.empty()) { poco_set_error("poco_finalize: missing required tensors: " + missing); return POCO_ERR_MISSING; }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { poco_set_error("poco_finalize: no HIP device (there is no CPU fallback)"); return POCO_ERR_HIP; }
+  e->err.clear();
+  if (!build_graph(*e, /*declare=*/false)) { poco_set_error("poco_finalize: " + e->err); return POCO_ERR_STATE; }
+  plan_workspace(*e);
+  POCO_HIP_CHECK(hipMalloc(&e->ws, e->ws_floats * sizeof(float)));
+  POCO_HIP_CHECK(hipMemset(e->ws, 0, e->ws_floats * sizeof(float)));
+  POCO_HIP_CHECK(hipDeviceSynchronize());
+  e->params.clear();   // host copies no longer needed
+  e->finalized = true;
+  return POCO_OK;
+}
+
+extern "C" int poco_forward(poco_handle_t h, int B, const poco_inputs_t* in, const poco_outputs_t* out, void* stream) {
+  Engine* e = H(h);
+  if (!e || !in || !out) { poco_set_error("poco_forward: bad arguments"); return POCO_ERR_ARG; }
+  if (!e->finalized) { poco_set_error("poco_forward: call poco_finalize first"); return POCO_ERR_STATE; }
+  if (B < 1 || B > e->max_batch) { poco_set_error("poco_forward: batch " + std::to_string(B) + " outside 1.." + std::to_string(e->max_batch)); return POCO_ERR_ARG; }
+  IO io{in, out};
+  for (Op& op : e->ops) {
+    int rc = run_op(*e, op, B, io, (hipStream_t)stream);
+    if (rc != POCO_OK) return rc;
+  }
+  hipError_t err = hipGetLastError();
+  if (err != hipSuccess) { poco_set_error(std::string("poco_forward: ") + hipGetErrorString(err)); return POCO_ERR_HIP; }
+  return POCO_OK;
+}
+
+extern "C" int poco_num_ops(poco_handle_t h) { return h ? (int)H(h)->ops.size() : -1; }
+
+extern "C" int poco_op_info(poco_handle_t h, int i, char* name, size_t name_cap, double* flops_per_crop, int* type) {
+  Engine* e = H(h);
+  if (!e || i < 0 || i >= (int)e->ops.size()) { poco_set_error("poco_op_info: index out of range"); return POCO_ERR_ARG; }
+  const Op& op = e->ops[i];
+  if (name && name_cap) { std::strncpy(name, op.name.c_str(), name_cap - 1); name[name_cap - 1] = 0; }
+  if (flops_per_crop) *flops_per_crop = op.flops;
+  if (type) *type = op.type;
+  return POCO_OK;
+}
+
+extern "C" int poco_profile_ops(poco_handle_t h, int B, const poco_inputs_t* in, const poco_outputs_t* out, int iters,
+                                float* ms_per_op, int cap, void* stream) {
+  Engine* e = H(h);
+  if (!e || !e->finalized || !ms_per_op) { poco_set_error("poco_profile_ops: bad state/arguments"); return POCO_ERR_ARG; }
+  const int n = (int)e->ops.size();
+  if (cap < n) { poco_set_error("poco_profile_ops: buffer too small"); return POCO_ERR_ARG; }
+  hipStream_t s = (hipStream_t)stream;
+  std::vector<hipEvent_t> ev(n + 1);
+  for (auto& x : ev) POCO_HIP_CHECK(hipEventCreate(&x));
+  std::vector<double> acc(n, 0.0);
+  IO io{in, out};
+  for (int it = 0; it < iters + 1; ++it) {
+    POCO_HIP_CHECK(hipEventRecord(ev[0], s));
+    for (int i = 0; i < n; ++i) {
+      int rc = run_op(*e, e->ops[i], B, io, s);
+      if (rc != POCO_OK) return rc;
+      POCO_HIP_CHECK(hipEventRecord(ev[i + 1], s));
+    }
+    POCO_HIP_CHECK(hipStreamSynchronize(s));
+    if (it == 0) continue;   // warm-up
+    for (int i = 0; i < n; ++i) { float ms = 0; POCO_HIP_CHECK(hipEventElapsedTime(&ms, ev[i], ev[i + 1])); acc[i] += ms; }
+  }
+  for (int i = 0; i < n; ++i) ms_per_op[i] = (float)(acc[i] / iters);
+  for (auto& x : ev) (void)hipEventDestroy(x);
+  return POCO_OK;
+}
+
+extern "C" size_t poco_workspace_bytes(poco_handle_t h) { return h ? H(h)->ws_floats * sizeof(float) : 0; }
+
+extern "C" int poco_uncert_feat_dim(poco_handle_t h) { return h ? H(h)->uncert_feat_dim : -1; }
+
+extern "C" int poco_set_conv_cfg(poco_handle_t h, int op_index, int B, const int* cfg6) {
+  Engine* e = H(h);
+  if (!e || op_index < 0 || op_index >= (int)e->ops.size() || !cfg6 || e->ops[op_index].type != OP_CONV) {
+    poco_set_error("poco_set_conv_cfg: bad arguments");
+    return POCO_ERR_ARG;
+  }
+  e->ops[op_index].cfg[B] = ConvCfg{cfg6[0], cfg6[1], cfg6[2], cfg6[3], cfg6[4], cfg6[5]};
+  return POCO_OK;
+}
+
+extern "C" int poco_get_conv_desc(poco_handle_t h, int op_index, int* desc8) {
+  Engine* e = H(h);
+  if (!e || op_index < 0 || op_index >= (int)e->ops.size() || !desc8) return POCO_ERR_ARG;
+  const Op& op = e->ops[op_index];
+  if (op.type != OP_CONV) return POCO_ERR_ARG;
+  const Act& ai = e->acts[op.in.act];
+  desc8[0] = ai.H; desc8[1] = ai.W; desc8[2] = op.Cin; desc8[3] = op.Cout; desc8[4] = op.ks; desc8[5] = op.stride;
+  desc8[6] = ai.C; desc8[7] = e->acts[op.out.act].C;
+  return POCO_OK;
+}
+
+// ---- stand-alone SMPL / RealNVP operators bound to an engine's loaded model -----------------------
+extern "C" int poco_smpl_lbs(poco_handle_t h, int B, const float* d_betas, const float* d_rotmat, float* d_verts,
+                             float* d_joints49, void* stream) {
+  Engine* e = H(h);
+  if (!e || !e->finalized || !d_betas || !d_rotmat || !d_verts || !d_joints49 || B < 1 || B > e->max_batch) {
+    poco_set_error("poco_smpl_lbs: bad state/arguments");
+    return POCO_ERR_ARG;
+  }
+  SmplIO sio{};
+  sio.betas = d_betas; sio.betas_stride = 10;
+  sio.rotmat = d_rotmat; sio.rot_stride = 216;
+  sio.A = e->ws + e->acts[e->a_A].off;
+  sio.joints24 = e->ws + e->acts[e->a_j24].off;
+  sio.verts = d_verts;
+  sio.joints49 = d_joints49;
+  launch_smpl_lbs(e->smpl, sio, B, (hipStream_t)stream);
+  return POCO_OK;
+}
+
+extern "C" int poco_realnvp(poco_handle_t h, int N, const float* d_x, const float* d_ctx, float* d_out, int forward,
+                            void* stream) {
+  Engine* e = H(h);
+  if (!e || !e->finalized || !e->has_flow) { poco_set_error("poco_realnvp: flow_head.flow.* tensors were not loaded"); return POCO_ERR_STATE; }
+  if (!d_x || !d_ctx || !d_out || N < 1) { poco_set_error("poco_realnvp: bad arguments"); return POCO_ERR_ARG; }
+  launch_realnvp(e->flow, d_x, d_ctx, d_out, N, forward, (hipStream_t)stream);
+  return POCO_OK;
+}

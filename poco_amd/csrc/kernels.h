@@ -1,0 +1,99 @@
+// Launchers of the non-GEMM kernels (all enqueue on `stream`, no allocation, no sync).
+#pragma once
+#include "common.h"
+
+// ---- backbone side kernels (kernels_misc.hip) ---------------------------------------------------
+// Direct small-Cin stem conv (Cin = 3): NCHW image -> NHWC features, + shift, ReLU.
+//   ks=3,stride 2,pad 1 : hrnet.py:467-469 ;  ks=7,stride 2,pad 3 : resnet.py:203-205
+// w: [ks*ks*3][Cout] (tap-major, scale folded), shift [Cout]; Cout must be 64.
+void launch_stem_conv(const float* img_nchw, const float* w, const float* shift, float* out_nhwc, int B,
+                      int H, int W, int ks, hipStream_t s);
+// 3x3 stride-2 pad-1 max pool, NHWC (resnet.py:206).
+void launch_maxpool3x3s2(const float* in, float* out, int B, int H, int W, int C, hipStream_t s);
+// x2 bilinear upsample, align_corners=True, NHWC (hrnet.py:440).
+void launch_bilinear_up2x(const float* in, float* out, int B, int H, int W, int C, hipStream_t s);
+// out = ReLU( sum_k addend_k[b, y >> shift_k, x >> shift_k, :] )  (HRNet fuse, hrnet.py:257-264).
+struct FuseArgs {
+  const float* src[4];
+  int shift[4];
+  int n;
+};
+// `out` points at the first output channel; out_cs = channels per pixel of the destination buffer.
+void launch_fuse_sum(const FuseArgs& a, float* out, int B, int H, int W, int C, int out_cs, int relu, hipStream_t s);
+// Global average pool NHWC [B,HW,C] -> dst[b*dst_stride + c] (hrnet_cls.py:482, cliff_head.py:96).
+void launch_avgpool(const float* in, float* dst, int B, int HW, int C, int dst_stride, hipStream_t s);
+
+// ---- head kernels (kernels_head.hip) ---------------------------------------------------------------
+// Part attention pooling (KeypointAttention, layers/keypoint_attention.py:34-48):
+//   out[b, c, j] = sum_p softmax_p(heat[b,p,1+j]) * feat[b,p,c]      (24 parts; heat channel 0 = bg)
+// heat: NHWC [B,HW,heat_cs] ; feat: NHWC [B,HW,C] ; out: dst[b*dst_stride + c*24 + j] (channel-major).
+// scratch: part_attention_scratch_floats(B, C) floats.  C <= 128.
+size_t part_attention_scratch_floats(int B, int C);
+void launch_part_attention_pool_ws(const float* heat, int heat_cs, const float* feat, int C, float* dst,
+                                   int dst_stride, int B, int HW, float* scratch, hipStream_t s);
+// LocallyConnected2d 128->6 per joint (layers/locallyconnected2d.py:27-37):
+//   pose6d[b, j, o] = sum_c x[b*x_stride + c*24 + j] * w[o][c][j]
+void launch_lc2d_pose(const float* x, int x_stride, const float* w /*[6][128][24]*/, float* pose6d /*[B,144]*/,
+                      int B, hipStream_t s);
+// rot6d -> rotmat (utils/geometry.py:247-261). in: [B, in_stride] holding 144 floats (24 x (3x2));
+// writes rotmat (24*9 per crop) to up to two destinations (stride in floats, nullable).
+void launch_rot6d(const float* in, int in_stride, float* dst0, int stride0, float* dst1, int stride1, int B,
+                  hipStream_t s);
+// Strided row copy: dst[b*dst_stride + i] = src[b*src_stride + i], i < n.
+void launch_copy_rows(const float* src, int src_stride, float* dst, int dst_stride, int n, int B,
+                      hipStream_t s);
+// dst[b*dst_stride + i] = src[i] (broadcast an init vector into every crop's row).
+void launch_broadcast_rows(const float* src, float* dst, int dst_stride, int n, int B, hipStream_t s);
+// NHWC [B,HW,cs] (first C channels) -> NCHW [B,C,HW]
+void launch_nhwc_to_nchw(const float* in, int cs, float* out, int B, int HW, int C, hipStream_t s);
+
+// ---- SMPL (kernels_smpl.hip) -------------------------------------------------------------------------
+struct SmplDev {
+  int V;                       // 6890
+  const float* v_template;     // [V,3]
+  const float* shapedirs;      // [10][V*3]   (transposed for coalescing)
+  const float* posedirs;       // [207][V*3]
+  const float* lbs_weights;    // [V,24]
+  const float* J_template;     // [24,3]      J_regressor . v_template
+  const float* J_shapedirs;    // [24,3,10]   J_regressor . shapedirs
+  const float* J_regressor_extra;  // [9,V]
+  const int* parents;          // [24]
+  const int* extra_vertex_ids; // [21]
+  const int* joint_map;        // [49]
+};
+struct SmplIO {
+  const float* betas;  int betas_stride;    // [B,10]
+  const float* rotmat; int rot_stride;      // [B,216]
+  float* A;                                 // scratch [B,24,12]
+  float* joints24;                          // scratch [B,24,3]
+  float* verts;                             // [B,V,3] output
+  float* joints49;                          // [B,49,3] output
+};
+// smplx.lbs.lbs restated + the 49-joint wrapper of smpl_head.py:22-34.
+void launch_smpl_lbs(const SmplDev& m, const SmplIO& io, int B, hipStream_t s);
+
+struct CamArgs {
+  const float* cam; int cam_stride;   // [B,3] (s,tx,ty)
+  const float* joints49;              // [B,49,3]
+  // cliff only (nullable for pare):
+  const float* focal; const float* scale; const float* center; const float* orig_shape;
+  float* cam_t;          // [B,3]
+  float* fullimg_cam_t;  // [B,3] (cliff) nullable
+  float* joints2d;       // [B,49,2]
+  int cliff;
+};
+// smpl_head.py:63-78 (pare) / smplcam_head.py:65-90 (cliff) camera conversion + projection.
+void launch_camera(const CamArgs& a, int B, hipStream_t s);
+
+// ---- RealNVP (kernels_flow.hip) -----------------------------------------------------------------------
+struct FlowDev {
+  int L;               // number of coupling layers (rows of mask)
+  int ctx;             // context dim (512)
+  const float* mask;   // [L,9]
+  // per layer, nets s and t: W0t [521][64] (input-major), b0[64], W1t [64][64], b1[64], W2 [9][64], b2[9]
+  const float* w0t[2]; const float* b0[2]; const float* w1t[2]; const float* b1[2];
+  const float* w2[2];  const float* b2[2];
+};
+// log_prob (backward_p + N(0,I) prior, layers/real_nvp.py:40-65) or forward_p (:25-38).
+void launch_realnvp(const FlowDev& f, const float* x, const float* ctx, float* out, int N, int forward,
+                    hipStream_t s);

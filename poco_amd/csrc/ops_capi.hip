@@ -52,7 +52,7 @@ static int conv_common(const float* d_in, int B, int H, int W, int Cin, const fl
   d.out = d_out; d.out_cs = Cout; d.out_co = 0;
   d.wfrag = dw.p; d.bias = db.p;
   d.B = B; d.H = H; d.W = W; d.Cin = Cin; d.Cout = Cout16;
-  d.ks = ks; d.stride = stride; d.relu = relu;
+  d.ks = ks; d.stride = stride; d.act = relu; d.res_after_act = 0;
   ConvCfg cfg = conv_default_cfg(d);
   if (cfg6 && cfg6[0] > 0) cfg = ConvCfg{cfg6[0], cfg6[1], cfg6[2], cfg6[3], cfg6[4], cfg6[5]};
   int rc = conv_launch(d, cfg, stream);

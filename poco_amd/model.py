@@ -1,0 +1,294 @@
+"""Host-side mirror of the reference's model interface for the MI355X engine.
+
+`POCO(backbone=..., **cfg.POCO, pretrained=ckpt)` + `model(batch) -> dict` with the same ctor
+kwargs, batch fields and output keys as pocolib/models/poco.py:13-129, so that it drops in at the
+reference's seam `output = self.model(batch)` (pocolib/core/tester.py:213,408).
+
+This file is plumbing only: it moves names, shapes and raw pointers across the C ABI
+(include/poco_hip.h).  All arithmetic runs in libpoco_hip.so; there is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+from typing import Dict, Iterable, List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from ._lib import PocoHipError, check, lib
+
+SMPL_KEYS = ("v_template", "shapedirs", "posedirs", "J_regressor", "J_regressor_extra", "lbs_weights",
+             "parents", "extra_vertex_ids", "joint_map")
+
+
+class _Inputs(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("img", "bbox_info", "focal_length", "scale", "center", "orig_shape")]
+
+
+class _Outputs(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in (
+        "pred_pose", "pred_pose6d", "pred_shape", "pred_cam", "pred_cam_t", "pred_fullimg_cam_t", "smpl_vertices",
+        "smpl_joints3d", "smpl_joints2d", "var_pose", "uncert_feat", "pred_segm_mask", "body_feat2")]
+
+
+def _bind():
+    L = lib()
+    L.poco_create.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+    L.poco_destroy.argtypes = [C.c_void_p]
+    L.poco_destroy.restype = None
+    L.poco_num_tensors.argtypes = [C.c_void_p]
+    L.poco_tensor_info.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_size_t, C.POINTER(C.c_int64),
+                                   C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.poco_load_tensor.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int]
+    L.poco_finalize.argtypes = [C.c_void_p]
+    L.poco_forward.argtypes = [C.c_void_p, C.c_int, C.POINTER(_Inputs), C.POINTER(_Outputs), C.c_void_p]
+    L.poco_num_ops.argtypes = [C.c_void_p]
+    L.poco_op_info.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_size_t, C.POINTER(C.c_double), C.POINTER(C.c_int)]
+    L.poco_profile_ops.argtypes = [C.c_void_p, C.c_int, C.POINTER(_Inputs), C.POINTER(_Outputs), C.c_int,
+                                   C.POINTER(C.c_float), C.c_int, C.c_void_p]
+    L.poco_workspace_bytes.argtypes = [C.c_void_p]
+    L.poco_workspace_bytes.restype = C.c_size_t
+    L.poco_uncert_feat_dim.argtypes = [C.c_void_p]
+    L.poco_set_conv_cfg.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int)]
+    L.poco_get_conv_desc.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+    L.poco_smpl_lbs.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 5
+    L.poco_realnvp.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    return L
+
+
+def _stream() -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class POCO:
+    """Drop-in for pocolib.models.POCO (inference only).
+
+    Extra kwargs on top of the reference ctor: `max_batch` (workspace is planned once for it),
+    `smpl` (dict or .npz path of the SMPL-shaped body model; the reference reads data/smpl),
+    `device`.
+    """
+
+    def __init__(self, backbone="resnet50-cliff", img_res=224, uncert_layer="diff_branch", activation_type="sigmoid",
+                 uncert_type=("pose",), uncert_inp_type="feat", loss_ver="norm_flow_res_gaus", num_neurons="1024-512",
+                 num_flow_layers=3, sigma_dim=1, num_nf_rv=9, mask_params_id="", nflow_mask_type="alter",
+                 exclude_uncert_idx="", use_dropout=False, use_iter_feats=False, cond_nflow=True, context_dim=512,
+                 gt_pose_cond=False, gt_pose_cond_ds="h36m", gt_pose_cond_ratio=0.25, pretrained=None,
+                 inf_model="best", is_test=True, *, max_batch=64, smpl=None, device="cuda:0"):
+        if img_res != 224:
+            raise ValueError("the engine is built for 224x224 crops (configs/demo_poco_*.yaml DATASET.IMG_RES)")
+        if uncert_layer != "diff_branch" or activation_type != "sigmoid" or sigma_dim != 1 or num_nf_rv != 9:
+            raise ValueError("only the shipped POCO configuration is supported "
+                             "(UNCERT_LAYER diff_branch, ACTIVATION_TYPE sigmoid, SIGMA_DIM 1, NUM_NF_RV 9)")
+        self.backbone_name, self.head_name = backbone.split("-")
+        self.variant = backbone
+        self.max_batch = int(max_batch)
+        self.num_flow_layers = int(num_flow_layers)
+        self.inf_model = inf_model
+        self.device = torch.device(device)
+        self._L = _bind()
+        self._h = C.c_void_p()
+        check(self._L.poco_create(backbone.encode(), self.max_batch, self.num_flow_layers, C.byref(self._h)),
+              "poco_create")
+        self._finalized = False
+        self._loaded = set()
+        if smpl is not None:
+            self.load_smpl(smpl)
+        if pretrained is not None:
+            self.load_pretrained(pretrained)
+
+    # ---- reference-compatible no-ops ---------------------------------------------------------
+    def eval(self):
+        return self
+
+    def to(self, *a, **k):
+        return self
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None) and self._h.value:
+                self._L.poco_destroy(self._h)
+                self._h = C.c_void_p()
+        except Exception:
+            pass
+
+    # ---- tensors -------------------------------------------------------------------------------
+    def expected_tensors(self) -> List[Tuple[str, Tuple[int, ...], bool]]:
+        out = []
+        name = C.create_string_buffer(256)
+        shape = (C.c_int64 * 6)()
+        rank, req = C.c_int(), C.c_int()
+        for i in range(self._L.poco_num_tensors(self._h)):
+            check(self._L.poco_tensor_info(self._h, i, name, 256, shape, C.byref(rank), C.byref(req)), "poco_tensor_info")
+            out.append((name.value.decode(), tuple(shape[k] for k in range(rank.value)), bool(req.value)))
+        return out
+
+    def _load_one(self, name: str, arr) -> None:
+        if isinstance(arr, torch.Tensor):
+            arr = arr.detach().cpu().numpy()
+        arr = np.ascontiguousarray(arr, dtype=np.float32)
+        shp = (C.c_int64 * max(1, arr.ndim))(*arr.shape)
+        check(self._L.poco_load_tensor(self._h, name.encode(), C.c_void_p(arr.ctypes.data), shp, arr.ndim),
+              f"poco_load_tensor({name})")
+        self._loaded.add(name)
+
+    def load_state_dict(self, state_dict: Dict[str, object], strict: bool = True):
+        """Keys as in the reference checkpoint after `model.` stripping: backbone.*, head.*,
+        uncert_head.*, flow_head.*  (pocolib/utils/train_utils.py:69-90).  strict: every key must
+        be known to the engine and (at finalize) every required tensor present."""
+        known = {n for n, _, _ in self.expected_tensors()}
+        unexpected = []
+        for k, v in state_dict.items():
+            k = k[len("model."):] if k.startswith("model.") else k
+            if k not in known:
+                unexpected.append(k)
+                continue
+            self._load_one(k, v)
+        if unexpected and strict:
+            raise PocoHipError(f"unexpected keys in state_dict: {unexpected[:8]}{' ...' if len(unexpected) > 8 else ''}")
+        return unexpected
+
+    def load_smpl(self, smpl) -> None:
+        if isinstance(smpl, (str, Path)):
+            smpl = dict(np.load(str(smpl)))
+        for k in SMPL_KEYS:
+            self._load_one("smpl." + k, np.asarray(smpl[k], dtype=np.float32))
+
+    def load_pretrained(self, file) -> None:
+        """pocolib/models/poco.py:131-154 (torch checkpoint -> state_dict -> per-part prefixes)."""
+        from .checkpoint import read_checkpoint
+        self.load_state_dict(read_checkpoint(file, self.inf_model), strict=True)
+
+    def finalize(self) -> "POCO":
+        if not self._finalized:
+            torch.cuda.set_device(self.device)
+            check(self._L.poco_finalize(self._h), "poco_finalize")
+            self._finalized = True
+        return self
+
+    # ---- forward ---------------------------------------------------------------------------------
+    def _alloc_outputs(self, B: int, want_segm: bool) -> Dict[str, torch.Tensor]:
+        d = self.device
+        f = torch.float32
+        ufd = self._L.poco_uncert_feat_dim(self._h)
+        o = {
+            "smpl_vertices": torch.empty(B, 6890, 3, device=d, dtype=f),
+            "smpl_joints3d": torch.empty(B, 49, 3, device=d, dtype=f),
+            "smpl_joints2d": torch.empty(B, 49, 2, device=d, dtype=f),
+            "pred_cam_t": torch.empty(B, 3, device=d, dtype=f),
+            "pred_pose": torch.empty(B, 24, 3, 3, device=d, dtype=f),
+            "pred_cam": torch.empty(B, 3, device=d, dtype=f),
+            "pred_shape": torch.empty(B, 10, device=d, dtype=f),
+            "uncert_feat": torch.empty(B, ufd, device=d, dtype=f),
+            "var_pose": torch.empty(B, 24, device=d, dtype=f),
+        }
+        if self.head_name == "cliff":
+            o["pred_fullimg_cam_t"] = torch.empty(B, 3, device=d, dtype=f)
+            o["pred_pose_6d"] = torch.empty(B, 144, device=d, dtype=f)
+            o["body_feat2"] = torch.empty(B, 1024, device=d, dtype=f)
+        else:
+            o["pred_pose6d"] = torch.empty(B, 24, 6, device=d, dtype=f)
+            if want_segm:
+                o["pred_segm_mask"] = torch.empty(B, 25, 56, 56, device=d, dtype=f)
+        return o
+
+    def _pack_io(self, batch, out):
+        def dp(t):
+            if t is None:
+                return None
+            if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+                raise PocoHipError("batch tensors must be contiguous float32 CUDA tensors")
+            return t.data_ptr()
+
+        img = batch["img"]
+        B = img.shape[0]
+        if tuple(img.shape[1:]) != (3, 224, 224):
+            raise PocoHipError(f"img must be [B,3,224,224], got {tuple(img.shape)}")
+        if self.head_name == "cliff":
+            orig = batch["orig_shape"].to(torch.float32).contiguous()
+            ins = _Inputs(dp(img), dp(batch["bbox_info"].contiguous()), dp(batch["focal_length"].to(torch.float32).contiguous()),
+                          dp(batch["scale"].to(torch.float32).contiguous()), dp(batch["center"].to(torch.float32).contiguous()),
+                          dp(orig))
+            keep = (orig,)
+        else:
+            ins = _Inputs(dp(img), None, None, None, None, None)
+            keep = ()
+        g = out.get
+        outs = _Outputs(dp(g("pred_pose")), dp(g("pred_pose6d", g("pred_pose_6d"))), dp(g("pred_shape")), dp(g("pred_cam")),
+                        dp(g("pred_cam_t")), dp(g("pred_fullimg_cam_t")), dp(g("smpl_vertices")), dp(g("smpl_joints3d")),
+                        dp(g("smpl_joints2d")), dp(g("var_pose")), dp(g("uncert_feat")), dp(g("pred_segm_mask")),
+                        dp(g("body_feat2")))
+        return B, ins, outs, keep
+
+    @torch.no_grad()
+    def __call__(self, batch: Dict[str, torch.Tensor], out: Optional[Dict[str, torch.Tensor]] = None,
+                 want_segm: bool = True) -> Dict[str, object]:
+        self.finalize()
+        B = batch["img"].shape[0]
+        if out is None:
+            out = self._alloc_outputs(B, want_segm)
+        B, ins, outs, _keep = self._pack_io(batch, out)
+        check(self._L.poco_forward(self._h, B, C.byref(ins), C.byref(outs), _stream()), "poco_forward")
+        res = dict(out)
+        res["log_phi"] = None            # nf_head.py:129-136: not evaluated at inference
+        res["gt_pose_cond_idx"] = []     # poco_head.py:100,150
+        return res
+
+    forward = __call__
+
+    # ---- introspection / stand-alone ops -----------------------------------------------------------
+    def ops(self):
+        name = C.create_string_buffer(256)
+        fl, ty = C.c_double(), C.c_int()
+        out = []
+        for i in range(self._L.poco_num_ops(self._h)):
+            check(self._L.poco_op_info(self._h, i, name, 256, C.byref(fl), C.byref(ty)), "poco_op_info")
+            out.append((name.value.decode(), fl.value, ty.value))
+        return out
+
+    def profile_ops(self, batch, iters=5):
+        self.finalize()
+        B = batch["img"].shape[0]
+        out = self._alloc_outputs(B, True)
+        B, ins, outs, _keep = self._pack_io(batch, out)
+        n = self._L.poco_num_ops(self._h)
+        ms = (C.c_float * n)()
+        check(self._L.poco_profile_ops(self._h, B, C.byref(ins), C.byref(outs), iters, ms, n, _stream()), "poco_profile_ops")
+        return [(nm, fl, ty, ms[i]) for i, (nm, fl, ty) in enumerate(self.ops())]
+
+    def conv_desc(self, op_index: int):
+        d = (C.c_int * 8)()
+        rc = self._L.poco_get_conv_desc(self._h, op_index, d)
+        return None if rc != 0 else tuple(d)
+
+    def set_conv_cfg(self, op_index: int, B: int, cfg) -> None:
+        arr = (C.c_int * 6)(*cfg)
+        check(self._L.poco_set_conv_cfg(self._h, op_index, B, arr), "poco_set_conv_cfg")
+
+    def workspace_bytes(self) -> int:
+        return int(self._L.poco_workspace_bytes(self._h))
+
+    def smpl_lbs(self, betas: torch.Tensor, rotmat: torch.Tensor):
+        self.finalize()
+        B = betas.shape[0]
+        verts = torch.empty(B, 6890, 3, device=self.device, dtype=torch.float32)
+        j49 = torch.empty(B, 49, 3, device=self.device, dtype=torch.float32)
+        check(self._L.poco_smpl_lbs(self._h, B, betas.contiguous().data_ptr(), rotmat.contiguous().data_ptr(),
+                                    verts.data_ptr(), j49.data_ptr(), _stream()), "poco_smpl_lbs")
+        return verts, j49
+
+    def realnvp_log_prob(self, x: torch.Tensor, ctx: torch.Tensor) -> torch.Tensor:
+        self.finalize()
+        N = x.shape[0]
+        out = torch.empty(N, device=self.device, dtype=torch.float32)
+        check(self._L.poco_realnvp(self._h, N, x.contiguous().data_ptr(), ctx.contiguous().data_ptr(), out.data_ptr(), 0,
+                                   _stream()), "poco_realnvp")
+        return out
+
+    def realnvp_forward(self, z: torch.Tensor, ctx: torch.Tensor) -> torch.Tensor:
+        self.finalize()
+        N = z.shape[0]
+        out = torch.empty(N, 9, device=self.device, dtype=torch.float32)
+        check(self._L.poco_realnvp(self._h, N, z.contiguous().data_ptr(), ctx.contiguous().data_ptr(), out.data_ptr(), 1,
+                                   _stream()), "poco_realnvp")
+        return out

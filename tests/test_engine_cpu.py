@@ -1,0 +1,60 @@
+"""CPU (no GPU): the C-ABI library loads, exports every symbol the header declares, and the
+engine's tensor declarations equal the reference's state_dict key set (recorded in
+tests/golden/spec_*.json by oracle/gen_golden.py).  No compute calls."""
+import ctypes as C
+import json
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from poco_amd import _lib, synth
+from poco_amd.model import POCO, SMPL_KEYS
+
+GOLD = Path(__file__).parent / "golden"
+VARIANTS = {"hrnet_w32-pare": 3, "hrnet_w48_cls-cliff": 1, "resnet50-cliff": 1}
+
+
+def test_library_exports_header_symbols():
+    L = _lib.lib()
+    syms = _lib.header_symbols()
+    assert len(syms) >= 15
+    missing = [s for s in syms if not hasattr(L, s)]
+    assert not missing, missing
+
+
+@pytest.mark.parametrize("variant", list(VARIANTS))
+def test_declared_tensors_match_reference_keys(variant):
+    m = POCO(backbone=variant, num_flow_layers=VARIANTS[variant], max_batch=2)
+    decl = {n: (s, r) for n, s, r in m.expected_tensors()}
+    spec = {n: tuple(s) for n, s in json.loads((GOLD / f"spec_{variant}.json").read_text())}
+    ref_keys = set(spec)
+    eng_keys = {k for k in decl if not k.startswith("smpl.")}
+    assert ref_keys - eng_keys == set(), sorted(ref_keys - eng_keys)[:10]      # every checkpoint key is accepted
+    assert eng_keys - ref_keys == set(), sorted(eng_keys - ref_keys)[:10]      # nothing invented
+    for k, shp in spec.items():
+        assert int(np.prod(decl[k][0])) == int(np.prod(shp)), (k, decl[k][0], shp)
+    assert {k[5:] for k in decl if k.startswith("smpl.")} == set(SMPL_KEYS)
+    # unused-by-forward tensors are tolerated, not required
+    for k, (s, req) in decl.items():
+        if k.endswith("num_batches_tracked") or k.startswith("flow_head.") or "classifier" in k:
+            assert not req, k
+
+
+def test_strict_loading_errors():
+    m = POCO(backbone="resnet50-cliff", num_flow_layers=1, max_batch=1)
+    with pytest.raises(_lib.PocoHipError, match="unexpected"):
+        m.load_state_dict({"backbone.not_a_layer.weight": np.zeros((1,), np.float32)})
+    with pytest.raises(_lib.PocoHipError, match="shape mismatch"):
+        m.load_state_dict({"backbone.conv1.weight": np.zeros((64, 3, 3, 3), np.float32)})
+    # finalize without weights: strict missing-key report (and no GPU needed to get there)
+    with pytest.raises(_lib.PocoHipError, match="missing required tensors"):
+        m._finalized = False
+        _lib.check(m._L.poco_finalize(m._h), "poco_finalize")
+
+
+def test_forward_before_finalize_is_an_error():
+    m = POCO(backbone="resnet50-cliff", num_flow_layers=1, max_batch=1)
+    from poco_amd.model import _Inputs, _Outputs
+    rc = m._L.poco_forward(m._h, 1, C.byref(_Inputs()), C.byref(_Outputs()), None)
+    assert rc != 0 and b"finalize" in m._L.poco_last_error()

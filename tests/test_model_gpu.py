@@ -1,0 +1,105 @@
+"""GPU parity of the whole hot path (through the C ABI) against
+  (a) the committed golden vectors produced by the reference's own modules (B=2), and
+  (b) the CPU oracle on the same seeded inputs at other batch sizes.
+Gate (BASELINE.json north_star): max-abs < 1e-3 on pose / shape / cam / confidence / vertices."""
+import numpy as np
+import pytest
+import torch
+
+from poco_amd import synth
+from tests import util
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3
+VARIANTS = ["hrnet_w32-pare", "hrnet_w48_cls-cliff", "resnet50-cliff"]
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_golden_b2(variant, cuda):
+    g = dict(np.load(util.GOLD / f"model_{variant}.npz"))
+    m = util.make_engine(variant, max_batch=4)
+    out = m(util.cuda_batch(synth.synth_batch(2, 1234), cuda))
+    torch.cuda.synchronize()
+    errs = {k: float(np.abs(_np(out[k]) - g[k]).max()) for k in ("pred_pose", "pred_shape", "pred_cam", "var_pose")}
+    p6 = out["pred_pose6d"] if "pred_pose6d" in out else out["pred_pose_6d"]
+    errs["pred_pose6d"] = float(np.abs(_np(p6).reshape(2, -1) - g["pred_pose6d"]).max())
+    errs["uncert_feat"] = float(np.abs(_np(out["uncert_feat"])[:, g["uncert_feat_idx"]] - g["uncert_feat_samples"]).max())
+    errs["vertices"] = float(np.abs(_np(out["smpl_vertices"])[:, g["oracle_vert_idx"]] - g["oracle_vert_samples"]).max())
+    errs["joints3d"] = float(np.abs(_np(out["smpl_joints3d"]) - g["oracle_smpl_joints3d"]).max())
+    errs["cam_t"] = float(np.abs(_np(out["pred_cam_t"]) - g["oracle_pred_cam_t"]).max())
+    j2 = np.abs(_np(out["smpl_joints2d"]) - g["oracle_smpl_joints2d"]).max()
+    # full-image pixels (values ~1e3) for cliff: relative gate; crop-normalised for pare: absolute
+    errs["joints2d"] = float(j2 / max(1.0, np.abs(g["oracle_smpl_joints2d"]).max()))
+    if variant.endswith("cliff"):
+        errs["body_feat2"] = float(np.abs(_np(out["body_feat2"])[:, :64] - g["body_feat2_samples"]).max())
+        errs["fullimg_cam_t"] = float(np.abs(_np(out["pred_fullimg_cam_t"]) - g["oracle_pred_fullimg_cam_t"]).max()
+                                      / max(1.0, np.abs(g["oracle_pred_fullimg_cam_t"]).max()))
+    else:
+        seg = _np(out["pred_segm_mask"]).reshape(2, -1)[:, g["segm_idx"]]
+        errs["segm"] = float(np.abs(seg - g["segm_samples"]).max())
+    print(variant, errs)
+    assert max(errs.values()) < TOL, errs
+    assert out["log_phi"] is None and out["gt_pose_cond_idx"] == []
+
+
+@pytest.mark.parametrize("variant,B", [("hrnet_w32-pare", 5), ("hrnet_w48_cls-cliff", 7), ("resnet50-cliff", 9),
+                                       ("resnet50-cliff", 1)])
+def test_oracle_other_batches(variant, B, cuda):
+    """Ragged batch sizes (partial tiles in every kernel) against the CPU oracle; also checks that a
+    smaller batch on a bigger workspace and repeated calls give identical results."""
+    torch.set_num_threads(8)
+    bnp = synth.synth_batch(B, 4321 + B)
+    ref = util.oracle_forward(variant, bnp)
+    m = util.make_engine(variant, max_batch=12)
+    batch = util.cuda_batch(bnp, cuda)
+    out = m(batch)
+    out2 = m(batch)
+    torch.cuda.synchronize()
+    for k in ("pred_pose", "pred_shape", "pred_cam", "var_pose", "smpl_vertices", "smpl_joints3d", "pred_cam_t"):
+        err = float(np.abs(_np(out[k]) - ref[k].numpy()).max())
+        assert err < TOL, (k, err)
+        assert torch.equal(out[k], out2[k]), k          # deterministic
+    j2 = np.abs(_np(out["smpl_joints2d"]) - ref["smpl_joints2d"].numpy()).max() / max(1.0, ref["smpl_joints2d"].abs().max().item())
+    assert j2 < TOL
+
+
+def test_smpl_lbs_op(cuda):
+    """poco_smpl_lbs vs the float64 numpy restatement; identity pose + zero betas -> template."""
+    from oracle import poco_ref, smpl_np
+    m = util.make_engine("resnet50-cliff", max_batch=16)
+    smpl = synth.synth_smpl(7)
+    r = np.random.default_rng(5)
+    B = 11
+    betas = r.standard_normal((B, 10)).astype(np.float32)
+    R = poco_ref.rot6d_to_rotmat(torch.from_numpy(r.standard_normal((B * 24, 6)).astype(np.float32))).reshape(B, 24, 3, 3)
+    v64, j64 = smpl_np.smpl_lbs_np(smpl, betas, R.numpy())
+    v, j = m.smpl_lbs(torch.from_numpy(betas).to(cuda), R.to(cuda))
+    assert np.abs(_np(v) - v64).max() < 2e-5 and np.abs(_np(j) - j64).max() < 2e-5
+    eye = torch.eye(3).repeat(2, 24, 1, 1).to(cuda)
+    v0, _ = m.smpl_lbs(torch.zeros(2, 10, device=cuda), eye)
+    assert np.abs(_np(v0) - smpl["v_template"][None]).max() < 1e-6
+
+
+@pytest.mark.parametrize("variant,L", [("hrnet_w32-pare", 3), ("resnet50-cliff", 1)])
+def test_realnvp_op(variant, L, cuda):
+    """RealNVP log_prob / forward_p vs the oracle (itself pinned to the reference's RealNVP in
+    tests/golden/ops.npz), plus the bijection property backward(forward(z)) == z via log_prob shift."""
+    from oracle import poco_ref
+    m = util.make_engine(variant, max_batch=2)
+    sd = poco_ref.to_torch(util.synth_weights(variant))
+    r = np.random.default_rng(8)
+    N = 48 + 5
+    x = torch.from_numpy(np.abs(r.standard_normal((N, 9))).astype(np.float32))
+    c = torch.from_numpy(r.standard_normal((N, 512)).astype(np.float32))
+    ref_lp = poco_ref.realnvp_log_prob(sd, x, c).numpy()
+    ref_fw = poco_ref.realnvp_forward(sd, x, c).numpy()
+    lp = _np(m.realnvp_log_prob(x.to(cuda), c.to(cuda)))
+    fw = _np(m.realnvp_forward(x.to(cuda), c.to(cuda)))
+    assert np.abs(lp - ref_lp).max() < 1e-3 * max(1.0, np.abs(ref_lp).max())
+    assert np.abs(fw - ref_fw).max() < 1e-3 * max(1.0, np.abs(ref_fw).max())
+    back, _ = poco_ref.realnvp_backward(sd, torch.from_numpy(fw), c)
+    assert np.abs(back.numpy() - x.numpy()).max() < 1e-3

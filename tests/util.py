@@ -1,0 +1,37 @@
+"""Shared helpers for the parity tests (seeded synthetic weights -> engine / oracle)."""
+import json
+from pathlib import Path
+
+import numpy as np
+
+from poco_amd import synth
+
+GOLD = Path(__file__).parent / "golden"
+FLOW_LAYERS = {"hrnet_w32-pare": 3, "hrnet_w48_cls-cliff": 1, "resnet50-cliff": 1}
+
+
+def load_spec(variant):
+    return [(n, tuple(s)) for n, s in json.loads((GOLD / f"spec_{variant}.json").read_text())]
+
+
+def synth_weights(variant, seed=0):
+    w = synth.synth_state_dict(load_spec(variant), seed)
+    return {k: v for k, v in w.items() if v.dtype != np.int64}
+
+
+def make_engine(variant, max_batch, seed=0, smpl_seed=7):
+    from poco_amd.model import POCO
+    m = POCO(backbone=variant, num_flow_layers=FLOW_LAYERS[variant], max_batch=max_batch, smpl=synth.synth_smpl(smpl_seed))
+    m.load_state_dict(synth_weights(variant, seed), strict=True)
+    return m.finalize()
+
+
+def cuda_batch(batch_np, device):
+    import torch
+    return {k: torch.from_numpy(v).to(device) for k, v in batch_np.items()}
+
+
+def oracle_forward(variant, batch_np, seed=0, smpl_seed=7):
+    from oracle import poco_ref
+    sd = poco_ref.to_torch(synth_weights(variant, seed))
+    return poco_ref.poco_forward(variant, sd, poco_ref.to_torch(synth.synth_smpl(smpl_seed)), poco_ref.to_torch(batch_np))
