@@ -60,25 +60,35 @@ def cpu_baseline(variant, seconds_budget=25.0):
     from oracle import poco_ref
     from poco_amd import synth
     cores = os.cpu_count() or 1
-    threads = max(1, min(cores // 2 if cores > 16 else cores, 128))
-    torch.set_num_threads(threads)
     w = synth.synth_state_dict(load_spec(variant), 0)
     sd = poco_ref.to_torch({k: v for k, v in w.items() if v.dtype != np.int64})
     smpl = poco_ref.to_torch(synth.synth_smpl(7))
     Bs = 32
     batch = poco_ref.to_torch(synth.synth_batch(Bs, 1234))
-    t0 = time.time()
-    poco_ref.poco_forward(variant, sd, smpl, batch)          # warm-up
-    warm = time.time() - t0
-    times = []
-    while len(times) < 5 and (sum(times) + warm) < seconds_budget:
+    t_start = time.time()
+    best = None
+    # torch's CPU conv does not scale to every core of a 2-socket host: probe a few thread counts
+    for th in sorted({min(cores, c) for c in (16, 32, 64, 128)}):
+        if best is not None and time.time() - t_start > 0.5 * seconds_budget:
+            break
+        torch.set_num_threads(th)
+        poco_ref.poco_forward(variant, sd, smpl, batch)      # warm-up at this thread count
+        t0 = time.time()
+        poco_ref.poco_forward(variant, sd, smpl, batch)
+        dt = time.time() - t0
+        if best is None or dt < best[0]:
+            best = (dt, th)
+    threads = best[1]
+    torch.set_num_threads(threads)
+    times = [best[0]]
+    while len(times) < 4 and (time.time() - t_start) < seconds_budget:
         t0 = time.time()
         poco_ref.poco_forward(variant, sd, smpl, batch)
         times.append(time.time() - t0)
-    med = float(np.median(times)) if times else warm
+    med = float(np.median(times))
     return {"value": round(Bs / med, 2), "unit": "crops/s", "cores": threads, "kind": "port",
             "sample": f"oracle/poco_ref.py (torch CPU fp32, {threads} threads of {cores} logical cpus) on {Bs} crops of "
-                      f"{variant}, median of {max(1, len(times))} passes"}
+                      f"{variant}, median of {len(times)} passes at the best of 16/32/64/128 threads"}
 
 
 def main():

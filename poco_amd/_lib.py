@@ -34,6 +34,9 @@ def lib() -> C.CDLL:
             raise PocoHipError(
                 f"{LIB_PATH} not found - build it with `python -m poco_amd.build` "
                 "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        # torch ships its own libamdhip64; it must be the one HIP runtime in the process, so load it
+        # before our library resolves its HIP symbols (otherwise two runtimes -> "no HIP device").
+        import torch  # noqa: F401
         _lib = C.CDLL(str(LIB_PATH))
         _lib.poco_last_error.restype = C.c_char_p
     return _lib
