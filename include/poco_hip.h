@@ -123,6 +123,11 @@ int poco_bench_conv2d(const float* d_in, int B, int H, int W, int Cin, const flo
                       int ks, int stride, float* d_out, const int* cfg6, int iters, float* ms_out,
                       int* cfg_used6, void* stream);
 
+/* Time `ncfg` tile configurations (6 ints each; MT<=0 = heuristic) for one conv shape on random
+ * data; ms_out[i] < 0 = configuration invalid for this shape.  Used by poco_amd/tune.py. */
+int poco_tune_conv(int B, int H, int W, int Cin, int Cout, int ks, int stride, const int* cfgs6, int ncfg,
+                   int iters, float* ms_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

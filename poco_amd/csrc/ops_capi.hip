@@ -3,6 +3,7 @@
 #include "../../include/poco_hip.h"
 #include "common.h"
 
+#include <cmath>
 #include <mutex>
 #include <vector>
 
@@ -97,4 +98,55 @@ extern "C" int poco_bench_conv2d(const float* d_in, int B, int H, int W, int Cin
   }
   return conv_common(d_in, B, H, W, Cin, h_weight, nullptr, nullptr, Cout, ks, stride, nullptr, 1, d_out,
                      cfg6, iters, ms_out, (hipStream_t)stream);
+}
+
+// Time a list of tile configurations for one conv shape (weights/activations allocated and filled
+// here once).  ms_out[i] < 0 marks a configuration that is invalid for the shape.
+extern "C" int poco_tune_conv(int B, int H, int W, int Cin, int Cout, int ks, int stride, const int* cfgs6,
+                              int ncfg, int iters, float* ms_out, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!cfgs6 || !ms_out || ncfg < 1 || Cin % 16 || Cout % 16) {
+    poco_set_error("poco_tune_conv: bad arguments");
+    return POCO_ERR_ARG;
+  }
+  const int pad = (ks - 1) / 2;
+  const int Ho = (H + 2 * pad - ks) / stride + 1, Wo = (W + 2 * pad - ks) / stride + 1;
+  const size_t nin = (size_t)B * H * W * Cin, nout = (size_t)B * Ho * Wo * Cout;
+  const size_t nw = conv_packed_weight_floats(Cin, Cout, ks);
+  uint32_t st = 12345u;
+  auto rnd = [&]() { st = st * 1664525u + 1013904223u; return ((st >> 8) & 0xffff) / 32768.0f - 1.0f; };
+  std::vector<float> hin(nin), hw(nw), hb(Cout);
+  for (auto& v : hin) v = rnd();
+  const float ws = 1.0f / sqrtf((float)(Cin * ks * ks));
+  for (auto& v : hw) v = rnd() * ws;
+  for (auto& v : hb) v = rnd() * 0.1f;
+  DevBuf din, dw, db, dout;
+  POCO_HIP_CHECK(din.upload(hin));
+  POCO_HIP_CHECK(dw.upload(hw));
+  POCO_HIP_CHECK(db.upload(hb));
+  POCO_HIP_CHECK(hipMalloc(&dout.p, nout * sizeof(float)));
+  ConvDesc d{};
+  d.in = din.p; d.in_cs = Cin; d.out = dout.p; d.out_cs = Cout; d.wfrag = dw.p; d.bias = db.p;
+  d.B = B; d.H = H; d.W = W; d.Cin = Cin; d.Cout = Cout; d.ks = ks; d.stride = stride; d.act = 1;
+  hipEvent_t e0, e1;
+  POCO_HIP_CHECK(hipEventCreate(&e0));
+  POCO_HIP_CHECK(hipEventCreate(&e1));
+  for (int i = 0; i < ncfg; ++i) {
+    const int* c = cfgs6 + 6 * i;
+    ConvCfg cfg{c[0], c[1], c[2], c[3], c[4], c[5]};
+    if (c[0] <= 0) cfg = conv_default_cfg(d);
+    ms_out[i] = -1.f;
+    if (conv_launch(d, cfg, stream) != POCO_OK) continue;
+    conv_launch(d, cfg, stream);
+    POCO_HIP_CHECK(hipEventRecord(e0, stream));
+    for (int k = 0; k < iters; ++k) conv_launch(d, cfg, stream);
+    POCO_HIP_CHECK(hipEventRecord(e1, stream));
+    POCO_HIP_CHECK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    POCO_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    ms_out[i] = ms / iters;
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  return POCO_OK;
 }

@@ -166,6 +166,18 @@ class POCO:
             self._finalized = True
         return self
 
+    def _apply_tuned(self, B: int) -> None:
+        """Measured conv tile table (poco_amd/tuned/gfx950.json, produced by poco_amd.tune) for this
+        batch size; shapes without an entry keep the built-in heuristic."""
+        done = self.__dict__.setdefault("_tuned_B", set())
+        if B in done:
+            return
+        done.add(B)
+        from . import tune
+        table = self.__dict__.setdefault("_tune_table", tune.load_table())
+        if table:
+            tune.apply_table(self, B, table)
+
     # ---- forward ---------------------------------------------------------------------------------
     def _alloc_outputs(self, B: int, want_segm: bool) -> Dict[str, torch.Tensor]:
         d = self.device
@@ -228,6 +240,7 @@ class POCO:
         if out is None:
             out = self._alloc_outputs(B, want_segm)
         B, ins, outs, _keep = self._pack_io(batch, out)
+        self._apply_tuned(B)
         check(self._L.poco_forward(self._h, B, C.byref(ins), C.byref(outs), _stream()), "poco_forward")
         res = dict(out)
         res["log_phi"] = None            # nf_head.py:129-136: not evaluated at inference
@@ -251,6 +264,7 @@ class POCO:
         B = batch["img"].shape[0]
         out = self._alloc_outputs(B, True)
         B, ins, outs, _keep = self._pack_io(batch, out)
+        self._apply_tuned(B)
         n = self._L.poco_num_ops(self._h)
         ms = (C.c_float * n)()
         check(self._L.poco_profile_ops(self._h, B, C.byref(ins), C.byref(outs), iters, ms, n, _stream()), "poco_profile_ops")

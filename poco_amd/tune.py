@@ -1,0 +1,144 @@
+"""Measured tile selection for the MFMA conv kernel ("measure, don't guess").
+
+    python -m poco_amd.tune --variant hrnet_w48_cls-cliff --batch 64      # on a GPU box
+
+For every distinct conv shape of a variant at a batch size, time the candidate tile decompositions
+(MT,NT,WM,WN,R,NI) with poco_tune_conv and keep the fastest.  Results are merged into
+poco_amd/tuned/gfx950.json (committed, so later runs need no re-tuning); POCO.finalize() applies
+the table, shapes/batches without an entry fall back to the built-in heuristic.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import itertools
+import json
+import time
+from pathlib import Path
+from typing import Dict, List, Tuple
+
+TABLE = Path(__file__).resolve().parent / "tuned" / "gfx950.json"
+
+
+def shape_key(B, H, W, Cin, Cout, ks, stride) -> str:
+    return f"{B}x{H}x{W}x{Cin}x{Cout}k{ks}s{stride}"
+
+
+def load_table() -> Dict[str, List[int]]:
+    if TABLE.exists():
+        return {k: v["cfg"] for k, v in json.loads(TABLE.read_text()).items()}
+    return {}
+
+
+def candidates(B, H, W, Cin, Cout, ks, stride, lds_cap=150 * 1024) -> List[Tuple[int, ...]]:
+    pad = (ks - 1) // 2
+    Ho = (H + 2 * pad - ks) // stride + 1
+    Wo = (W + 2 * pad - ks) // stride + 1
+    nT = Cout // 16
+    out = set()
+    for MT, NT, WM, WN in itertools.product((4, 7, 13), (1, 2, 3, 4), (1, 2, 4, 8), (1, 2, 4, 8)):
+        if WM * WN > 8 or (MT == 13 and NT > (2 if ks == 3 else 3)) or nT % NT:
+            continue
+        if (nT // NT) % WN and WN > 1 and (nT // NT) > WN:
+            continue
+        if WN > nT // NT:
+            continue
+        cap = WM * MT * 16
+        for R in range(1, Ho + 1):
+            if R * Wo > cap:
+                break
+            nis = {1, max(1, cap // (R * Wo))} if R == Ho or Ho % R == 0 or R * Wo * 2 > cap else {1}
+            for ni in nis:
+                if ni > max(1, B * ((Ho + R - 1) // R)):
+                    continue
+                util = ni * R * Wo / cap
+                if util < 0.75:
+                    continue
+                pr, pw = (R - 1) * stride + ks, (Wo - 1) * stride + ks
+                lds = 4 * ((ni * pr * pw + 15) // 16 * 16) * 16
+                if lds > lds_cap:
+                    continue
+                out.add((MT, NT, WM, WN, R, ni))
+    return sorted(out)
+
+
+def tune_shape(L, B, H, W, Cin, Cout, ks, stride, iters=8):
+    cands = [(0, 0, 0, 0, 0, 0)] + candidates(B, H, W, Cin, Cout, ks, stride)
+    flat = (C.c_int * (6 * len(cands)))(*[v for c in cands for v in c])
+    ms = (C.c_float * len(cands))()
+    from ._lib import check
+    check(L.poco_tune_conv(B, H, W, Cin, Cout, ks, stride, flat, len(cands), iters, ms, None), "poco_tune_conv")
+    res = [(ms[i], cands[i]) for i in range(len(cands)) if ms[i] > 0]
+    base = ms[0]
+    # re-time the top few with more iterations to reduce noise
+    top = sorted(res)[:6]
+    cands2 = [c for _, c in top]
+    flat2 = (C.c_int * (6 * len(cands2)))(*[v for c in cands2 for v in c])
+    ms2 = (C.c_float * len(cands2))()
+    check(L.poco_tune_conv(B, H, W, Cin, Cout, ks, stride, flat2, len(cands2), iters * 4, ms2, None), "poco_tune_conv")
+    best_i = min(range(len(cands2)), key=lambda i: ms2[i])
+    return cands2[best_i], float(ms2[best_i]), float(base), len(cands)
+
+
+def tune_model(model, B: int, verbose=True) -> Dict[str, dict]:
+    from ._lib import lib
+    L = lib()
+    L.poco_tune_conv.argtypes = [C.c_int] * 7 + [C.POINTER(C.c_int), C.c_int, C.c_int, C.POINTER(C.c_float), C.c_void_p]
+    shapes = {}
+    for i, (name, flops, ty) in enumerate(model.ops()):
+        d = model.conv_desc(i)
+        if d is None:
+            continue
+        H, W, Cin, Cout, ks, stride = d[:6]
+        shapes.setdefault((H, W, Cin, Cout, ks, stride), []).append(i)
+    out = {}
+    t0 = time.time()
+    for (H, W, Cin, Cout, ks, stride), idxs in sorted(shapes.items(), key=lambda kv: -len(kv[1])):
+        cfg, ms, base, n = tune_shape(L, B, H, W, Cin, Cout, ks, stride)
+        key = shape_key(B, H, W, Cin, Cout, ks, stride)
+        fl = 2.0 * B * ((H + 2 * ((ks - 1) // 2) - ks) // stride + 1) ** 2 * Cout * Cin * ks * ks if H == W else 0
+        out[key] = {"cfg": list(cfg), "ms": round(ms, 5), "heuristic_ms": round(base, 5), "uses": len(idxs),
+                    "tflops": round(fl / ms / 1e9, 1) if ms > 0 else 0}
+        if verbose:
+            print(f"{key:34s} x{len(idxs):3d}  {base:.4f} -> {ms:.4f} ms  {out[key]['tflops']:6.1f} TF  cfg={cfg}  ({n} cands)", flush=True)
+    if verbose:
+        print(f"tuned {len(out)} shapes in {time.time()-t0:.1f}s")
+    return out
+
+
+def apply_table(model, B: int, table=None) -> int:
+    table = load_table() if table is None else table
+    n = 0
+    for i, _ in enumerate(model.ops()):
+        d = model.conv_desc(i)
+        if d is None:
+            continue
+        cfg = table.get(shape_key(B, *d[:6]))
+        if cfg and cfg[0] > 0:
+            model.set_conv_cfg(i, B, cfg)
+            n += 1
+    return n
+
+
+def main():
+    import numpy as np
+    import torch
+    from . import synth
+    from .model import POCO
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--variant", default="hrnet_w48_cls-cliff")
+    ap.add_argument("--batch", type=int, nargs="+", default=[64])
+    args = ap.parse_args()
+    torch.cuda.set_device(0)
+    fl = {"hrnet_w32-pare": 3, "hrnet_w48_cls-cliff": 1, "resnet50-cliff": 1}[args.variant]
+    m = POCO(backbone=args.variant, num_flow_layers=fl, max_batch=1)   # declarations only: shapes, no weights
+    full = json.loads(TABLE.read_text()) if TABLE.exists() else {}
+    for B in args.batch:
+        full.update({k: v for k, v in tune_model(m, B).items() if v["cfg"][0] > 0})
+    TABLE.parent.mkdir(exist_ok=True)
+    TABLE.write_text(json.dumps(full, indent=0, sort_keys=True))
+    print("wrote", TABLE, len(full), "entries")
+
+
+if __name__ == "__main__":
+    main()
