@@ -84,6 +84,10 @@ int poco_finalize(poco_handle_t h);
 /* Enqueue one forward pass for B <= max_batch crops on `stream`.  No allocation, no sync. */
 int poco_forward(poco_handle_t h, int B, const poco_inputs_t* in, const poco_outputs_t* out, void* stream);
 
+/* Independent branches of the network (HRNet branches, fuse terms, head branches) are enqueued on up
+ * to 4 HIP streams forked from / joined to `stream` (default 4; 1 = everything on `stream`). */
+int poco_set_num_lanes(poco_handle_t h, int n);
+
 /* Introspection / tuning. */
 int poco_num_ops(poco_handle_t h);
 int poco_op_info(poco_handle_t h, int i, char* name, size_t name_cap, double* flops_per_crop, int* type);

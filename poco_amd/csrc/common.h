@@ -36,7 +36,10 @@ struct ConvCfg {
   int WN;      // waves along output channels  (block = WM*WN waves)
   int R;       // output rows per slab
   int NI;      // slabs (row bands / whole images) per block
+  int ALG;     // 0: register-staged single LDS buffer; 1: LDS-DMA double-buffered (patch + weights)
 };
+constexpr int CONV_CFG_INTS = 7;   // ints per configuration in the C ABI / tuning table
+inline ConvCfg conv_cfg_from(const int* c) { return ConvCfg{c[0], c[1], c[2], c[3], c[4], c[5], c[6]}; }
 
 struct ConvDesc {
   // activations: NHWC, each buffer may be a channel slice of a wider buffer

@@ -22,6 +22,7 @@
 //   * epilogue: + shift[co] (+ residual) (ReLU), written into a channel slice of the destination
 //     (makes torch.cat free, hrnet.py:519).
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -52,8 +53,12 @@ struct ConvKParams {
   int R, NI, S;          // rows per slab, slabs per block, total slabs (= B * nbands)
   int PR, PW;            // patch rows / cols per slab
   int npos;              // NI * PR * PW
-  int planeF4;           // float4 elements per LDS plane (multiple of 16)
+  int planeF4;           // float4 elements per LDS plane (multiple of 16; of 64 for ALG 1)
   int WM, WN;
+  int NTB;               // n-tiles per block (WN * NT)
+  int bufF4;             // ALG 1: float4 per LDS buffer (4 planes + KS*KS*NTB weight fragments)
+  int ngroups;           // ALG 1: planeF4 / 64
+  int repeat;         // K-loop repetitions (1; >1 = profiling experiment, results meaningless)
   int act;            // 0 none, 1 ReLU, 2 sigmoid
   int res_after_act;  // add the residual after the activation (hrnet_cls.py:475-477)
   FastDiv dPW, dSlab /*PR*PW*/, dBands, dWo, dRWo;
@@ -103,8 +108,10 @@ conv_mfma_kernel(const ConvKParams p) {
   const bool nvalid = nt0 < p.nT16;   // wave-uniform (grid.y may overshoot when WN does not divide)
   const int total_units = ((p.npos + 7) >> 3) << 5;   // (pos rounded to 8) * 4 quads
 
-  for (int c = 0; c < p.nC16; ++c) {
-    if (c > 0) __syncthreads();
+  const int nIter = p.nC16 * p.repeat;   // repeat > 1 only for profiling experiments
+  for (int it = 0; it < nIter; ++it) {
+    const int c = it % p.nC16;
+    if (it > 0) __syncthreads();
     // ---- stage the 16-channel slice c of the halo patch ------------------------------------
 #pragma unroll 4
     for (int u = tid; u < total_units; u += nthreads) {
@@ -202,11 +209,192 @@ conv_mfma_kernel(const ConvKParams p) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// ALG 1: same math, but the halo patch AND the weight fragments of the next 16-channel slice are
+// streamed into the other half of a double-buffered LDS by LDS-DMA (global_load_lds_dwordx4) while
+// the MFMAs of the current slice run: no staging VGPRs, no ds_write pass, one barrier per slice.
+// The LDS images are lane-linear per wave instruction by construction (64 consecutive patch
+// positions of one channel-quad plane; one 1 KiB weight fragment), which is exactly what the DMA
+// writes (wave-uniform base + lane*16).  Zero padding comes from a 16-byte zero page in HBM.
+// The DMA is issued through inline asm so that hipcc does not drain it at every ds_read/barrier
+// (cdna_hip_programming.md 5.7); completion = our own s_waitcnt vmcnt(0) + the block barrier.
+// ------------------------------------------------------------------------------------------------
+__device__ float4 g_zero_page;
+
+__device__ __forceinline__ void lds_dma16(const void* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(gsrc), "s"(lds_dst)
+      : "memory");
+}
+
+constexpr int DMA_MAXG = 6;   // 64-position groups of the patch each wave may own
+
 template <int KS, int STRIDE, int MT, int NT>
-int launch_inst(const ConvKParams& kp, dim3 grid, int nthreads, size_t lds, hipStream_t stream) {
-  auto fn = conv_mfma_kernel<KS, STRIDE, MT, NT>;
+__global__ void __launch_bounds__(512)
+conv_dma_kernel(const ConvKParams p) {
+  extern __shared__ float4 smem[];
+  constexpr int PAD = (KS - 1) / 2;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nwaves = blockDim.x >> 6;
+  const int wm = wave % p.WM;
+  const int wn = wave / p.WM;
+  const int idx = lane & 15;
+  const int g = lane >> 4;
+  const int s0 = blockIdx.x * p.NI;
+  const int ntb0 = blockIdx.y * p.NTB;             // first n-tile of the block
+  const int nt0 = ntb0 + wn * NT;                  // first n-tile of this wave
+
+  int base[MT];
+  int ooff[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    const uint32_t pix = (uint32_t)((wm * MT + m) * 16 + idx);
+    const uint32_t sl = fdiv(pix, p.dRWo);
+    const uint32_t rem = pix - sl * p.dRWo.d;
+    const uint32_t yl = fdiv(rem, p.dWo);
+    const uint32_t x = rem - yl * p.dWo.d;
+    const uint32_t s = s0 + sl;
+    const uint32_t b = fdiv(s, p.dBands);
+    const uint32_t band = s - b * p.dBands.d;
+    const uint32_t y = band * p.R + yl;
+    const bool valid = (sl < (uint32_t)p.NI) && (s < (uint32_t)p.S) && (y < (uint32_t)p.Ho);
+    base[m] = valid ? (int)((sl * p.PR + yl * STRIDE) * p.PW + x * STRIDE) : 0;
+    ooff[m] = valid ? (int)((b * p.Ho + y) * p.Wo + x) : -1;
+  }
+
+  // source offsets (floats) of this lane's patch positions, one per owned 64-position group
+  int goff[DMA_MAXG];
+#pragma unroll
+  for (int k = 0; k < DMA_MAXG; ++k) {
+    goff[k] = -1;
+    const int grp = wave + k * nwaves;
+    const uint32_t pos = (uint32_t)(grp * 64 + lane);
+    if (grp < p.ngroups && pos < (uint32_t)p.npos) {
+      const uint32_t sl = fdiv(pos, p.dSlab);
+      const uint32_t rem = pos - sl * p.dSlab.d;
+      const uint32_t prow = fdiv(rem, p.dPW);
+      const uint32_t pcol = rem - prow * p.dPW.d;
+      const uint32_t s = s0 + sl;
+      const uint32_t b = fdiv(s, p.dBands);
+      const uint32_t band = s - b * p.dBands.d;
+      const int iy = (int)(band * p.R) * STRIDE - PAD + (int)prow;
+      const int ix = (int)pcol - PAD;
+      if (s < (uint32_t)p.S && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
+        goff[k] = (int)(((size_t)(b * p.H + iy) * p.W + ix) * p.in_cs + p.in_co);
+    }
+  }
+
+  const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) float4*)smem;
+  const int nwitems = KS * KS * p.NTB;
+
+  auto issue = [&](int c, int buf) {
+    const unsigned bb = lds_base + (unsigned)buf * (unsigned)p.bufF4 * 16u;
+#pragma unroll
+    for (int k = 0; k < DMA_MAXG; ++k) {
+      const int grp = wave + k * nwaves;
+      if (grp < p.ngroups) {
+        const float* src0 = p.in + goff[k] + c * 16;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const void* src = (goff[k] >= 0) ? (const void*)(src0 + q * 4) : (const void*)&g_zero_page;
+          lds_dma16(src, (unsigned)__builtin_amdgcn_readfirstlane((int)(bb + (unsigned)(q * p.planeF4 + grp * 64) * 16u)));
+        }
+      }
+    }
+    for (int i = wave; i < nwitems; i += nwaves) {
+      const int tap = i / p.NTB, j = i - tap * p.NTB;
+      const int nt = min(ntb0 + j, p.nT16 - 1);
+      const float4* src = p.wfrag + (((size_t)tap * p.nC16 + c) * p.nT16 + nt) * 64 + lane;
+      lds_dma16(src, (unsigned)__builtin_amdgcn_readfirstlane((int)(bb + (unsigned)(4 * p.planeF4 + i * 64) * 16u)));
+    }
+  };
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  issue(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  const int nIter = p.nC16 * p.repeat;   // repeat > 1 only for profiling experiments
+  for (int it = 0; it < nIter; ++it) {
+    if (it + 1 < nIter) issue((it + 1) % p.nC16, (it + 1) & 1);
+    const float4* bufp = smem + (size_t)(it & 1) * p.bufF4;
+    const float4* pl = bufp + g * p.planeF4;
+    const float4* wl = bufp + 4 * p.planeF4 + (wn * NT) * 64 + lane;
+    int tr = 0, ts = 0;
+#pragma unroll 1
+    for (int tap = 0; tap < KS * KS; ++tap) {
+      const int toff = tr * p.PW + ts;
+      if (++ts == KS) { ts = 0; ++tr; }
+      float4 wv[NT];
+#pragma unroll
+      for (int n = 0; n < NT; ++n) wv[n] = wl[(tap * p.NTB + n) * 64];
+#pragma unroll
+      for (int m0 = 0; m0 < MT; m0 += 2) {
+        const float4 a0 = pl[base[m0] + toff];
+        const float4 a1 = pl[base[(m0 + 1 < MT) ? m0 + 1 : m0] + toff];
+        const float a0v[4] = {a0.x, a0.y, a0.z, a0.w};
+        const float a1v[4] = {a1.x, a1.y, a1.z, a1.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+          for (int n = 0; n < NT; ++n) {
+            const float wj = (j == 0) ? wv[n].x : (j == 1) ? wv[n].y : (j == 2) ? wv[n].z : wv[n].w;
+            acc[m0][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wj, a0v[j], acc[m0][n], 0, 0, 0);
+            if (m0 + 1 < MT)
+              acc[m0 + 1][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wj, a1v[j], acc[m0 + 1][n], 0, 0, 0);
+          }
+        }
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+
+  if (nt0 >= p.nT16) return;
+#pragma unroll
+  for (int n = 0; n < NT; ++n) {
+    if (nt0 + n >= p.nT16) break;
+    const int co = (nt0 + n) * 16 + g * 4;
+    const float4 sh = *reinterpret_cast<const float4*>(p.bias + co);
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      if (ooff[m] >= 0) {
+        f32x4 v = acc[m][n];
+        v[0] += sh.x; v[1] += sh.y; v[2] += sh.z; v[3] += sh.w;
+        float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p.res) r = *reinterpret_cast<const float4*>(p.res + (size_t)ooff[m] * p.res_cs + p.res_co + co);
+        if (!p.res_after_act) { v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w; }
+        if (p.act == 1) {
+          v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f);
+          v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+        } else if (p.act == 2) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = 1.f / (1.f + __expf(-v[e]));
+        }
+        if (p.res_after_act) { v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w; }
+        *reinterpret_cast<float4*>(p.out + (size_t)ooff[m] * p.out_cs + p.out_co + co) =
+            make_float4(v[0], v[1], v[2], v[3]);
+      }
+    }
+  }
+}
+
+template <int KS, int STRIDE, int MT, int NT>
+int launch_inst(int alg, const ConvKParams& kp, dim3 grid, int nthreads, size_t lds, hipStream_t stream) {
+  auto fn = alg == 1 ? conv_dma_kernel<KS, STRIDE, MT, NT> : conv_mfma_kernel<KS, STRIDE, MT, NT>;
   if (lds > 64 * 1024) {
-    static thread_local size_t configured = 0;
+    static thread_local size_t configured_alg[2] = {0, 0};
+    size_t& configured = configured_alg[alg == 1];
     if (lds > configured) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
@@ -227,10 +415,10 @@ int launch_inst(const ConvKParams& kp, dim3 grid, int nthreads, size_t lds, hipS
 }
 
 template <int KS, int STRIDE>
-int launch_mtnt(int MT, int NT, const ConvKParams& kp, dim3 grid, int nthreads, size_t lds,
+int launch_mtnt(int alg, int MT, int NT, const ConvKParams& kp, dim3 grid, int nthreads, size_t lds,
                 hipStream_t stream) {
 #define POCO_CASE(mt, nt) \
-  if (MT == mt && NT == nt) return launch_inst<KS, STRIDE, mt, nt>(kp, grid, nthreads, lds, stream);
+  if (MT == mt && NT == nt) return launch_inst<KS, STRIDE, mt, nt>(alg, kp, grid, nthreads, lds, stream);
   POCO_CASE(4, 1) POCO_CASE(4, 2) POCO_CASE(4, 3) POCO_CASE(4, 4)
   POCO_CASE(7, 1) POCO_CASE(7, 2) POCO_CASE(7, 3) POCO_CASE(7, 4)
   POCO_CASE(13, 1) POCO_CASE(13, 2) POCO_CASE(13, 3)
@@ -254,7 +442,7 @@ bool geometry(const ConvDesc& d, const ConvCfg& c, Geometry* g) {
   g->PR = (c.R - 1) * d.stride + d.ks;
   g->PW = (g->Wo - 1) * d.stride + d.ks;
   g->npos = c.NI * g->PR * g->PW;
-  g->planeF4 = ((g->npos + 15) / 16) * 16;
+  g->planeF4 = c.ALG == 1 ? ((g->npos + 63) / 64) * 64 : ((g->npos + 15) / 16) * 16;
   g->nblocks_m = (g->S + c.NI - 1) / c.NI;
   return true;
 }
@@ -289,10 +477,16 @@ void conv_pack_weights(const float* w, const float* scale, int Cout, int Cin, in
         }
 }
 
+static size_t lds_bytes_for(const ConvDesc& d, const ConvCfg& cfg, const Geometry& g) {
+  if (cfg.ALG == 1)
+    return (size_t)2 * ((size_t)4 * g.planeF4 + (size_t)d.ks * d.ks * cfg.WN * cfg.NT * 64) * sizeof(float4);
+  return (size_t)4 * g.planeF4 * sizeof(float4);
+}
+
 size_t conv_lds_bytes(const ConvDesc& d, const ConvCfg& cfg) {
   Geometry g;
   if (!geometry(d, cfg, &g)) return 0;
-  return (size_t)4 * g.planeF4 * sizeof(float4);
+  return lds_bytes_for(d, cfg, g);
 }
 
 ConvCfg conv_default_cfg(const ConvDesc& d) {
@@ -328,7 +522,7 @@ ConvCfg conv_default_cfg(const ConvDesc& d) {
               if (NI < 1) continue;
               if (NI > d.B) NI = d.B;
             }
-            ConvCfg c{MT, NT, WM, WN, R, NI};
+            ConvCfg c{MT, NT, WM, WN, R, NI, 0};
             Geometry g;
             if (!geometry(d, c, &g)) continue;
             const size_t lds = (size_t)4 * g.planeF4 * 16;
@@ -386,7 +580,15 @@ int conv_launch(const ConvDesc& d, const ConvCfg& cfg, hipStream_t stream) {
     poco_set_error("conv: block pixel count exceeds WM*MT*16");
     return POCO_ERR_ARG;
   }
-  const size_t lds = (size_t)4 * g.planeF4 * sizeof(float4);
+  const size_t lds = lds_bytes_for(d, cfg, g);
+  if (cfg.ALG == 1 && (g.planeF4 / 64 + nwaves - 1) / nwaves > DMA_MAXG) {
+    poco_set_error("conv: halo patch too large for the LDS-DMA variant");
+    return POCO_ERR_ARG;
+  }
+  if (cfg.ALG < 0 || cfg.ALG > 1) {
+    poco_set_error("conv: unknown ALG");
+    return POCO_ERR_ARG;
+  }
   if (lds > 160 * 1024) {
     poco_set_error("conv: halo patch does not fit in LDS");
     return POCO_ERR_ARG;
@@ -403,7 +605,14 @@ int conv_launch(const ConvDesc& d, const ConvCfg& cfg, hipStream_t stream) {
   kp.R = cfg.R; kp.NI = cfg.NI; kp.S = g.S;
   kp.PR = g.PR; kp.PW = g.PW; kp.npos = g.npos; kp.planeF4 = g.planeF4;
   kp.WM = cfg.WM; kp.WN = cfg.WN;
+  kp.NTB = cfg.WN * cfg.NT;
+  kp.bufF4 = 4 * g.planeF4 + d.ks * d.ks * kp.NTB * 64;
+  kp.ngroups = g.planeF4 / 64;
   kp.act = d.act; kp.res_after_act = d.res_after_act;
+  {
+    static const int rep = [] { const char* e = getenv("POCO_CONV_REPEAT"); return e ? atoi(e) : 1; }();
+    kp.repeat = rep >= 0 ? rep : 1;
+  }
   kp.dPW = make_fastdiv(g.PW);
   kp.dSlab = make_fastdiv(g.PR * g.PW);
   kp.dBands = make_fastdiv(g.nbands);
@@ -412,8 +621,8 @@ int conv_launch(const ConvDesc& d, const ConvCfg& cfg, hipStream_t stream) {
   const int nb_n = (kp.nT16 + cfg.WN * cfg.NT - 1) / (cfg.WN * cfg.NT);
   dim3 grid(g.nblocks_m, nb_n);
   const int nthreads = nwaves * 64;
-  if (d.ks == 1 && d.stride == 1) return launch_mtnt<1, 1>(cfg.MT, cfg.NT, kp, grid, nthreads, lds, stream);
-  if (d.ks == 1 && d.stride == 2) return launch_mtnt<1, 2>(cfg.MT, cfg.NT, kp, grid, nthreads, lds, stream);
-  if (d.ks == 3 && d.stride == 1) return launch_mtnt<3, 1>(cfg.MT, cfg.NT, kp, grid, nthreads, lds, stream);
-  return launch_mtnt<3, 2>(cfg.MT, cfg.NT, kp, grid, nthreads, lds, stream);
+  if (d.ks == 1 && d.stride == 1) return launch_mtnt<1, 1>(cfg.ALG, cfg.MT, cfg.NT, kp, grid, nthreads, lds, stream);
+  if (d.ks == 1 && d.stride == 2) return launch_mtnt<1, 2>(cfg.ALG, cfg.MT, cfg.NT, kp, grid, nthreads, lds, stream);
+  if (d.ks == 3 && d.stride == 1) return launch_mtnt<3, 1>(cfg.ALG, cfg.MT, cfg.NT, kp, grid, nthreads, lds, stream);
+  return launch_mtnt<3, 2>(cfg.ALG, cfg.MT, cfg.NT, kp, grid, nthreads, lds, stream);
 }

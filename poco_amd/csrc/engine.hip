@@ -63,6 +63,7 @@ struct Ref {            // a (possibly strided) view: activation + channel offse
 
 struct Op {
   int type = 0;
+  int phase = 0, lane = 0;
   std::string name;
   double flops = 0;     // per crop
   Ref in, in2, res, out, out2;
@@ -93,6 +94,11 @@ struct Engine {
   float* ws = nullptr;
   size_t ws_floats = 0;
   std::vector<void*> dev_allocs;
+  int num_lanes = 4;      // 1 = run everything on the caller's stream
+  int num_splits = 1;     // >1: the batch is cut into sub-batches that run the whole program on own streams
+  int b0 = 0;             // first crop of the sub-batch currently being enqueued
+  hipStream_t split_stream[4][4] = {};   // [split][lane]; [0][0] is the caller's stream
+  hipEvent_t ev_sfork = nullptr, ev_sjoin[4] = {}, ev_lfork[4] = {}, ev_ljoin[4][4] = {};
   // SMPL / flow device models
   SmplDev smpl{};
   int a_A = -1, a_j24 = -1, a_verts = -1, a_j49 = -1, a_attn_scratch = -1, a_camt = -1, a_fullt = -1, a_j2d = -1;
@@ -103,6 +109,15 @@ struct Engine {
   std::string err;
 
   ~Engine() {
+    for (int sp = 0; sp < 4; ++sp) {
+      for (int k = 0; k < 4; ++k) {
+        if ((sp > 0 || k > 0) && split_stream[sp][k]) (void)hipStreamDestroy(split_stream[sp][k]);
+        if (ev_ljoin[sp][k]) (void)hipEventDestroy(ev_ljoin[sp][k]);
+      }
+      if (ev_sjoin[sp]) (void)hipEventDestroy(ev_sjoin[sp]);
+      if (ev_lfork[sp]) (void)hipEventDestroy(ev_lfork[sp]);
+    }
+    if (ev_sfork) (void)hipEventDestroy(ev_sfork);
     for (void* p : dev_allocs) (void)hipFree(p);
     if (ws) (void)hipFree(ws);
   }
@@ -158,7 +173,20 @@ struct Builder {
   static Ref R(int act, int co = 0) { Ref r; r.act = act; r.co = co; return r; }
   static Ref X(int ext) { Ref r; r.ext = ext; return r; }
 
-  void push(Op&& op) { e.ops.push_back(std::move(op)); }
+  // Scheduling model: the program is a sequence of PHASES separated by full joins; inside a phase
+  // ops are split into LANES (HIP streams) that run concurrently, each lane in program order.
+  // Outside a parallel region every op is its own single-lane phase.
+  int cur_phase = -1, cur_lane = 0;
+  bool in_parallel = false;
+  void begin_parallel() { ++cur_phase; cur_lane = 0; in_parallel = true; }
+  void end_parallel() { in_parallel = false; }
+  void lane(int k) { cur_lane = k % 4; }
+  void push(Op&& op) {
+    if (!in_parallel) { ++cur_phase; cur_lane = 0; }
+    op.phase = cur_phase;
+    op.lane = cur_lane;
+    e.ops.push_back(std::move(op));
+  }
 
   // BN(eval) folded into per-channel scale/shift:  y = conv*scale + shift
   void bn_fold(const std::string& bn, const HostParam* conv_bias, int Cout, std::vector<float>& scale,
@@ -286,15 +314,23 @@ struct Builder {
   // concat buffer (POCO-PARE's 480-channel feature map) instead of a fresh tensor.
   std::vector<int> hr_module(const std::string& p, std::vector<int> xs, const std::vector<int>& ch, Ref out0 = Ref()) {
     const int nb = (int)xs.size();
-    for (int i = 0; i < nb; ++i)
-      for (int k = 0; k < 4; ++k) xs[i] = basic_block(p + ".branches." + std::to_string(i) + "." + std::to_string(k), xs[i], ch[i]);
-    std::vector<int> outs(nb);
+    // phase 1: the branches are independent chains of 8 convs -> one lane (HIP stream) each
+    begin_parallel();
     for (int i = 0; i < nb; ++i) {
-      std::vector<std::pair<int, int>> terms;
+      lane(i);
+      for (int k = 0; k < 4; ++k) xs[i] = basic_block(p + ".branches." + std::to_string(i) + "." + std::to_string(k), xs[i], ch[i]);
+    }
+    end_parallel();
+    // phase 2: every cross-resolution term (i,j) is an independent conv chain
+    std::vector<std::vector<std::pair<int, int>>> terms(nb);
+    begin_parallel();
+    int rr = 0;
+    for (int i = 0; i < nb; ++i) {
       for (int j = 0; j < nb; ++j) {
         const std::string q = p + ".fuse_layers." + std::to_string(i) + "." + std::to_string(j);
-        if (j == i) terms.push_back({xs[j], 0});
-        else if (j > i) terms.push_back({conv_bn(q + ".0", q + ".1", xs[j], ch[j], ch[i], 1, 1, 0), j - i});
+        if (j == i) { terms[i].push_back({xs[j], 0}); continue; }
+        lane(rr++);
+        if (j > i) terms[i].push_back({conv_bn(q + ".0", q + ".1", xs[j], ch[j], ch[i], 1, 1, 0), j - i});
         else {
           int t = xs[j];
           for (int k = 0; k < i - j; ++k) {
@@ -302,13 +338,21 @@ struct Builder {
             const std::string qq = q + "." + std::to_string(k);
             t = conv_bn(qq + ".0", qq + ".1", t, ch[j], lastk ? ch[i] : ch[j], 3, 2, lastk ? 0 : 1);
           }
-          terms.push_back({t, 0});
+          terms[i].push_back({t, 0});
         }
       }
-      const Act a = e.acts[xs[i]];
-      if (i == 0 && out0.act >= 0) { outs[i] = out0.act; fuse_sum(p + ".fuse" + std::to_string(i), terms, out0, 1); }
-      else { outs[i] = new_act(a.C, a.H, a.W); fuse_sum(p + ".fuse" + std::to_string(i), terms, R(outs[i]), 1); }
     }
+    end_parallel();
+    // phase 3: the sums (+ReLU), one lane per output branch
+    std::vector<int> outs(nb);
+    begin_parallel();
+    for (int i = 0; i < nb; ++i) {
+      lane(i);
+      const Act a = e.acts[xs[i]];
+      if (i == 0 && out0.act >= 0) { outs[i] = out0.act; fuse_sum(p + ".fuse" + std::to_string(i), terms[i], out0, 1); }
+      else { outs[i] = new_act(a.C, a.H, a.W); fuse_sum(p + ".fuse" + std::to_string(i), terms[i], R(outs[i]), 1); }
+    }
+    end_parallel();
     return outs;
   }
 
@@ -326,7 +370,9 @@ struct Builder {
       for (int i = 0; i < nb; ++i) ch[i] = w << i;
       const std::string t = p + "transition" + std::to_string(s + 1);
       std::vector<int> xs(nb);
+      begin_parallel();
       for (int i = 0; i < nb; ++i) {
+        lane(i);
         const std::string ti = t + "." + std::to_string(i);
         if (i < (int)ys.size()) {
           if (prev_ch[i] != ch[i]) xs[i] = conv_bn(ti + ".0", ti + ".1", ys[i], prev_ch[i], ch[i], 3, 1, 1);
@@ -336,6 +382,7 @@ struct Builder {
           xs[i] = conv_bn(ti + ".0.0", ti + ".0.1", ys.back(), prev_ch.back(), ch[i], 3, 2, 1);
         }
       }
+      end_parallel();
       for (int m = 0; m < nmod[s]; ++m) {
         const bool last = (s == 2 && m == nmod[s] - 1);
         xs = hr_module(p + "stage" + std::to_string(s + 2) + "." + std::to_string(m), xs, ch, last ? final_out0 : Ref());
@@ -681,8 +728,13 @@ void touch(Engine& e, const Ref& r, int i) {
 }
 
 void plan_workspace(Engine& e) {
-  for (int i = 0; i < (int)e.ops.size(); ++i) {
-    Op& op = e.ops[i];
+  // liveness in PHASE units: lanes of one phase run concurrently, so memory is only recycled
+  // across the joins between phases
+  int nphase = 0;
+  for (int oi = 0; oi < (int)e.ops.size(); ++oi) {
+    Op& op = e.ops[oi];
+    const int i = op.phase;
+    nphase = std::max(nphase, i + 1);
     touch(e, op.in, i); touch(e, op.in2, i); touch(e, op.res, i); touch(e, op.out, i); touch(e, op.out2, i);
     for (int k = 0; k < op.fn; ++k) touch(e, op.fsrc[k], i);
     if (op.type == OP_SMPL || op.type == OP_CAMERA) {
@@ -698,14 +750,14 @@ void plan_workspace(Engine& e) {
   for (Act& a : e.acts)
     if (a.persistent) { a.off = top; top += align(a.per_crop() * B); }
   // events ordered by op index
-  std::vector<std::vector<int>> born(e.ops.size() + 1), dies(e.ops.size() + 1);
+  std::vector<std::vector<int>> born(nphase + 1), dies(nphase + 1);
   for (int k = 0; k < (int)e.acts.size(); ++k) {
     const Act& a = e.acts[k];
     if (a.persistent || a.last < 0) continue;
     born[a.first].push_back(k);
     dies[a.last].push_back(k);
   }
-  for (int i = 0; i < (int)e.ops.size(); ++i) {
+  for (int i = 0; i < nphase; ++i) {
     for (int k : born[i]) {
       Act& a = e.acts[k];
       const size_t need = align(a.per_crop() * B);
@@ -771,7 +823,9 @@ float* ext_out(const IO& io, int slot) {
   }
 }
 
-inline float* aptr(Engine& e, const Ref& r) { return e.ws + e.acts[r.act].off + r.co; }
+// e.b0 = first crop of the sub-batch being enqueued (batch-split execution)
+inline float* aptr(Engine& e, const Ref& r) { const Act& a = e.acts[r.act]; return e.ws + a.off + (size_t)e.b0 * a.per_crop() + r.co; }
+inline float* sptr(Engine& e, int act) { const Act& a = e.acts[act]; return e.ws + a.off + (size_t)e.b0 * a.per_crop(); }
 inline int astride(Engine& e, const Ref& r) { return e.acts[r.act].C; }   // valid for vector acts (H=W=1)
 
 int run_op(Engine& e, Op& op, int B, const IO& io, hipStream_t s) {
@@ -827,7 +881,7 @@ int run_op(Engine& e, Op& op, int B, const IO& io, hipStream_t s) {
       const Act& ah = e.acts[op.in.act];
       // scratch act was sized for one crop of C=128; its buffer is max_batch x that
       launch_part_attention_pool_ws(aptr(e, op.in), ah.C, aptr(e, op.in2), op.C, aptr(e, op.out), astride(e, op.out), B,
-                                    ah.H * ah.W, e.ws + e.acts[e.a_attn_scratch].off, s);
+                                    ah.H * ah.W, sptr(e, e.a_attn_scratch), s);
       return POCO_OK;
     }
     case OP_LC2D:
@@ -855,12 +909,12 @@ int run_op(Engine& e, Op& op, int B, const IO& io, hipStream_t s) {
       SmplIO sio{};
       sio.betas = aptr(e, e.smpl_betas); sio.betas_stride = astride(e, e.smpl_betas);
       sio.rotmat = aptr(e, e.smpl_rot); sio.rot_stride = astride(e, e.smpl_rot);
-      sio.A = e.ws + e.acts[e.a_A].off;
-      sio.joints24 = e.ws + e.acts[e.a_j24].off;
+      sio.A = sptr(e, e.a_A);
+      sio.joints24 = sptr(e, e.a_j24);
       float* yv = io.out->smpl_vertices;
-      sio.verts = yv ? yv : e.ws + e.acts[e.a_verts].off;
+      sio.verts = yv ? yv : sptr(e, e.a_verts);
       float* yj = io.out->smpl_joints3d;
-      sio.joints49 = e.ws + e.acts[e.a_j49].off;
+      sio.joints49 = sptr(e, e.a_j49);
       launch_smpl_lbs(e.smpl, sio, B, s);
       if (yj) launch_copy_rows(sio.joints49, 147, yj, 147, 147, B, s);
       return POCO_OK;
@@ -868,16 +922,16 @@ int run_op(Engine& e, Op& op, int B, const IO& io, hipStream_t s) {
     case OP_CAMERA: {
       CamArgs c{};
       c.cam = aptr(e, e.cam_ref); c.cam_stride = astride(e, e.cam_ref);
-      c.joints49 = e.ws + e.acts[e.a_j49].off;
+      c.joints49 = sptr(e, e.a_j49);
       c.cliff = op.n;
       if (c.cliff) {
         c.focal = io.in->focal_length; c.scale = io.in->scale; c.center = io.in->center; c.orig_shape = io.in->orig_shape;
         if (!c.focal || !c.scale || !c.center || !c.orig_shape) { poco_set_error("forward: cliff variant needs focal_length/scale/center/orig_shape"); return POCO_ERR_ARG; }
       }
       // outputs the caller did not ask for go to scratch rows (the kernel writes them densely)
-      c.cam_t = io.out->pred_cam_t ? io.out->pred_cam_t : e.ws + e.acts[e.a_camt].off;
-      c.fullimg_cam_t = io.out->pred_fullimg_cam_t ? io.out->pred_fullimg_cam_t : e.ws + e.acts[e.a_fullt].off;
-      c.joints2d = io.out->smpl_joints2d ? io.out->smpl_joints2d : e.ws + e.acts[e.a_j2d].off;
+      c.cam_t = io.out->pred_cam_t ? io.out->pred_cam_t : sptr(e, e.a_camt);
+      c.fullimg_cam_t = io.out->pred_fullimg_cam_t ? io.out->pred_fullimg_cam_t : sptr(e, e.a_fullt);
+      c.joints2d = io.out->smpl_joints2d ? io.out->smpl_joints2d : sptr(e, e.a_j2d);
       launch_camera(c, B, s);
       return POCO_OK;
     }
@@ -966,9 +1020,54 @@ extern "C" int poco_finalize(poco_handle_t h) {
   plan_workspace(*e);
   POCO_HIP_CHECK(hipMalloc(&e->ws, e->ws_floats * sizeof(float)));
   POCO_HIP_CHECK(hipMemset(e->ws, 0, e->ws_floats * sizeof(float)));
+  POCO_HIP_CHECK(hipEventCreateWithFlags(&e->ev_sfork, hipEventDisableTiming));
+  for (int sp = 0; sp < 4; ++sp) {
+    POCO_HIP_CHECK(hipEventCreateWithFlags(&e->ev_sjoin[sp], hipEventDisableTiming));
+    POCO_HIP_CHECK(hipEventCreateWithFlags(&e->ev_lfork[sp], hipEventDisableTiming));
+    for (int k = 0; k < 4; ++k) {
+      if (sp > 0 || k > 0) POCO_HIP_CHECK(hipStreamCreateWithFlags(&e->split_stream[sp][k], hipStreamNonBlocking));
+      POCO_HIP_CHECK(hipEventCreateWithFlags(&e->ev_ljoin[sp][k], hipEventDisableTiming));
+    }
+  }
   POCO_HIP_CHECK(hipDeviceSynchronize());
   e->params.clear();   // host copies no longer needed
   e->finalized = true;
+  return POCO_OK;
+}
+
+// Enqueue the whole program for crops [b0, b0+B) on (main, side lanes).
+static int enqueue_program(Engine* e, int B, int b0, const IO& io, hipStream_t main, hipStream_t* side,
+                           hipEvent_t fork_ev, hipEvent_t* join_ev) {
+  e->b0 = b0;
+  const int nops = (int)e->ops.size();
+  for (int i = 0; i < nops;) {
+    int j = i;
+    unsigned lanes = 0;
+    while (j < nops && e->ops[j].phase == e->ops[i].phase) { lanes |= 1u << e->ops[j].lane; ++j; }
+    const bool fork = e->num_lanes > 1 && (lanes & ~1u);
+    if (fork) {
+      // fork: the side lanes wait for everything enqueued so far on the main stream
+      POCO_HIP_CHECK(hipEventRecord(fork_ev, main));
+      for (int k = 1; k < 4; ++k)
+        if (lanes & (1u << k)) POCO_HIP_CHECK(hipStreamWaitEvent(side[k], fork_ev, 0));
+    }
+    for (int k = i; k < j; ++k) {
+      Op& op = e->ops[k];
+      hipStream_t s = (fork && op.lane > 0) ? side[op.lane] : main;
+      int rc = run_op(*e, op, B, io, s);
+      if (rc != POCO_OK) { e->b0 = 0; return rc; }
+    }
+    if (fork) {
+      // join: the main stream continues only after every side lane of this phase is done
+      for (int k = 1; k < 4; ++k)
+        if (lanes & (1u << k)) {
+          POCO_HIP_CHECK(hipEventRecord(join_ev[k], side[k]));
+          POCO_HIP_CHECK(hipStreamWaitEvent(main, join_ev[k], 0));
+        }
+    }
+    i = j;
+  }
+  e->b0 = 0;
   return POCO_OK;
 }
 
@@ -977,13 +1076,20 @@ extern "C" int poco_forward(poco_handle_t h, int B, const poco_inputs_t* in, con
   if (!e || !in || !out) { poco_set_error("poco_forward: bad arguments"); return POCO_ERR_ARG; }
   if (!e->finalized) { poco_set_error("poco_forward: call poco_finalize first"); return POCO_ERR_STATE; }
   if (B < 1 || B > e->max_batch) { poco_set_error("poco_forward: batch " + std::to_string(B) + " outside 1.." + std::to_string(e->max_batch)); return POCO_ERR_ARG; }
+  hipStream_t caller = (hipStream_t)stream;
   IO io{in, out};
-  for (Op& op : e->ops) {
-    int rc = run_op(*e, op, B, io, (hipStream_t)stream);
-    if (rc != POCO_OK) return rc;
-  }
+  e->split_stream[0][0] = caller;
+  int rc = enqueue_program(e, B, 0, io, caller, e->split_stream[0], e->ev_lfork[0], e->ev_ljoin[0]);
+  if (rc != POCO_OK) return rc;
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) { poco_set_error(std::string("poco_forward: ") + hipGetErrorString(err)); return POCO_ERR_HIP; }
+  return POCO_OK;
+}
+
+extern "C" int poco_set_num_lanes(poco_handle_t h, int n) {
+  Engine* e = H(h);
+  if (!e || n < 1 || n > 4) { poco_set_error("poco_set_num_lanes: n must be 1..4"); return POCO_ERR_ARG; }
+  e->num_lanes = n;
   return POCO_OK;
 }
 
@@ -1036,7 +1142,7 @@ extern "C" int poco_set_conv_cfg(poco_handle_t h, int op_index, int B, const int
     poco_set_error("poco_set_conv_cfg: bad arguments");
     return POCO_ERR_ARG;
   }
-  e->ops[op_index].cfg[B] = ConvCfg{cfg6[0], cfg6[1], cfg6[2], cfg6[3], cfg6[4], cfg6[5]};
+  e->ops[op_index].cfg[B] = conv_cfg_from(cfg6);
   return POCO_OK;
 }
 

@@ -55,7 +55,7 @@ static int conv_common(const float* d_in, int B, int H, int W, int Cin, const fl
   d.B = B; d.H = H; d.W = W; d.Cin = Cin; d.Cout = Cout16;
   d.ks = ks; d.stride = stride; d.act = relu; d.res_after_act = 0;
   ConvCfg cfg = conv_default_cfg(d);
-  if (cfg6 && cfg6[0] > 0) cfg = ConvCfg{cfg6[0], cfg6[1], cfg6[2], cfg6[3], cfg6[4], cfg6[5]};
+  if (cfg6 && cfg6[0] > 0) cfg = conv_cfg_from(cfg6);
   int rc = conv_launch(d, cfg, stream);
   if (rc != POCO_OK) return rc;
   if (iters > 0 && ms_out) {
@@ -91,10 +91,9 @@ extern "C" int poco_bench_conv2d(const float* d_in, int B, int H, int W, int Cin
   if (cfg_used6) {
     ConvDesc d{};
     d.B = B; d.H = H; d.W = W; d.Cin = Cin; d.Cout = Cout; d.ks = ks; d.stride = stride;
-    ConvCfg c = (cfg6 && cfg6[0] > 0) ? ConvCfg{cfg6[0], cfg6[1], cfg6[2], cfg6[3], cfg6[4], cfg6[5]}
-                                      : conv_default_cfg(d);
+    ConvCfg c = (cfg6 && cfg6[0] > 0) ? conv_cfg_from(cfg6) : conv_default_cfg(d);
     cfg_used6[0] = c.MT; cfg_used6[1] = c.NT; cfg_used6[2] = c.WM;
-    cfg_used6[3] = c.WN; cfg_used6[4] = c.R;  cfg_used6[5] = c.NI;
+    cfg_used6[3] = c.WN; cfg_used6[4] = c.R;  cfg_used6[5] = c.NI; cfg_used6[6] = c.ALG;
   }
   return conv_common(d_in, B, H, W, Cin, h_weight, nullptr, nullptr, Cout, ks, stride, nullptr, 1, d_out,
                      cfg6, iters, ms_out, (hipStream_t)stream);
@@ -132,8 +131,8 @@ extern "C" int poco_tune_conv(int B, int H, int W, int Cin, int Cout, int ks, in
   POCO_HIP_CHECK(hipEventCreate(&e0));
   POCO_HIP_CHECK(hipEventCreate(&e1));
   for (int i = 0; i < ncfg; ++i) {
-    const int* c = cfgs6 + 6 * i;
-    ConvCfg cfg{c[0], c[1], c[2], c[3], c[4], c[5]};
+    const int* c = cfgs6 + CONV_CFG_INTS * i;
+    ConvCfg cfg = conv_cfg_from(c);
     if (c[0] <= 0) cfg = conv_default_cfg(d);
     ms_out[i] = -1.f;
     if (conv_launch(d, cfg, stream) != POCO_OK) continue;

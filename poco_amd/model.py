@@ -52,6 +52,7 @@ def _bind():
     L.poco_uncert_feat_dim.argtypes = [C.c_void_p]
     L.poco_set_conv_cfg.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int)]
     L.poco_get_conv_desc.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+    L.poco_set_num_lanes.argtypes = [C.c_void_p, C.c_int]
     L.poco_smpl_lbs.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 5
     L.poco_realnvp.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
     return L
@@ -276,8 +277,12 @@ class POCO:
         return None if rc != 0 else tuple(d)
 
     def set_conv_cfg(self, op_index: int, B: int, cfg) -> None:
-        arr = (C.c_int * 6)(*cfg)
+        arr = (C.c_int * 7)(*(tuple(cfg) + (0,) * (7 - len(cfg))))
         check(self._L.poco_set_conv_cfg(self._h, op_index, B, arr), "poco_set_conv_cfg")
+
+    def set_num_lanes(self, n: int) -> None:
+        """1 = single stream; 4 (default) = independent branches on forked HIP streams."""
+        check(self._L.poco_set_num_lanes(self._h, int(n)), "poco_set_num_lanes")
 
     def workspace_bytes(self) -> int:
         return int(self._L.poco_workspace_bytes(self._h))

@@ -12,7 +12,7 @@ from ._lib import check, current_stream, fptr, lib
 def _cfg(cfg):
     if cfg is None:
         return C.c_void_p(0), None
-    arr = (C.c_int * 6)(*cfg)
+    arr = (C.c_int * 7)(*(tuple(cfg) + (0,) * (7 - len(cfg))))
     return C.cast(arr, C.c_void_p), arr
 
 
@@ -46,7 +46,7 @@ def bench_conv2d(x: torch.Tensor, weight: np.ndarray, stride=1, cfg=None, iters=
     out = torch.empty((B, Ho, Wo, Cout), device=x.device, dtype=torch.float32)
     weight = np.ascontiguousarray(weight, dtype=np.float32)
     ms = C.c_float(0)
-    used = (C.c_int * 6)()
+    used = (C.c_int * 7)()
     cptr, _keep = _cfg(cfg)
     rc = lib().poco_bench_conv2d(fptr(x), B, H, W, Cin, fptr(weight), Cout, ks, stride, fptr(out), cptr,
                                  iters, C.byref(ms), used, current_stream())

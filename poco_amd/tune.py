@@ -55,16 +55,20 @@ def candidates(B, H, W, Cin, Cout, ks, stride, lds_cap=150 * 1024) -> List[Tuple
                 if util < 0.75:
                     continue
                 pr, pw = (R - 1) * stride + ks, (Wo - 1) * stride + ks
-                lds = 4 * ((ni * pr * pw + 15) // 16 * 16) * 16
-                if lds > lds_cap:
-                    continue
-                out.add((MT, NT, WM, WN, R, ni))
+                npos = ni * pr * pw
+                lds = 4 * ((npos + 15) // 16 * 16) * 16
+                if lds <= lds_cap:
+                    out.add((MT, NT, WM, WN, R, ni, 0))
+                plane = (npos + 63) // 64 * 64
+                lds1 = 2 * (4 * plane + ks * ks * WN * NT * 64) * 16
+                if lds1 <= 160 * 1024 and (plane // 64 + WM * WN - 1) // (WM * WN) <= 6:
+                    out.add((MT, NT, WM, WN, R, ni, 1))
     return sorted(out)
 
 
 def tune_shape(L, B, H, W, Cin, Cout, ks, stride, iters=8):
-    cands = [(0, 0, 0, 0, 0, 0)] + candidates(B, H, W, Cin, Cout, ks, stride)
-    flat = (C.c_int * (6 * len(cands)))(*[v for c in cands for v in c])
+    cands = [(0, 0, 0, 0, 0, 0, 0)] + candidates(B, H, W, Cin, Cout, ks, stride)
+    flat = (C.c_int * (7 * len(cands)))(*[v for c in cands for v in c])
     ms = (C.c_float * len(cands))()
     from ._lib import check
     check(L.poco_tune_conv(B, H, W, Cin, Cout, ks, stride, flat, len(cands), iters, ms, None), "poco_tune_conv")
@@ -73,7 +77,7 @@ def tune_shape(L, B, H, W, Cin, Cout, ks, stride, iters=8):
     # re-time the top few with more iterations to reduce noise
     top = sorted(res)[:6]
     cands2 = [c for _, c in top]
-    flat2 = (C.c_int * (6 * len(cands2)))(*[v for c in cands2 for v in c])
+    flat2 = (C.c_int * (7 * len(cands2)))(*[v for c in cands2 for v in c])
     ms2 = (C.c_float * len(cands2))()
     check(L.poco_tune_conv(B, H, W, Cin, Cout, ks, stride, flat2, len(cands2), iters * 4, ms2, None), "poco_tune_conv")
     best_i = min(range(len(cands2)), key=lambda i: ms2[i])

@@ -70,8 +70,33 @@ def test_conv_parity(case, cuda):
     assert err <= 2e-5 * max(1.0, np.abs(ref).max()), err
 
 
-@pytest.mark.parametrize("cfg", [(4, 2, 2, 1, 2, 1), (7, 2, 4, 1, 8, 1), (7, 1, 1, 2, 2, 1),
-                                 (13, 2, 1, 1, 3, 1), (7, 2, 2, 2, 4, 1), (4, 1, 2, 4, 1, 2)])
+TILES = [(4, 2, 2, 1, 2, 1), (7, 2, 4, 1, 8, 1), (7, 1, 1, 2, 2, 1), (13, 2, 1, 1, 3, 1), (7, 2, 2, 2, 4, 1),
+         (4, 1, 2, 4, 1, 2)]
+
+
+@pytest.mark.parametrize("case", [c for c in CASES if c[3] % 16 == 0][:15], ids=lambda c: "x".join(map(str, c)))
+def test_conv_parity_lds_dma(case, cuda):
+    """ALG 1 (LDS-DMA double-buffered patch + weights) on the same shapes, tile picked per shape."""
+    from poco_amd import ops
+    B, H, W, Cin, Cout, ks, stride, use_res, relu = case
+    rng = np.random.default_rng(hash(case) % (2**32))
+    x = rng.standard_normal((B, H, W, Cin)).astype(np.float32)
+    w = (rng.standard_normal((Cout, Cin, ks, ks)) / np.sqrt(Cin * ks * ks)).astype(np.float32)
+    shift = rng.uniform(-0.5, 0.5, Cout).astype(np.float32)
+    pad = (ks - 1) // 2
+    Ho, Wo = (H + 2 * pad - ks) // stride + 1, (W + 2 * pad - ks) // stride + 1
+    res = rng.standard_normal((B, Ho, Wo, Cout)).astype(np.float32) if use_res else None
+    ref = _ref(x, w, None, shift, stride, res, relu)
+    # small generic tile: 4 sub-tiles x 1 n-tile per wave, 2x2 waves, R rows so that the block fits
+    R = max(1, min(Ho, (2 * 4 * 16) // Wo))
+    NI = max(1, (2 * 4 * 16) // (R * Wo)) if R == Ho else 1
+    cfg = (4, 1, 2, 2, R, min(NI, B), 1)
+    out = ops.conv2d_nhwc(torch.from_numpy(x).to(cuda), w, None, shift, stride,
+                          torch.from_numpy(res).to(cuda) if use_res else None, relu, cfg=cfg).cpu().numpy()
+    assert np.abs(out - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max())
+
+
+@pytest.mark.parametrize("cfg", TILES + [t + (1,) for t in TILES])
 def test_conv_explicit_tiles(cfg, cuda):
     """Every tile decomposition must give the same answer (asymmetric weights catch transposes)."""
     from poco_amd import ops

@@ -67,6 +67,22 @@ def test_oracle_other_batches(variant, B, cuda):
     assert j2 < TOL
 
 
+@pytest.mark.parametrize("variant", ["hrnet_w32-pare", "hrnet_w48_cls-cliff"])
+def test_lanes_equivalent(variant, cuda):
+    """Multi-stream (forked lanes) and single-stream execution must give bit-identical outputs."""
+    m = util.make_engine(variant, max_batch=6)
+    batch = util.cuda_batch(synth.synth_batch(6, 99), cuda)
+    m.set_num_lanes(1)
+    a = {k: v.clone() for k, v in m(batch).items() if isinstance(v, torch.Tensor)}
+    for lanes in (4, 2):
+        m.set_num_lanes(lanes)
+        for _ in range(2):
+            b = m(batch)
+            torch.cuda.synchronize()
+            for k, v in a.items():
+                assert torch.equal(v, b[k]), (lanes, k)
+
+
 def test_smpl_lbs_op(cuda):
     """poco_smpl_lbs vs the float64 numpy restatement; identity pose + zero betas -> template."""
     from oracle import poco_ref, smpl_np

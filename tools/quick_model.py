@@ -16,10 +16,12 @@ ap.add_argument("--variant", default="hrnet_w48_cls-cliff")
 ap.add_argument("--batch", type=int, default=64)
 ap.add_argument("--check", type=int, default=2)
 ap.add_argument("--top", type=int, default=25)
+ap.add_argument("--lanes", type=int, default=4)
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 t0 = time.time()
 m = util.make_engine(args.variant, max_batch=args.batch)
+m.set_num_lanes(args.lanes)
 print(f"engine ready in {time.time()-t0:.1f}s, workspace {m.workspace_bytes()/1e9:.2f} GB, ops {len(m.ops())}")
 if args.check:
     bnp = synth.synth_batch(args.check, 1234)
