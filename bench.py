@@ -27,7 +27,6 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 / 32x32x2_f32 dense peak
 FLOW_LAYERS = {"hrnet_w32-pare": 3, "hrnet_w48_cls-cliff": 1, "resnet50-cliff": 1}
-REC = 254                        # floats per crop in the all-gathered record
 
 
 def load_spec(variant):
@@ -42,16 +41,6 @@ def build_model(variant, max_batch, device):
     w = synth.synth_state_dict(load_spec(variant), 0)
     m.load_state_dict({k: v for k, v in w.items() if v.dtype != np.int64}, strict=True)
     return m.finalize()
-
-
-def pack_record(out, rec):
-    """[B,254] record that is all-gathered."""
-    B = rec.shape[0]
-    rec[:, 0:216] = out["pred_pose"].reshape(B, 216)
-    rec[:, 216:226] = out["pred_shape"]
-    rec[:, 226:229] = out["pred_cam"]
-    rec[:, 229:253] = out["var_pose"]
-    rec[:, 253] = out["var_pose"][:, 0]
 
 
 def cpu_baseline(variant, seconds_budget=25.0):
@@ -120,15 +109,14 @@ def main():
     model = build_model(args.variant, B, device)
     batch = {k: torch.from_numpy(v).to(device) for k, v in synth.synth_batch(B, 1234 + rank).items()}
     out = model._alloc_outputs(B, want_segm=False)
-    rec = torch.empty(B, REC, device=device)
-    gathered = torch.empty(world * B, REC, device=device) if world > 1 else None
+    from poco_amd import dist as pdist
+    gathered = torch.empty(world * B, pdist.REC, device=device) if world > 1 else None
     flops_per_crop = sum(f for _, f, _ in model.ops())
 
     def step():
         model(batch, out=out)
         if world > 1 and not args.no_gather:
-            pack_record(out, rec)
-            dist.all_gather_into_tensor(gathered, rec)
+            dist.all_gather_into_tensor(gathered, pdist.pack_records(out))
 
     for _ in range(args.warmup):
         step()

@@ -1,0 +1,57 @@
+"""demo.py - the reference's demo CLI (demo.py:219-311) on the MI355X engine.
+
+    python demo.py --cfg configs/demo_poco_cliff.yaml --ckpt data/poco_cliff.pt \\
+                   --mode folder --image_folder <dir> --output_folder out --smpl data/smpl/SMPL_NEUTRAL.npz
+
+Same flags as the reference where they concern the regressor (--cfg --ckpt --mode --image_folder
+--vid_file --output_folder --batch_size --no_render --no_kinematic_uncert --inf_model).  Detector /
+tracker / renderer are third-party and out of scope: person boxes come from
+--detections (json {image name: [[cx,cy,w,h],...]}, the format multi_person_tracker produces) or
+default to one centred box; results are written as .npz next to what the reference would render.
+--mode video expects --vid_file to be a folder of extracted frames (the reference shells out to
+ffmpeg first, demo.py:71; ffmpeg/cv2 are not part of this image).
+"""
+import argparse
+import json
+import os
+import sys
+
+
+def parse_args(argv=None):
+    p = argparse.ArgumentParser()
+    p.add_argument("--cfg", type=str, required=True, help="config file that defines model hyperparams")
+    p.add_argument("--ckpt", type=str, required=True, help="checkpoint path (.pt/.ckpt/.pth or run dir)")
+    p.add_argument("--inf_model", type=str, default="best")
+    p.add_argument("--mode", default="folder", choices=["video", "folder", "directory", "webcam"])
+    p.add_argument("--vid_file", type=str, help="folder of extracted video frames")
+    p.add_argument("--image_folder", type=str, help="input image folder")
+    p.add_argument("--output_folder", type=str, default="out", help="output folder to write results")
+    p.add_argument("--batch_size", type=int, default=64, help="batch size of POCO")
+    p.add_argument("--tracker_batch_size", type=int, default=12)
+    p.add_argument("--detector", type=str, default="yolo")
+    p.add_argument("--no_render", action="store_true", help="(rendering is out of scope; always off)")
+    p.add_argument("--no_kinematic_uncert", action="store_false",
+                   help="Do not use SMPL Kinematic for uncert (same store_false semantics as the reference)")
+    p.add_argument("--smooth", action="store_true")
+    p.add_argument("--skip_frame", type=int, default=1)
+    p.add_argument("--detections", type=str, default=None, help="json: {image name: [[cx,cy,w,h],...]}")
+    p.add_argument("--smpl", type=str, default="data/smpl/SMPL_NEUTRAL.npz",
+                   help="SMPL body model as .npz (tools/convert_smpl.py converts the licensed .pkl)")
+    return p.parse_args(argv)
+
+
+def main(args):
+    from poco_amd.tester import POCOTester, load_detections
+    if args.mode in ("webcam",):
+        sys.exit("webcam mode needs a capture device + renderer: out of scope")
+    folder = args.image_folder if args.mode in ("folder", "directory") else args.vid_file
+    if not folder or not os.path.isdir(folder):
+        sys.exit(f"input folder not found: {folder}")
+    tester = POCOTester(args)
+    stats = tester.run_on_image_folder(folder, load_detections(args.detections),
+                                       os.path.join(args.output_folder, os.path.basename(os.path.normpath(folder)) + "_"))
+    print(json.dumps({"poco_fps": round(stats["fps"], 2), **stats}))     # reference logs 'poco FPS' (demo.py:136-145)
+
+
+if __name__ == "__main__":
+    main(parse_args())

@@ -127,6 +127,13 @@ int poco_bench_conv2d(const float* d_in, int B, int H, int W, int Cin, const flo
                       int ks, int stride, float* d_out, const int* cfg6, int iters, float* ms_out,
                       int* cfg_used6, void* stream);
 
+/* GPU-side crop + normalise: replaces the per-detection CPU loop cv2.warpAffine(INTER_LINEAR,
+ * BORDER_CONSTANT) -> ToTensor -> Normalize + per-crop H2D copy of pocolib/core/tester.py:182-203 and
+ * pocolib/utils/vibe_image_utils.py:94-107,233-266,343-351.
+ * d_frame uint8 [H,W,3] RGB, d_boxes [N,4] (cx,cy,w,h) px, d_out [N,3,res,res] fp32 NCHW. */
+int poco_crop_normalize(const unsigned char* d_frame, int H, int W, const float* d_boxes, int N, float bbox_scale,
+                        int res, float* d_out, void* stream);
+
 /* Time `ncfg` tile configurations (6 ints each; MT<=0 = heuristic) for one conv shape on random
  * data; ms_out[i] < 0 = configuration invalid for this shape.  Used by poco_amd/tune.py. */
 int poco_tune_conv(int B, int H, int W, int Cin, int Cout, int ks, int stride, const int* cfgs6, int ncfg,

@@ -97,3 +97,9 @@ struct FlowDev {
 // log_prob (backward_p + N(0,I) prior, layers/real_nvp.py:40-65) or forward_p (:25-38).
 void launch_realnvp(const FlowDev& f, const float* x, const float* ctx, float* out, int N, int forward,
                     hipStream_t s);
+
+// ---- preprocessing (kernels_misc.hip) --------------------------------------------------------------------
+// frame: uint8 [H,W,3] RGB (device); boxes: [N,4] = (cx, cy, w, h) in pixels; out: [N,3,res,res] fp32 NCHW,
+// bilinear affine crop of box*scale -> uint8 rounding -> /255 -> ImageNet mean/std.
+void launch_crop_normalize(const unsigned char* frame, int H, int W, const float* boxes, float bbox_scale, float* out,
+                           int N, int res, hipStream_t s);

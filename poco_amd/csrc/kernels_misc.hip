@@ -185,3 +185,43 @@ void launch_avgpool(const float* in, float* dst, int B, int HW, int C, int dst_s
   hipLaunchKernelGGL(avgpool_kernel, dim3(nblk(n, 256)), dim3(256), 0, s, (const float4*)in, dst, B, HW, C / 4,
                      dst_stride);
 }
+
+// ---- GPU-side crop + normalise ---------------------------------------------------
+// Replaces the per-crop CPU loop  cv2.warpAffine(bilinear, BORDER_CONSTANT) -> ToTensor -> Normalize
+// + per-crop H2D copy of pocolib/core/tester.py:182-203 / utils/vibe_image_utils.py:94-107,233-266,
+// 343-351.  One thread per output pixel, frame read once from HBM (uint8 HWC RGB), output NCHW fp32.
+namespace {
+__global__ void crop_normalize_kernel(const unsigned char* __restrict__ frame, int H, int W,
+                                      const float* __restrict__ boxes, float bbox_scale, float* __restrict__ out,
+                                      int N, int res) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)N * res * res) return;
+  const int x = (int)(i % res), y = (int)((i / res) % res), n = (int)(i / ((long)res * res));
+  const float cx = boxes[n * 4], cy = boxes[n * 4 + 1], bw = boxes[n * 4 + 2], bh = boxes[n * 4 + 3];
+  // gen_trans_from_patch_cv (rot = 0): src = centre + (dst - res/2) * (bbox * scale / res)
+  const float sx = cx + ((float)x - 0.5f * res) * (bw * bbox_scale / res);
+  const float sy = cy + ((float)y - 0.5f * res) * (bh * bbox_scale / res);
+  const int x0 = (int)floorf(sx), y0 = (int)floorf(sy);
+  const float fx = sx - x0, fy = sy - y0;
+  const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    float v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int xx = x0 + (k & 1), yy = y0 + (k >> 1);
+      v[k] = ((unsigned)xx < (unsigned)W && (unsigned)yy < (unsigned)H) ? (float)frame[((size_t)yy * W + xx) * 3 + c] : 0.f;
+    }
+    float p = (1.f - fy) * ((1.f - fx) * v[0] + fx * v[1]) + fy * ((1.f - fx) * v[2] + fx * v[3]);
+    p = fminf(fmaxf(rintf(p), 0.f), 255.f);                 // cv2 stores the warped crop as uint8
+    out[(((size_t)n * 3 + c) * res + y) * res + x] = (p / 255.f - mean[c]) / stdv[c];
+  }
+}
+}  // namespace
+
+void launch_crop_normalize(const unsigned char* frame, int H, int W, const float* boxes, float bbox_scale, float* out,
+                           int N, int res, hipStream_t s) {
+  const long n = (long)N * res * res;
+  hipLaunchKernelGGL(crop_normalize_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, frame, H, W, boxes,
+                     bbox_scale, out, N, res);
+}

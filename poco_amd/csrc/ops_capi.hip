@@ -149,3 +149,17 @@ extern "C" int poco_tune_conv(int B, int H, int W, int Cin, int Cout, int ks, in
   (void)hipEventDestroy(e1);
   return POCO_OK;
 }
+
+#include "kernels.h"
+extern "C" int poco_crop_normalize(const unsigned char* d_frame, int H, int W, const float* d_boxes, int N,
+                                   float bbox_scale, int res, float* d_out, void* stream) {
+  if (!d_frame || !d_boxes || !d_out || N < 0 || H < 1 || W < 1 || res < 1) {
+    poco_set_error("poco_crop_normalize: bad arguments");
+    return POCO_ERR_ARG;
+  }
+  if (N == 0) return POCO_OK;
+  launch_crop_normalize(d_frame, H, W, d_boxes, bbox_scale, d_out, N, res, (hipStream_t)stream);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { poco_set_error(std::string("poco_crop_normalize: ") + hipGetErrorString(e)); return POCO_ERR_HIP; }
+  return POCO_OK;
+}

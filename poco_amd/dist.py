@@ -1,0 +1,56 @@
+"""Multi-GPU data parallelism for the per-crop regressor (new functionality; the reference has no
+distributed inference).  One process per GPU; crops are independent, so a batch is cut
+into contiguous shards and the only exchange is an all-gather of a packed per-crop record
+[rotmat 216 | betas 10 | cam 3 | var 24 | global-uncert 1] = 254 floats (RCCL over xGMI when the
+process group's backend is "nccl"; the same code runs on gloo for the CPU tests)."""
+from __future__ import annotations
+
+from typing import Dict, List, Tuple
+
+import torch
+
+REC = 254
+FIELDS = (("pred_pose", 0, 216), ("pred_shape", 216, 226), ("pred_cam", 226, 229), ("var_pose", 229, 253),
+          ("var_global", 253, 254))
+
+
+def shard_range(n: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous shard [lo, hi) of n crops for `rank`: the first n % world ranks get one extra."""
+    base, extra = divmod(n, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def pack_records(out: Dict[str, torch.Tensor], var_global: torch.Tensor | None = None) -> torch.Tensor:
+    B = out["pred_shape"].shape[0]
+    rec = torch.empty(B, REC, device=out["pred_shape"].device, dtype=torch.float32)
+    rec[:, 0:216] = out["pred_pose"].reshape(B, 216)
+    rec[:, 216:226] = out["pred_shape"]
+    rec[:, 226:229] = out["pred_cam"]
+    rec[:, 229:253] = out["var_pose"]
+    rec[:, 253] = out["var_pose"][:, 0] if var_global is None else var_global
+    return rec
+
+
+def unpack_records(rec: torch.Tensor) -> Dict[str, torch.Tensor]:
+    d = {name: rec[:, lo:hi] for name, lo, hi in FIELDS}
+    d["pred_pose"] = d["pred_pose"].reshape(-1, 24, 3, 3)
+    d["var_global"] = d["var_global"][:, 0]
+    return d
+
+
+def all_gather_records(rec: torch.Tensor, n_total: int, group=None) -> torch.Tensor:
+    """Gather the per-rank [n_r, 254] records into [n_total, 254] in crop order (ragged shards are
+    padded to the largest shard for the collective and trimmed afterwards)."""
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    sizes = [shard_range(n_total, r, world) for r in range(world)]
+    nmax = max(hi - lo for lo, hi in sizes)
+    send = rec
+    if rec.shape[0] < nmax:
+        send = torch.zeros(nmax, REC, device=rec.device, dtype=rec.dtype)
+        send[: rec.shape[0]] = rec
+    buf = torch.empty(world * nmax, REC, device=rec.device, dtype=rec.dtype)
+    dist.all_gather_into_tensor(buf, send.contiguous(), group=group)
+    parts: List[torch.Tensor] = [buf[r * nmax: r * nmax + (hi - lo)] for r, (lo, hi) in enumerate(sizes)]
+    return torch.cat(parts, 0)

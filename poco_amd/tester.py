@@ -1,0 +1,144 @@
+"""POCOTester for the MI355X engine: batch assembly + post-processing of
+pocolib/core/tester.py:153-245 (folder mode) and :362-479 (per-track video mode), without the
+third-party detector / tracker / renderer (out of scope: SURVEY.md 2 rows 2,27).  Detections are an
+input: {image name: [[cx, cy, w, h], ...]} (what multi_person_tracker hands to the reference).
+
+Per image the crops are produced on the GPU (poco_crop_normalize) from the decoded frame, so the
+reference's per-detection cv2.warpAffine + per-crop H2D copy (tester.py:182-203) disappears."""
+from __future__ import annotations
+
+import ctypes as C
+import json
+import os
+import time
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+
+from . import postproc
+from ._lib import check, lib
+from .config import model_kwargs, update_hparams
+from .model import POCO
+
+IMG_EXT = (".png", ".jpg", ".jpeg")
+
+
+def calculate_focal_length(img_h, img_w):
+    return float((img_w ** 2 + img_h ** 2) ** 0.5)          # image_utils.py:171-172
+
+
+def calculate_bbox_info(center, scale, orig_shape):
+    img_h, img_w = orig_shape
+    f = calculate_focal_length(img_h, img_w)
+    info = np.array([center[0] - img_w / 2.0, center[1] - img_h / 2.0, scale * 200.0])
+    info[:2] = info[:2] / f * 2.8
+    info[2] = (info[2] - 0.24 * f) / (0.06 * f)
+    return info.astype(np.float32)                            # image_utils.py:174-187
+
+
+def crop_normalize(frame_u8: torch.Tensor, boxes: torch.Tensor, bbox_scale: float = 1.0, res: int = 224) -> torch.Tensor:
+    """frame uint8 [H,W,3] RGB cuda, boxes [N,4] (cx,cy,w,h) cuda fp32 -> [N,3,res,res] fp32."""
+    assert frame_u8.is_cuda and frame_u8.dtype == torch.uint8 and frame_u8.is_contiguous()
+    H, W, _ = frame_u8.shape
+    N = boxes.shape[0]
+    out = torch.empty(N, 3, res, res, device=frame_u8.device, dtype=torch.float32)
+    L = lib()
+    L.poco_crop_normalize.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_void_p,
+                                      C.c_void_p]
+    check(L.poco_crop_normalize(frame_u8.data_ptr(), H, W, boxes.contiguous().data_ptr(), N, float(bbox_scale), res,
+                                out.data_ptr(), C.c_void_p(torch.cuda.current_stream().cuda_stream)), "poco_crop_normalize")
+    return out
+
+
+class POCOTester:
+    def __init__(self, args):
+        self.args = args
+        self.model_cfg = update_hparams(args.cfg)
+        # demo.py:305 passes store_false: default True = kinematic post-processing on
+        self.model_cfg.POCO.KINEMATIC_UNCERT = getattr(args, "no_kinematic_uncert", True)
+        self.backbone = self.model_cfg.POCO.BACKBONE
+        self.device = torch.device("cuda:0")
+        kw = model_kwargs(self.model_cfg)
+        self.model = POCO(**kw, pretrained=args.ckpt, inf_model=getattr(args, "inf_model", "best"),
+                          max_batch=max(int(args.batch_size), 1), smpl=args.smpl, device="cuda:0").finalize()
+
+    # ---- one batch of detections of one frame ---------------------------------------------------
+    def make_batch(self, frame_u8: torch.Tensor, dets: np.ndarray, bbox_scale: float = 1.0) -> Dict[str, torch.Tensor]:
+        H, W = int(frame_u8.shape[0]), int(frame_u8.shape[1])
+        dets = np.asarray(dets, dtype=np.float32).reshape(-1, 4)
+        boxes = torch.from_numpy(dets).to(self.device)
+        centers = dets[:, :2]
+        scales = np.maximum(dets[:, 2], dets[:, 3]) / 200.0                        # tester.py:196
+        info = np.stack([calculate_bbox_info(c, s, (H, W)) for c, s in zip(centers, scales)])
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(self.device)   # noqa: E731
+        return {"img": crop_normalize(frame_u8, boxes, bbox_scale, self.model_cfg.DATASET.IMG_RES),
+                "bbox_info": t(info), "focal_length": t(np.full(len(dets), calculate_focal_length(H, W))),
+                "scale": t(scales), "center": t(centers), "orig_shape": t(np.tile([[H, W]], (len(dets), 1)))}
+
+    def postprocess(self, output, dets: np.ndarray, W: int, H: int) -> Dict[str, np.ndarray]:
+        dets = np.asarray(dets, dtype=np.float32).reshape(-1, 4)
+        pred_cam = output["pred_cam"].cpu().numpy()
+        res = {"pred_cam": pred_cam, "orig_cam": postproc.convert_crop_cam_to_orig_img(pred_cam, dets, W, H),
+               "verts": output["smpl_vertices"].cpu().numpy(), "pose": output["pred_pose"].cpu().numpy(),
+               "betas": output["pred_shape"].cpu().numpy(), "joints3d": output["smpl_joints3d"].cpu().numpy(),
+               "bboxes": dets}
+        j2d = output["smpl_joints2d"].cpu().numpy()
+        if "cliff" not in self.backbone:                                             # tester.py:225-230
+            j2d = postproc.convert_crop_coords_to_orig_img(dets, j2d, self.model_cfg.DATASET.IMG_RES)
+        res["smpl_joints2d"] = np.concatenate([j2d, np.ones((len(dets), 49, 1), np.float32)], -1)
+        var = postproc.prepare_uncert(output["var_pose"], self.model_cfg.POCO.KINEMATIC_UNCERT)
+        res["var"] = var
+        res["var_global"] = postproc.global_uncert(var, self.backbone)               # tester.py:242-245
+        return res
+
+    @torch.no_grad()
+    def run_on_frames(self, frames, detections: List[np.ndarray], bbox_scale: float = 1.0):
+        """frames: iterable of uint8 [H,W,3] RGB arrays; detections[i]: [n_i,4].  Returns per-frame results."""
+        results = []
+        bs = self.model.max_batch
+        for frame, dets in zip(frames, detections):
+            dets = np.asarray(dets, dtype=np.float32).reshape(-1, 4)
+            if len(dets) == 0:
+                results.append(None)
+                continue
+            fr = torch.from_numpy(np.ascontiguousarray(frame)).to(self.device)
+            parts = []
+            for lo in range(0, len(dets), bs):
+                d = dets[lo:lo + bs]
+                out = self.model(self.make_batch(fr, d, bbox_scale), want_segm=False)
+                parts.append(self.postprocess(out, d, frame.shape[1], frame.shape[0]))
+            results.append({k: np.concatenate([p[k] for p in parts], 0) for k in parts[0]})
+        return results
+
+    def run_on_image_folder(self, image_folder: str, detections: Optional[dict], output_path: str, bbox_scale=1.0):
+        from PIL import Image
+        names = sorted(x for x in os.listdir(image_folder) if x.lower().endswith(IMG_EXT))
+        frames, dets = [], []
+        for n in names:
+            img = np.asarray(Image.open(os.path.join(image_folder, n)).convert("RGB"))
+            frames.append(img)
+            if detections and n in detections:
+                dets.append(np.asarray(detections[n], dtype=np.float32))
+            else:                       # no detector in scope: one centred square box over the image
+                H, W = img.shape[:2]
+                s = float(min(H, W))
+                dets.append(np.array([[W / 2.0, H / 2.0, s, s]], dtype=np.float32))
+        t0 = time.time()
+        results = self.run_on_frames(frames, dets, bbox_scale)
+        torch.cuda.synchronize()
+        dt = time.time() - t0
+        os.makedirs(output_path, exist_ok=True)
+        n_crops = sum(len(d) for d in dets)
+        for n, r in zip(names, results):
+            if r is not None:
+                np.savez_compressed(os.path.join(output_path, os.path.splitext(n)[0] + "_poco.npz"), **r)
+        return {"images": len(names), "crops": n_crops, "seconds": dt, "fps": len(names) / max(dt, 1e-9),
+                "crops_per_s": n_crops / max(dt, 1e-9)}
+
+
+def load_detections(path: Optional[str]) -> Optional[dict]:
+    if not path:
+        return None
+    with open(path) as f:
+        return json.load(f)

@@ -1,0 +1,67 @@
+"""CPU: the N>1 host path (contiguous sharding + all-gather of SMPL records) with 2 gloo processes."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from poco_amd import dist as pdist
+
+
+def test_shard_ranges_cover_exactly():
+    for n in (0, 1, 7, 64, 65, 511):
+        for w in (1, 2, 3, 8):
+            spans = [pdist.shard_range(n, r, w) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def _fake_outputs(lo, hi):
+    idx = torch.arange(lo, hi, dtype=torch.float32)
+    B = hi - lo
+    return {"pred_pose": (idx.view(B, 1, 1, 1) + torch.arange(216.).view(1, 24, 3, 3) / 1000).contiguous(),
+            "pred_shape": idx.view(B, 1) * 2 + torch.arange(10.).view(1, 10),
+            "pred_cam": idx.view(B, 1) * 3 + torch.arange(3.).view(1, 3),
+            "var_pose": idx.view(B, 1) / 100 + torch.arange(24.).view(1, 24) / 1e4}
+
+
+def _worker(rank, world, port, n_total, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lo, hi = pdist.shard_range(n_total, rank, world)
+    rec = pdist.pack_records(_fake_outputs(lo, hi))
+    full = pdist.all_gather_records(rec, n_total)
+    expect = pdist.pack_records(_fake_outputs(0, n_total))
+    q.put((rank, bool(torch.equal(full, expect)), tuple(full.shape)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_total", [8, 7])
+def test_two_rank_gather_gloo(n_total):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_total, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _ in res), res
+    assert all(shape == (n_total, pdist.REC) for _, _, shape in res)
+
+
+def test_unpack_roundtrip():
+    o = _fake_outputs(0, 5)
+    d = pdist.unpack_records(pdist.pack_records(o))
+    for k in ("pred_pose", "pred_shape", "pred_cam", "var_pose"):
+        assert torch.equal(d[k], o[k])
