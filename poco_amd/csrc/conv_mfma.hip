@@ -22,6 +22,7 @@
 //   * epilogue: + shift[co] (+ residual) (ReLU), written into a channel slice of the destination
 //     (makes torch.cat free, hrnet.py:519).
 #include "common.h"
+#include <algorithm>
 #include <cstdlib>
 
 namespace {
@@ -57,7 +58,9 @@ struct ConvKParams {
   int WM, WN;
   int NTB;               // n-tiles per block (WN * NT)
   int bufF4;             // ALG 1: float4 per LDS buffer (4 planes + KS*KS*NTB weight fragments)
-  int ngroups;           // ALG 1: planeF4 / 64
+  int ngroups;           // ALG 1/2: planeF4 / 64
+  int nblocks_m, nb_n;   // ALG 2: tile grid walked by the persistent blocks
+  int dbg;            // profiling experiments: bit0 = skip the epilogue, bit1 = skip the DMA prologue wait
   int repeat;         // K-loop repetitions (1; >1 = profiling experiment, results meaningless)
   int act;            // 0 none, 1 ReLU, 2 sigmoid
   int res_after_act;  // add the residual after the activation (hrnet_cls.py:475-477)
@@ -330,6 +333,44 @@ conv_dma_kernel(const ConvKParams p) {
     const float4* bufp = smem + (size_t)(it & 1) * p.bufF4;
     const float4* pl = bufp + g * p.planeF4;
     const float4* wl = bufp + 4 * p.planeF4 + (wn * NT) * 64 + lane;
+    if constexpr (MT <= 7 && KS == 3) {
+      // register double-buffered taps: the LDS reads of tap t+1 are in flight while tap t's MFMAs
+      // issue (one wave per SIMD has nobody else to hide the ds_read latency behind)
+      float4 wv[2][NT], av[2][MT];
+#pragma unroll
+      for (int n = 0; n < NT; ++n) wv[0][n] = wl[n * 64];
+#pragma unroll
+      for (int m = 0; m < MT; ++m) av[0][m] = pl[base[m]];
+#pragma unroll
+      for (int tap = 0; tap < KS * KS; ++tap) {
+        const int cur = tap & 1, nxt = cur ^ 1;
+        if (tap + 1 < KS * KS) {
+          const int toff = ((tap + 1) / KS) * p.PW + ((tap + 1) % KS);
+#pragma unroll
+          for (int n = 0; n < NT; ++n) wv[nxt][n] = wl[((tap + 1) * p.NTB + n) * 64];
+#pragma unroll
+          for (int m = 0; m < MT; ++m) av[nxt][m] = pl[base[m] + toff];
+        }
+        __builtin_amdgcn_sched_barrier(0);   // keep the prefetch reads ahead of this tap's MFMAs
+#pragma unroll
+        for (int m0 = 0; m0 < MT; m0 += 2) {
+          const float a0v[4] = {av[cur][m0].x, av[cur][m0].y, av[cur][m0].z, av[cur][m0].w};
+          const int m1 = (m0 + 1 < MT) ? m0 + 1 : m0;
+          const float a1v[4] = {av[cur][m1].x, av[cur][m1].y, av[cur][m1].z, av[cur][m1].w};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+              const float4 w4 = wv[cur][n];
+              const float wj = (j == 0) ? w4.x : (j == 1) ? w4.y : (j == 2) ? w4.z : w4.w;
+              acc[m0][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wj, a0v[j], acc[m0][n], 0, 0, 0);
+              if (m0 + 1 < MT)
+                acc[m0 + 1][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wj, a1v[j], acc[m0 + 1][n], 0, 0, 0);
+            }
+          }
+        }
+      }
+    } else {
     int tr = 0, ts = 0;
 #pragma unroll 1
     for (int tap = 0; tap < KS * KS; ++tap) {
@@ -356,11 +397,12 @@ conv_dma_kernel(const ConvKParams p) {
         }
       }
     }
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
 
-  if (nt0 >= p.nT16) return;
+  if (nt0 >= p.nT16 || (p.dbg & 1)) return;
 #pragma unroll
   for (int n = 0; n < NT; ++n) {
     if (nt0 + n >= p.nT16) break;
@@ -389,12 +431,256 @@ conv_dma_kernel(const ConvKParams p) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// ALG 2: ALG 1 made PERSISTENT.  The grid is sized to the machine (blocks = CUs x resident blocks),
+// each block walks tiles  t = blockIdx.x, +gridDim.x, ...  and the (tile, 16-channel slice) pairs
+// form one flat software pipeline: the LDS-DMA of the next slice - or of the NEXT TILE's first
+// slice - is in flight during the current slice's MFMAs, and a tile's epilogue stores are issued
+// right after its last barrier and drain in the background while the next tile computes.  This
+// hides the per-tile prologue (first patch fetch) and epilogue (an HBM-write burst of the whole
+// output tile that every CU used to do at the same time) that cost 10-25 us per launch in ALG 1.
+// ------------------------------------------------------------------------------------------------
+template <int KS, int STRIDE, int MT, int NT>
+__global__ void __launch_bounds__(512)
+conv_dma_persist_kernel(const ConvKParams p) {
+  extern __shared__ float4 smem[];
+  constexpr int PAD = (KS - 1) / 2;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nwaves = blockDim.x >> 6;
+  const int wm = wave % p.WM;
+  const int wn = wave / p.WM;
+  const int idx = lane & 15;
+  const int g = lane >> 4;
+  const int ntiles = p.nblocks_m * p.nb_n;
+  const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) float4*)smem;
+  const int nwitems = KS * KS * p.NTB;
+
+  int base[MT];
+  int goff[DMA_MAXG], goffN[DMA_MAXG];
+
+  auto decode_pixels = [&](int tile) {
+    const int s0 = (tile % p.nblocks_m) * p.NI;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      uint32_t pix = (uint32_t)((wm * MT + m) * 16 + idx);
+      asm volatile("" : "+v"(pix));   // opaque: keep hipcc from hoisting the tile-invariant part into VGPRs
+      const uint32_t sl = fdiv(pix, p.dRWo);
+      const uint32_t rem = pix - sl * p.dRWo.d;
+      const uint32_t yl = fdiv(rem, p.dWo);
+      const uint32_t x = rem - yl * p.dWo.d;
+      const uint32_t s = s0 + sl;
+      const uint32_t b = fdiv(s, p.dBands);
+      const uint32_t band = s - b * p.dBands.d;
+      const uint32_t y = band * p.R + yl;
+      const bool valid = (sl < (uint32_t)p.NI) && (s < (uint32_t)p.S) && (y < (uint32_t)p.Ho);
+      base[m] = valid ? (int)((sl * p.PR + yl * STRIDE) * p.PW + x * STRIDE) : 0;
+    }
+  };
+  // output pixel index of sub-tile m (recomputed in the epilogue instead of living in VGPRs)
+  auto out_pixel = [&](int tile, int m) -> int {
+    const int s0 = (tile % p.nblocks_m) * p.NI;
+    uint32_t pix = (uint32_t)((wm * MT + m) * 16 + idx);
+    asm volatile("" : "+v"(pix));
+    const uint32_t sl = fdiv(pix, p.dRWo);
+    const uint32_t rem = pix - sl * p.dRWo.d;
+    const uint32_t yl = fdiv(rem, p.dWo);
+    const uint32_t x = rem - yl * p.dWo.d;
+    const uint32_t s = s0 + sl;
+    const uint32_t b = fdiv(s, p.dBands);
+    const uint32_t band = s - b * p.dBands.d;
+    const uint32_t y = band * p.R + yl;
+    const bool valid = (sl < (uint32_t)p.NI) && (s < (uint32_t)p.S) && (y < (uint32_t)p.Ho);
+    return valid ? (int)((b * p.Ho + y) * p.Wo + x) : -1;
+  };
+  auto decode_goff = [&](int tile, int* go) {
+    const int s0 = (tile % p.nblocks_m) * p.NI;
+#pragma unroll
+    for (int k = 0; k < DMA_MAXG; ++k) {
+      go[k] = -1;
+      const int grp = wave + k * nwaves;
+      uint32_t pos = (uint32_t)(grp * 64 + lane);
+      asm volatile("" : "+v"(pos));
+      if (grp < p.ngroups && pos < (uint32_t)p.npos) {
+        const uint32_t sl = fdiv(pos, p.dSlab);
+        const uint32_t rem = pos - sl * p.dSlab.d;
+        const uint32_t prow = fdiv(rem, p.dPW);
+        const uint32_t pcol = rem - prow * p.dPW.d;
+        const uint32_t s = s0 + sl;
+        const uint32_t b = fdiv(s, p.dBands);
+        const uint32_t band = s - b * p.dBands.d;
+        const int iy = (int)(band * p.R) * STRIDE - PAD + (int)prow;
+        const int ix = (int)pcol - PAD;
+        if (s < (uint32_t)p.S && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
+          go[k] = (int)(((size_t)(b * p.H + iy) * p.W + ix) * p.in_cs + p.in_co);
+      }
+    }
+  };
+  auto issue = [&](int c, int buf, const int* go, int ntb0) {
+    const unsigned bb = lds_base + (unsigned)buf * (unsigned)p.bufF4 * 16u;
+#pragma unroll
+    for (int k = 0; k < DMA_MAXG; ++k) {
+      const int grp = wave + k * nwaves;
+      if (grp < p.ngroups) {
+        const float* src0 = p.in + go[k] + c * 16;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const void* src = (go[k] >= 0) ? (const void*)(src0 + q * 4) : (const void*)&g_zero_page;
+          lds_dma16(src, (unsigned)__builtin_amdgcn_readfirstlane((int)(bb + (unsigned)(q * p.planeF4 + grp * 64) * 16u)));
+        }
+      }
+    }
+    for (int i = wave; i < nwitems; i += nwaves) {
+      const int tap = i / p.NTB, j = i - tap * p.NTB;
+      const int nt = min(ntb0 + j, p.nT16 - 1);
+      const float4* src = p.wfrag + (((size_t)tap * p.nC16 + c) * p.nT16 + nt) * 64 + lane;
+      lds_dma16(src, (unsigned)__builtin_amdgcn_readfirstlane((int)(bb + (unsigned)(4 * p.planeF4 + i * 64) * 16u)));
+    }
+  };
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  int t = blockIdx.x;
+  if (t >= ntiles) return;
+  decode_goff(t, goff);
+  issue(0, 0, goff, (t / p.nblocks_m) * p.NTB);
+  decode_pixels(t);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  int it = 0;
+  for (; t < ntiles; t += gridDim.x) {
+    const int tn = t + gridDim.x;
+    const bool has_next = tn < ntiles;
+    const int ntb0 = (t / p.nblocks_m) * p.NTB;
+    const int nt0 = ntb0 + wn * NT;
+    for (int c = 0; c < p.nC16; ++c, ++it) {
+      if (c + 1 < p.nC16) issue(c + 1, (it + 1) & 1, goff, ntb0);
+      else if (has_next) {
+        decode_goff(tn, goffN);
+        issue(0, (it + 1) & 1, goffN, (tn / p.nblocks_m) * p.NTB);
+      }
+      const float4* bufp = smem + (size_t)(it & 1) * p.bufF4;
+      const float4* pl = bufp + g * p.planeF4;
+      const float4* wl = bufp + 4 * p.planeF4 + (wn * NT) * 64 + lane;
+      if constexpr (MT <= 7 && KS == 3) {
+        float4 wv[2][NT], av[2][MT];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) wv[0][n] = wl[n * 64];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) av[0][m] = pl[base[m]];
+#pragma unroll
+        for (int tap = 0; tap < KS * KS; ++tap) {
+          const int cur = tap & 1, nxt = cur ^ 1;
+          if (tap + 1 < KS * KS) {
+            const int toff = ((tap + 1) / KS) * p.PW + ((tap + 1) % KS);
+#pragma unroll
+            for (int n = 0; n < NT; ++n) wv[nxt][n] = wl[((tap + 1) * p.NTB + n) * 64];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) av[nxt][m] = pl[base[m] + toff];
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int m0 = 0; m0 < MT; m0 += 2) {
+            const int m1 = (m0 + 1 < MT) ? m0 + 1 : m0;
+            const float a0v[4] = {av[cur][m0].x, av[cur][m0].y, av[cur][m0].z, av[cur][m0].w};
+            const float a1v[4] = {av[cur][m1].x, av[cur][m1].y, av[cur][m1].z, av[cur][m1].w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+#pragma unroll
+              for (int n = 0; n < NT; ++n) {
+                const float4 w4 = wv[cur][n];
+                const float wj = (j == 0) ? w4.x : (j == 1) ? w4.y : (j == 2) ? w4.z : w4.w;
+                acc[m0][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wj, a0v[j], acc[m0][n], 0, 0, 0);
+                if (m0 + 1 < MT)
+                  acc[m0 + 1][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wj, a1v[j], acc[m0 + 1][n], 0, 0, 0);
+              }
+            }
+          }
+        }
+      } else {
+        int tr = 0, ts = 0;
+#pragma unroll 1
+        for (int tap = 0; tap < KS * KS; ++tap) {
+          const int toff = tr * p.PW + ts;
+          if (++ts == KS) { ts = 0; ++tr; }
+          float4 wv[NT];
+#pragma unroll
+          for (int n = 0; n < NT; ++n) wv[n] = wl[(tap * p.NTB + n) * 64];
+#pragma unroll
+          for (int m0 = 0; m0 < MT; m0 += 2) {
+            const float4 a0 = pl[base[m0] + toff];
+            const float4 a1 = pl[base[(m0 + 1 < MT) ? m0 + 1 : m0] + toff];
+            const float a0v[4] = {a0.x, a0.y, a0.z, a0.w};
+            const float a1v[4] = {a1.x, a1.y, a1.z, a1.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+#pragma unroll
+              for (int n = 0; n < NT; ++n) {
+                const float wj = (j == 0) ? wv[n].x : (j == 1) ? wv[n].y : (j == 2) ? wv[n].z : wv[n].w;
+                acc[m0][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wj, a0v[j], acc[m0][n], 0, 0, 0);
+                if (m0 + 1 < MT)
+                  acc[m0 + 1][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wj, a1v[j], acc[m0 + 1][n], 0, 0, 0);
+              }
+            }
+          }
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+    // ---- epilogue of tile t: stores drain while the next tile's MFMAs run ------------------------
+    if (nt0 < p.nT16 && !(p.dbg & 1)) {
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        const int oo = out_pixel(t, m);
+        if (oo < 0) continue;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          if (nt0 + n >= p.nT16) break;
+          const int co = (nt0 + n) * 16 + g * 4;
+          const float4 sh = *reinterpret_cast<const float4*>(p.bias + co);
+          f32x4 v = acc[m][n];
+          v[0] += sh.x; v[1] += sh.y; v[2] += sh.z; v[3] += sh.w;
+          float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (p.res) r = *reinterpret_cast<const float4*>(p.res + (size_t)oo * p.res_cs + p.res_co + co);
+          if (!p.res_after_act) { v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w; }
+          if (p.act == 1) {
+            v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f);
+            v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+          } else if (p.act == 2) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = 1.f / (1.f + __expf(-v[e]));
+          }
+          if (p.res_after_act) { v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w; }
+          *reinterpret_cast<float4*>(p.out + (size_t)oo * p.out_cs + p.out_co + co) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+      }
+    }
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int n = 0; n < NT; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (has_next) {
+#pragma unroll
+      for (int k = 0; k < DMA_MAXG; ++k) goff[k] = goffN[k];
+      decode_pixels(tn);
+    }
+  }
+}
+
 template <int KS, int STRIDE, int MT, int NT>
 int launch_inst(int alg, const ConvKParams& kp, dim3 grid, int nthreads, size_t lds, hipStream_t stream) {
-  auto fn = alg == 1 ? conv_dma_kernel<KS, STRIDE, MT, NT> : conv_mfma_kernel<KS, STRIDE, MT, NT>;
+  auto fn = alg == 2 ? conv_dma_persist_kernel<KS, STRIDE, MT, NT>
+            : alg == 1 ? conv_dma_kernel<KS, STRIDE, MT, NT> : conv_mfma_kernel<KS, STRIDE, MT, NT>;
   if (lds > 64 * 1024) {
-    static thread_local size_t configured_alg[2] = {0, 0};
-    size_t& configured = configured_alg[alg == 1];
+    static thread_local size_t configured_alg[3] = {0, 0, 0};
+    size_t& configured = configured_alg[alg];
     if (lds > configured) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
@@ -442,7 +728,7 @@ bool geometry(const ConvDesc& d, const ConvCfg& c, Geometry* g) {
   g->PR = (c.R - 1) * d.stride + d.ks;
   g->PW = (g->Wo - 1) * d.stride + d.ks;
   g->npos = c.NI * g->PR * g->PW;
-  g->planeF4 = c.ALG == 1 ? ((g->npos + 63) / 64) * 64 : ((g->npos + 15) / 16) * 16;
+  g->planeF4 = c.ALG >= 1 ? ((g->npos + 63) / 64) * 64 : ((g->npos + 15) / 16) * 16;
   g->nblocks_m = (g->S + c.NI - 1) / c.NI;
   return true;
 }
@@ -478,7 +764,7 @@ void conv_pack_weights(const float* w, const float* scale, int Cout, int Cin, in
 }
 
 static size_t lds_bytes_for(const ConvDesc& d, const ConvCfg& cfg, const Geometry& g) {
-  if (cfg.ALG == 1)
+  if (cfg.ALG >= 1)
     return (size_t)2 * ((size_t)4 * g.planeF4 + (size_t)d.ks * d.ks * cfg.WN * cfg.NT * 64) * sizeof(float4);
   return (size_t)4 * g.planeF4 * sizeof(float4);
 }
@@ -581,11 +867,11 @@ int conv_launch(const ConvDesc& d, const ConvCfg& cfg, hipStream_t stream) {
     return POCO_ERR_ARG;
   }
   const size_t lds = lds_bytes_for(d, cfg, g);
-  if (cfg.ALG == 1 && (g.planeF4 / 64 + nwaves - 1) / nwaves > DMA_MAXG) {
+  if (cfg.ALG >= 1 && (g.planeF4 / 64 + nwaves - 1) / nwaves > DMA_MAXG) {
     poco_set_error("conv: halo patch too large for the LDS-DMA variant");
     return POCO_ERR_ARG;
   }
-  if (cfg.ALG < 0 || cfg.ALG > 1) {
+  if (cfg.ALG < 0 || cfg.ALG > 2) {
     poco_set_error("conv: unknown ALG");
     return POCO_ERR_ARG;
   }
@@ -612,6 +898,8 @@ int conv_launch(const ConvDesc& d, const ConvCfg& cfg, hipStream_t stream) {
   {
     static const int rep = [] { const char* e = getenv("POCO_CONV_REPEAT"); return e ? atoi(e) : 1; }();
     kp.repeat = rep >= 0 ? rep : 1;
+    static const int dbg = [] { const char* e = getenv("POCO_CONV_DBG"); return e ? atoi(e) : 0; }();
+    kp.dbg = dbg;
   }
   kp.dPW = make_fastdiv(g.PW);
   kp.dSlab = make_fastdiv(g.PR * g.PW);
@@ -620,6 +908,13 @@ int conv_launch(const ConvDesc& d, const ConvCfg& cfg, hipStream_t stream) {
   kp.dRWo = make_fastdiv(cfg.R * g.Wo);
   const int nb_n = (kp.nT16 + cfg.WN * cfg.NT - 1) / (cfg.WN * cfg.NT);
   dim3 grid(g.nblocks_m, nb_n);
+  kp.nblocks_m = g.nblocks_m; kp.nb_n = nb_n;
+  if (cfg.ALG == 2) {
+    // persistent: as many blocks as can be resident (LDS-limited), never more than tiles
+    const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(2, (160 * 1024) / std::max<size_t>(lds, 1)));
+    const long tiles = (long)g.nblocks_m * nb_n;
+    grid = dim3((unsigned)std::min<long>(tiles, 256L * per_cu), 1);
+  }
   const int nthreads = nwaves * 64;
   if (d.ks == 1 && d.stride == 1) return launch_mtnt<1, 1>(cfg.ALG, cfg.MT, cfg.NT, kp, grid, nthreads, lds, stream);
   if (d.ks == 1 && d.stride == 2) return launch_mtnt<1, 2>(cfg.ALG, cfg.MT, cfg.NT, kp, grid, nthreads, lds, stream);

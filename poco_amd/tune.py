@@ -63,6 +63,7 @@ def candidates(B, H, W, Cin, Cout, ks, stride, lds_cap=150 * 1024) -> List[Tuple
                 lds1 = 2 * (4 * plane + ks * ks * WN * NT * 64) * 16
                 if lds1 <= 160 * 1024 and (plane // 64 + WM * WN - 1) // (WM * WN) <= 6:
                     out.add((MT, NT, WM, WN, R, ni, 1))
+                    out.add((MT, NT, WM, WN, R, ni, 2))
     return sorted(out)
 
 

@@ -74,9 +74,10 @@ TILES = [(4, 2, 2, 1, 2, 1), (7, 2, 4, 1, 8, 1), (7, 1, 1, 2, 2, 1), (13, 2, 1, 
          (4, 1, 2, 4, 1, 2)]
 
 
+@pytest.mark.parametrize("alg", [1, 2])
 @pytest.mark.parametrize("case", [c for c in CASES if c[3] % 16 == 0][:15], ids=lambda c: "x".join(map(str, c)))
-def test_conv_parity_lds_dma(case, cuda):
-    """ALG 1 (LDS-DMA double-buffered patch + weights) on the same shapes, tile picked per shape."""
+def test_conv_parity_lds_dma(case, alg, cuda):
+    """ALG 1 (LDS-DMA double-buffered patch + weights) and ALG 2 (the same, persistent over tiles)."""
     from poco_amd import ops
     B, H, W, Cin, Cout, ks, stride, use_res, relu = case
     rng = np.random.default_rng(hash(case) % (2**32))
@@ -90,18 +91,18 @@ def test_conv_parity_lds_dma(case, cuda):
     # small generic tile: 4 sub-tiles x 1 n-tile per wave, 2x2 waves, R rows so that the block fits
     R = max(1, min(Ho, (2 * 4 * 16) // Wo))
     NI = max(1, (2 * 4 * 16) // (R * Wo)) if R == Ho else 1
-    cfg = (4, 1, 2, 2, R, min(NI, B), 1)
+    cfg = (4, 1, 2, 2, R, min(NI, B), alg)
     out = ops.conv2d_nhwc(torch.from_numpy(x).to(cuda), w, None, shift, stride,
                           torch.from_numpy(res).to(cuda) if use_res else None, relu, cfg=cfg).cpu().numpy()
     assert np.abs(out - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max())
 
 
-@pytest.mark.parametrize("cfg", TILES + [t + (1,) for t in TILES])
+@pytest.mark.parametrize("cfg", TILES + [t + (1,) for t in TILES] + [t + (2,) for t in TILES])
 def test_conv_explicit_tiles(cfg, cuda):
     """Every tile decomposition must give the same answer (asymmetric weights catch transposes)."""
     from poco_amd import ops
     rng = np.random.default_rng(7)
-    B, H, W, Cin, Cout = 3, 56, 56, 32, 64
+    B, H, W, Cin, Cout = 37, 56, 56, 32, 64     # enough tiles that persistent blocks walk several
     x = rng.standard_normal((B, H, W, Cin)).astype(np.float32)
     w = (rng.standard_normal((Cout, Cin, 3, 3)) / 17.0).astype(np.float32)
     ref = _ref(x, w, None, None, 1, None, False)

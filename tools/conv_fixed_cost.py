@@ -9,10 +9,10 @@ from pathlib import Path
 
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 SHAPES = [
-    ((64, 56, 56, 48, 48, 3, 1), [(7, 3, 8, 1, 16, 1, 0), (7, 3, 4, 1, 8, 1, 1), (7, 3, 4, 1, 8, 1, 0), (7, 1, 1, 3, 2, 1, 1), (7, 3, 2, 1, 4, 1, 1), (7, 3, 1, 1, 2, 1, 1)]),
-    ((64, 28, 28, 96, 96, 3, 1), [(7, 3, 4, 1, 7, 2, 1), (7, 3, 2, 2, 7, 1, 0)]),
-    ((64, 14, 14, 192, 192, 3, 1), [(4, 3, 4, 1, 7, 2, 1), (4, 1, 2, 2, 9, 1, 0)]),
-    ((64, 7, 7, 384, 384, 3, 1), [(7, 1, 4, 1, 7, 9, 1), (4, 1, 1, 8, 7, 1, 0)]),
+    ((64, 56, 56, 48, 48, 3, 1), [(7, 3, 8, 1, 16, 1, 0), (7, 3, 4, 1, 8, 1, 1), (7, 3, 4, 1, 8, 1, 2), (7, 3, 2, 1, 4, 1, 2), (7, 3, 4, 1, 4, 2, 2)]),
+    ((64, 28, 28, 96, 96, 3, 1), [(7, 3, 4, 1, 7, 2, 1), (7, 3, 4, 1, 7, 2, 2), (7, 3, 2, 2, 7, 1, 2)]),
+    ((64, 14, 14, 192, 192, 3, 1), [(4, 3, 4, 1, 7, 2, 1), (4, 3, 4, 1, 7, 2, 2)]),
+    ((64, 7, 7, 384, 384, 3, 1), [(7, 1, 4, 1, 7, 9, 1), (7, 1, 4, 1, 7, 9, 2)]),
 ]
 if len(sys.argv) > 1 and sys.argv[1] == "child":
     from poco_amd._lib import lib, check
