@@ -36,7 +36,8 @@ struct ConvCfg {
   int WN;      // waves along output channels  (block = WM*WN waves)
   int R;       // output rows per slab
   int NI;      // slabs (row bands / whole images) per block
-  int ALG;     // 0: register-staged single LDS buffer; 1: LDS-DMA double-buffered (patch + weights)
+  int ALG;     // 0: register-staged single LDS buffer; 1: LDS-DMA double-buffered (patch + weights);
+               // 2: ALG 1 persistent over tiles; 3: Winograd F(2x2,3x3) (MT ignored, NT in {1,2}, R even)
 };
 constexpr int CONV_CFG_INTS = 7;   // ints per configuration in the C ABI / tuning table
 inline ConvCfg conv_cfg_from(const int* c) { return ConvCfg{c[0], c[1], c[2], c[3], c[4], c[5], c[6]}; }
@@ -47,6 +48,7 @@ struct ConvDesc {
   const float* res; int res_cs, res_co;   // optional residual (same spatial shape as the output)
   float*       out; int out_cs, out_co;
   const float* wfrag;                     // weights in MFMA fragment order (see conv_pack_weights)
+  const float* wfrag_wino;                // 3x3 stride-1 only: Winograd-transformed weights (ALG 3), nullable
   const float* bias;                      // [Cout_padded] folded BN shift / conv bias
   int B, H, W, Cin, Cout;                 // Cout = padded to a multiple of 16
   int ks, stride;                         // ks in {1,3}; pad = (ks-1)/2; stride in {1,2}
@@ -66,3 +68,10 @@ ConvCfg conv_default_cfg(const ConvDesc& d);
 int conv_launch(const ConvDesc& d, const ConvCfg& cfg, hipStream_t stream);
 // LDS bytes a configuration needs (0 if invalid).
 size_t conv_lds_bytes(const ConvDesc& d, const ConvCfg& cfg);
+
+// ---- Winograd F(2x2,3x3) variant (conv_wino.hip) --------------------------------------------------
+#include <vector>
+// [Cout][Cin][16] transformed filters (G g G^T, float64 on the host); pack with conv_pack_weights(ks=4).
+void conv_wino_transform_weights(const float* w_oihw, int Cout, int Cin, std::vector<float>* out);
+size_t conv_wino_lds_bytes(const ConvDesc& d, const ConvCfg& cfg);
+int conv_wino_launch(const ConvDesc& d, const ConvCfg& cfg, hipStream_t stream);

@@ -770,6 +770,7 @@ static size_t lds_bytes_for(const ConvDesc& d, const ConvCfg& cfg, const Geometr
 }
 
 size_t conv_lds_bytes(const ConvDesc& d, const ConvCfg& cfg) {
+  if (cfg.ALG == 3) return conv_wino_lds_bytes(d, cfg);
   Geometry g;
   if (!geometry(d, cfg, &g)) return 0;
   return lds_bytes_for(d, cfg, g);
@@ -840,6 +841,13 @@ ConvCfg conv_default_cfg(const ConvDesc& d) {
 }
 
 int conv_launch(const ConvDesc& d, const ConvCfg& cfg, hipStream_t stream) {
+  if (cfg.ALG == 3) {
+    if (d.Cin % 16 || d.Cout % 16 || ((d.in_cs | d.in_co | d.out_cs | d.out_co | d.res_cs | d.res_co) & 3)) {
+      poco_set_error("conv: channel counts/strides must be multiples of 16/4");
+      return POCO_ERR_ARG;
+    }
+    return conv_wino_launch(d, cfg, stream);
+  }
   if (!(d.ks == 1 || d.ks == 3) || !(d.stride == 1 || d.stride == 2)) {
     poco_set_error("conv: ks must be 1|3 and stride 1|2");
     return POCO_ERR_ARG;
@@ -871,7 +879,7 @@ int conv_launch(const ConvDesc& d, const ConvCfg& cfg, hipStream_t stream) {
     poco_set_error("conv: halo patch too large for the LDS-DMA variant");
     return POCO_ERR_ARG;
   }
-  if (cfg.ALG < 0 || cfg.ALG > 2) {
+  if (cfg.ALG < 0 || cfg.ALG > 3) {
     poco_set_error("conv: unknown ALG");
     return POCO_ERR_ARG;
   }

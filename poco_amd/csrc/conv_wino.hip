@@ -1,0 +1,358 @@
+// Winograd F(2x2, 3x3) convolution (stride 1, pad 1) + folded-BN shift + residual + activation on
+// v_mfma_f32_16x16x4_f32  --  ALG 3 of the conv operator (same call sites as conv_mfma.hip).
+//
+// Why: on gfx950 exact-fp32 MFMA runs at the fp32 vector rate (157 TF), so the 3x3 convs of HRNet are
+// bound by MFMA issue, not by HBM.  F(2x2,3x3) needs 16 multiplies per 2x2 output tile and input
+// channel instead of 36 (2.25x fewer MFMAs) at the price of cheap VALU transforms; everything stays
+// fp32 (error a few ulp larger than the direct form, far inside the 1e-3 gate).
+//
+//   Y = A^T [ sum_ci (G g G^T) (.) (B^T d B) ] A          (Lavin & Gray 2016)
+//
+// Mapping (MI355X-first):
+//   * the 16 transform positions xi are 16 independent GEMMs  M_xi[co][tile] += U_xi[co][ci] V_xi[ci][tile];
+//     one wave owns ONE 16-tile sub-tile x NT 16-channel n-tiles x ALL 16 positions, so the inverse
+//     transform needs no cross-lane / LDS exchange: lane (tile = l&15, g = l>>4) ends up with the 16
+//     M_xi values of its tile for 4 consecutive output channels, transforms them in registers and
+//     stores the 2x2 output pixels as 16-byte NHWC pieces.
+//   * the raw input halo patch of the block (R output rows x full width, 16-channel slice) is streamed
+//     into LDS by LDS-DMA exactly as in ALG 1; each lane reads its tile's 4x4 window (16 ds_read_b128
+//     of 4 channels each) and runs B^T d B on float4s.  The patch buffer is single: after every wave
+//     has its window in registers (barrier) the DMA of the next slice overwrites it while the MFMAs of
+//     this slice run.
+//   * the transformed weights U (16 positions, host-side in float64, BN scale folded) are packed in MFMA
+//     fragment order and double-buffered in LDS by the same DMA.
+#include "common.h"
+
+#include <algorithm>
+#include <cstdlib>
+#include <vector>
+
+namespace {
+
+struct FastDiv {
+  uint32_t magic, d;
+};
+inline FastDiv make_fastdiv(uint32_t d) {
+  FastDiv f;
+  f.d = d;
+  f.magic = (uint32_t)(((1ull << 32) + d - 1) / d);
+  return f;
+}
+__device__ __forceinline__ uint32_t fdiv(uint32_t n, FastDiv f) { return f.d == 1 ? n : __umulhi(n, f.magic); }
+
+__device__ float4 g_zero_page_w;
+
+__device__ __forceinline__ void lds_dma16(const void* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(gsrc), "s"(lds_dst)
+      : "memory");
+}
+
+struct WinoParams {
+  const float* in;
+  const float* res;
+  float* out;
+  const float4* ufrag;   // [16][Cin/16][Cout16/16][64] float4
+  const float* bias;
+  int in_cs, in_co, res_cs, res_co, out_cs, out_co;
+  int H, W;              // == Ho, Wo
+  int nC16, nT16;
+  int R, NI, S;          // output rows per slab (even), slabs per block, total slabs
+  int TX;                // tiles per row = ceil(W/2)
+  int PR, PW, npos, planeF4, ngroups;
+  int WM, WN, NTB;
+  int ubufF4;            // float4 per U buffer = 16 * NTB * 64
+  int act, res_after_act;
+  int dbg;               // profiling experiments: 4 = skip MFMAs, 8 = skip window reads, 16 = skip DMA of slices > 0
+  FastDiv dPW, dSlab, dBands, dTX, dTslab /* (R/2)*TX */;
+};
+
+constexpr int WINO_MAXG = 4;
+
+__device__ __forceinline__ float4 f4sub(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+__device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+
+// NT = 1: up to 12 waves per block (VGPR cap 170), NT = 2: up to 8 waves (cap 256)
+template <int NT>
+__global__ void __launch_bounds__(NT == 1 ? 768 : 512)
+conv_wino_kernel(const WinoParams p) {
+  extern __shared__ float4 smem[];   // [raw patch: 4 planes][U buffer 0][U buffer 1]
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nwaves = blockDim.x >> 6;
+  const int wm = wave % p.WM;
+  const int wn = wave / p.WM;
+  const int idx = lane & 15;
+  const int g = lane >> 4;
+  const int s0 = blockIdx.x * p.NI;
+  const int ntb0 = blockIdx.y * p.NTB;
+  const int nt0 = ntb0 + wn * NT;
+
+  // ---- this lane's tile -----------------------------------------------------------------------
+  int base;        // patch position of the window's top-left corner
+  int oy, ox, ob;  // output coordinates of the tile's (0,0) pixel; ob < 0 = no tile
+  {
+    const uint32_t tidx = (uint32_t)(wm * 16 + idx);
+    const uint32_t sl = fdiv(tidx, p.dTslab);
+    const uint32_t rem = tidx - sl * p.dTslab.d;
+    const uint32_t tyl = fdiv(rem, p.dTX);
+    const uint32_t tx = rem - tyl * p.dTX.d;
+    const uint32_t s = s0 + sl;
+    const uint32_t b = fdiv(s, p.dBands);
+    const uint32_t band = s - b * p.dBands.d;
+    const bool valid = (sl < (uint32_t)p.NI) && (s < (uint32_t)p.S);
+    base = valid ? (int)((sl * p.PR + 2 * tyl) * p.PW + 2 * tx) : 0;
+    ob = valid ? (int)b : -1;
+    oy = (int)(band * p.R + 2 * tyl);
+    ox = (int)(2 * tx);
+  }
+
+  // ---- raw-patch DMA bookkeeping --------------------------------------------------------------
+  int goff[WINO_MAXG];
+#pragma unroll
+  for (int k = 0; k < WINO_MAXG; ++k) {
+    goff[k] = -1;
+    const int grp = wave + k * nwaves;
+    const uint32_t pos = (uint32_t)(grp * 64 + lane);
+    if (grp < p.ngroups && pos < (uint32_t)p.npos) {
+      const uint32_t sl = fdiv(pos, p.dSlab);
+      const uint32_t rem = pos - sl * p.dSlab.d;
+      const uint32_t prow = fdiv(rem, p.dPW);
+      const uint32_t pcol = rem - prow * p.dPW.d;
+      const uint32_t s = s0 + sl;
+      const uint32_t b = fdiv(s, p.dBands);
+      const uint32_t band = s - b * p.dBands.d;
+      const int iy = (int)(band * p.R) - 1 + (int)prow;
+      const int ix = (int)pcol - 1;
+      if (s < (uint32_t)p.S && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
+        goff[k] = (int)(((size_t)(b * p.H + iy) * p.W + ix) * p.in_cs + p.in_co);
+    }
+  }
+  const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) float4*)smem;
+  const int nuitems = 16 * p.NTB;
+
+  auto issue_raw = [&](int c) {
+#pragma unroll
+    for (int k = 0; k < WINO_MAXG; ++k) {
+      const int grp = wave + k * nwaves;
+      if (grp < p.ngroups) {
+        const float* src0 = p.in + goff[k] + c * 16;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const void* src = (goff[k] >= 0) ? (const void*)(src0 + q * 4) : (const void*)&g_zero_page_w;
+          lds_dma16(src, (unsigned)__builtin_amdgcn_readfirstlane((int)(lds_base + (unsigned)(q * p.planeF4 + grp * 64) * 16u)));
+        }
+      }
+    }
+  };
+  auto issue_u = [&](int c, int buf) {
+    const unsigned ub = lds_base + (unsigned)(4 * p.planeF4 + buf * p.ubufF4) * 16u;
+    for (int i = wave; i < nuitems; i += nwaves) {
+      const int xi = i / p.NTB, j = i - xi * p.NTB;
+      const int nt = min(ntb0 + j, p.nT16 - 1);
+      const float4* src = p.ufrag + (((size_t)xi * p.nC16 + c) * p.nT16 + nt) * 64 + lane;
+      lds_dma16(src, (unsigned)__builtin_amdgcn_readfirstlane((int)(ub + (unsigned)(i * 64) * 16u)));
+    }
+  };
+
+  f32x4 acc[16][NT];
+#pragma unroll
+  for (int xi = 0; xi < 16; ++xi)
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[xi][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  issue_raw(0);
+  issue_u(0, 0);
+
+  for (int c = 0; c < p.nC16; ++c) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                   // raw(c) and U(c) have landed
+    // ---- window -> registers ---------------------------------------------------------------
+    const float4* pl = smem + g * p.planeF4 + base;
+    float4 v[16];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v[r * 4 + q] = (p.dbg & 8) ? make_float4(1.f, 2.f, 3.f, 4.f) : pl[r * p.PW + q];
+    __syncthreads();                                   // every wave holds its window: patch is free
+    if (c + 1 < p.nC16 && !(p.dbg & 16)) {
+      issue_raw(c + 1);
+      issue_u(c + 1, (c + 1) & 1);
+    }
+    // ---- V = B^T d B  (rows, then columns; in place) ------------------------------------------
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 d0 = v[q], d1 = v[4 + q], d2 = v[8 + q], d3 = v[12 + q];
+      v[q] = f4sub(d0, d2); v[4 + q] = f4add(d1, d2); v[8 + q] = f4sub(d2, d1); v[12 + q] = f4sub(d1, d3);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float4 t0 = v[r * 4], t1 = v[r * 4 + 1], t2 = v[r * 4 + 2], t3 = v[r * 4 + 3];
+      v[r * 4] = f4sub(t0, t2); v[r * 4 + 1] = f4add(t1, t2); v[r * 4 + 2] = f4sub(t2, t1); v[r * 4 + 3] = f4sub(t1, t3);
+    }
+    // ---- 16 position GEMMs -----------------------------------------------------------------------
+    const float4* ul = smem + 4 * p.planeF4 + (c & 1) * p.ubufF4 + (wn * NT) * 64 + lane;
+    if (p.dbg & 4) { asm volatile("" :: "v"(v[0].x), "v"(v[5].y), "v"(v[10].z), "v"(v[15].w)); continue; }
+    // the transform must be complete before the MFMA stream starts, and the U fragments of the next
+    // position pair are fetched while the current pair's MFMAs issue (hipcc would otherwise sink
+    // both next to their consumers: VALU->MFMA wait states + exposed ds_read latency per MFMA)
+    __builtin_amdgcn_sched_barrier(0);
+    float4 ub[2][2][NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) { ub[0][0][n] = ul[n * 64]; ub[0][1][n] = ul[(p.NTB + n) * 64]; }
+#pragma unroll
+    for (int xp = 0; xp < 16; xp += 2) {
+      const int cur = (xp >> 1) & 1, nxt = cur ^ 1;
+      if (xp + 2 < 16) {
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          ub[nxt][0][n] = ul[((xp + 2) * p.NTB + n) * 64];
+          ub[nxt][1][n] = ul[((xp + 3) * p.NTB + n) * 64];
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      const float a0[4] = {v[xp].x, v[xp].y, v[xp].z, v[xp].w};
+      const float a1[4] = {v[xp + 1].x, v[xp + 1].y, v[xp + 1].z, v[xp + 1].w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          const float4 u0 = ub[cur][0][n], u1 = ub[cur][1][n];
+          const float w0 = (j == 0) ? u0.x : (j == 1) ? u0.y : (j == 2) ? u0.z : u0.w;
+          const float w1 = (j == 0) ? u1.x : (j == 1) ? u1.y : (j == 2) ? u1.z : u1.w;
+          acc[xp][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0, a0[j], acc[xp][n], 0, 0, 0);
+          acc[xp + 1][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1, a1[j], acc[xp + 1][n], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  // ---- Y = A^T M A, epilogue ----------------------------------------------------------------------
+  if (ob < 0 || nt0 >= p.nT16) return;
+#pragma unroll
+  for (int n = 0; n < NT; ++n) {
+    if (nt0 + n >= p.nT16) break;
+    const int co = (nt0 + n) * 16 + g * 4;
+    const float4 sh = *reinterpret_cast<const float4*>(p.bias + co);
+    f32x4 s[2][4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      s[0][q] = acc[q][n] + acc[4 + q][n] + acc[8 + q][n];
+      s[1][q] = acc[4 + q][n] - acc[8 + q][n] - acc[12 + q][n];
+    }
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int y = oy + r;
+      if (y >= p.H) continue;
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int x = ox + q;
+        if (x >= p.W) continue;
+        f32x4 v4 = (q == 0) ? (s[r][0] + s[r][1] + s[r][2]) : (s[r][1] - s[r][2] - s[r][3]);
+        const size_t opix = ((size_t)ob * p.H + y) * p.W + x;
+        v4[0] += sh.x; v4[1] += sh.y; v4[2] += sh.z; v4[3] += sh.w;
+        float4 rr = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p.res) rr = *reinterpret_cast<const float4*>(p.res + opix * p.res_cs + p.res_co + co);
+        if (!p.res_after_act) { v4[0] += rr.x; v4[1] += rr.y; v4[2] += rr.z; v4[3] += rr.w; }
+        if (p.act == 1) {
+          v4[0] = fmaxf(v4[0], 0.f); v4[1] = fmaxf(v4[1], 0.f); v4[2] = fmaxf(v4[2], 0.f); v4[3] = fmaxf(v4[3], 0.f);
+        } else if (p.act == 2) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v4[e] = 1.f / (1.f + __expf(-v4[e]));
+        }
+        if (p.res_after_act) { v4[0] += rr.x; v4[1] += rr.y; v4[2] += rr.z; v4[3] += rr.w; }
+        *reinterpret_cast<float4*>(p.out + opix * p.out_cs + p.out_co + co) = make_float4(v4[0], v4[1], v4[2], v4[3]);
+      }
+    }
+  }
+}
+
+struct WGeo {
+  int TX, nbands, S, PR, PW, npos, planeF4, nblocks_m;
+};
+bool wgeo(const ConvDesc& d, const ConvCfg& c, WGeo* g) {
+  if (c.R < 2 || (c.R & 1) || c.NI < 1 || c.WM < 1 || c.WN < 1 || c.NT < 1 || c.NT > 2) return false;
+  g->TX = (d.W + 1) / 2;
+  const int Hc = (d.H + 1) / 2 * 2;
+  if (c.R > Hc) return false;
+  g->nbands = (d.H + c.R - 1) / c.R;
+  g->S = d.B * g->nbands;
+  g->PR = c.R + 2;
+  g->PW = 2 * g->TX + 2;
+  g->npos = c.NI * g->PR * g->PW;
+  g->planeF4 = (g->npos + 63) / 64 * 64;   // dead lanes use base 0: every window stays inside its slab (PR >= 4)
+  g->nblocks_m = (g->S + c.NI - 1) / c.NI;
+  return true;
+}
+
+}  // namespace
+
+size_t conv_wino_lds_bytes(const ConvDesc& d, const ConvCfg& cfg) {
+  WGeo g;
+  if (!wgeo(d, cfg, &g)) return 0;
+  return ((size_t)4 * g.planeF4 + (size_t)2 * 16 * cfg.WN * cfg.NT * 64) * sizeof(float4);
+}
+
+// U = G g G^T per (co, ci), float64 on the host, written as a [Cout][Cin][16] "16-tap" filter that
+// conv_pack_weights(ks = 4) lays out in fragment order.
+void conv_wino_transform_weights(const float* w_oihw, int Cout, int Cin, std::vector<float>* out) {
+  static const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
+  out->assign((size_t)Cout * Cin * 16, 0.f);
+  for (size_t oc = 0; oc < (size_t)Cout * Cin; ++oc) {
+    const float* gk = w_oihw + oc * 9;
+    double t[4][3];
+    for (int i = 0; i < 4; ++i)
+      for (int j = 0; j < 3; ++j) t[i][j] = G[i][0] * gk[0 * 3 + j] + G[i][1] * gk[1 * 3 + j] + G[i][2] * gk[2 * 3 + j];
+    for (int i = 0; i < 4; ++i)
+      for (int j = 0; j < 4; ++j)
+        (*out)[oc * 16 + i * 4 + j] = (float)(t[i][0] * G[j][0] + t[i][1] * G[j][1] + t[i][2] * G[j][2]);
+  }
+}
+
+int conv_wino_launch(const ConvDesc& d, const ConvCfg& cfg, hipStream_t stream) {
+  if (d.ks != 3 || d.stride != 1 || !d.wfrag_wino) {
+    poco_set_error("conv(winograd): needs a 3x3 stride-1 conv with transformed weights");
+    return POCO_ERR_ARG;
+  }
+  WGeo g;
+  if (!wgeo(d, cfg, &g)) { poco_set_error("conv(winograd): invalid tile configuration"); return POCO_ERR_ARG; }
+  const int nwaves = cfg.WM * cfg.WN;
+  if (nwaves > (cfg.NT == 1 ? 12 : 8)) { poco_set_error("conv(winograd): at most 12 (NT=1) / 8 (NT=2) waves per block"); return POCO_ERR_ARG; }
+  if (cfg.NI * (cfg.R / 2) * g.TX > cfg.WM * 16) { poco_set_error("conv(winograd): tiles per block exceed WM*16"); return POCO_ERR_ARG; }
+  if ((g.planeF4 / 64 + nwaves - 1) / nwaves > WINO_MAXG) { poco_set_error("conv(winograd): patch too large"); return POCO_ERR_ARG; }
+  const size_t lds = conv_wino_lds_bytes(d, cfg);
+  if (lds > 160 * 1024) { poco_set_error("conv(winograd): LDS budget exceeded"); return POCO_ERR_ARG; }
+  WinoParams p;
+  p.in = d.in; p.res = d.res; p.out = d.out; p.ufrag = reinterpret_cast<const float4*>(d.wfrag_wino); p.bias = d.bias;
+  p.in_cs = d.in_cs; p.in_co = d.in_co; p.res_cs = d.res_cs; p.res_co = d.res_co; p.out_cs = d.out_cs; p.out_co = d.out_co;
+  p.H = d.H; p.W = d.W; p.nC16 = d.Cin / 16; p.nT16 = d.Cout / 16;
+  p.R = cfg.R; p.NI = cfg.NI; p.S = g.S; p.TX = g.TX; p.PR = g.PR; p.PW = g.PW; p.npos = g.npos; p.planeF4 = g.planeF4;
+  p.ngroups = g.planeF4 / 64;
+  p.WM = cfg.WM; p.WN = cfg.WN; p.NTB = cfg.WN * cfg.NT; p.ubufF4 = 16 * p.NTB * 64;
+  p.act = d.act; p.res_after_act = d.res_after_act;
+  {
+    static const int dbg = [] { const char* e = getenv("POCO_CONV_DBG"); return e ? atoi(e) : 0; }();
+    p.dbg = dbg;
+  }
+  p.dPW = make_fastdiv(g.PW); p.dSlab = make_fastdiv(g.PR * g.PW); p.dBands = make_fastdiv(g.nbands);
+  p.dTX = make_fastdiv(g.TX); p.dTslab = make_fastdiv((cfg.R / 2) * g.TX);
+  const int nb_n = (p.nT16 + p.NTB - 1) / p.NTB;
+  dim3 grid(g.nblocks_m, nb_n);
+  auto fn = cfg.NT == 2 ? conv_wino_kernel<2> : conv_wino_kernel<1>;
+  if (lds > 64 * 1024) {
+    static thread_local bool configured[3] = {false, false, false};
+    if (!configured[cfg.NT]) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (e != hipSuccess) { poco_set_error(std::string("hipFuncSetAttribute: ") + hipGetErrorString(e)); return POCO_ERR_HIP; }
+      configured[cfg.NT] = true;
+    }
+  }
+  hipLaunchKernelGGL(fn, grid, dim3(nwaves * 64), lds, stream, p);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { poco_set_error(std::string("conv(winograd) launch: ") + hipGetErrorString(e)); return POCO_ERR_HIP; }
+  return POCO_OK;
+}

@@ -71,6 +71,7 @@ struct Op {
   int Cin = 0, Cout = 0, ks = 1, stride = 1, actfn = 0, res_after = 0;
   float* wdev = nullptr;
   float* bdev = nullptr;
+  float* wdev_wino = nullptr;   // 3x3 stride-1 convs: Winograd-transformed weights (ALG 3)
   // fuse
   Ref fsrc[4];
   int fshift[4] = {0, 0, 0, 0};
@@ -255,6 +256,12 @@ struct Builder {
       std::copy(shift.begin(), shift.end(), sh.begin());
       op.wdev = upload(packed);
       op.bdev = upload(sh);
+      if (ks == 3 && stride == 1 && !is_linear) {
+        std::vector<float> wt, pu(conv_packed_weight_floats(Cin, Cout16, 4));
+        conv_wino_transform_weights(wp, Cout, Cin, &wt);
+        conv_pack_weights(wt.data(), scale.data(), Cout, Cin, 4, Cout16, pu.data());
+        op.wdev_wino = upload(pu);
+      }
     }
     push(std::move(op));
     return out_act;
@@ -843,7 +850,7 @@ int run_op(Engine& e, Op& op, int B, const IO& io, hipStream_t s) {
       d.in = aptr(e, op.in); d.in_cs = ai.C; d.in_co = 0;
       if (op.res.act >= 0) { d.res = aptr(e, op.res); d.res_cs = e.acts[op.res.act].C; }
       d.out = aptr(e, op.out); d.out_cs = ao.C; d.out_co = 0;
-      d.wfrag = op.wdev; d.bias = op.bdev;
+      d.wfrag = op.wdev; d.bias = op.bdev; d.wfrag_wino = op.wdev_wino;
       d.B = B; d.H = ai.H; d.W = ai.W; d.Cin = op.Cin; d.Cout = op.Cout; d.ks = op.ks; d.stride = op.stride;
       d.act = op.actfn; d.res_after_act = op.res_after;
       auto it = op.cfg.find(B);

@@ -44,10 +44,17 @@ static int conv_common(const float* d_in, int B, int H, int W, int Cin, const fl
   std::vector<float> shift(Cout16, 0.f);
   if (h_shift)
     for (int i = 0; i < Cout; ++i) shift[i] = h_shift[i];
-  DevBuf dw, db;
+  DevBuf dw, db, dwu;
   POCO_HIP_CHECK(dw.upload(packed));
   POCO_HIP_CHECK(db.upload(shift));
   ConvDesc d{};
+  if (ks == 3 && stride == 1) {
+    std::vector<float> wt, pu(conv_packed_weight_floats(Cin, Cout16, 4));
+    conv_wino_transform_weights(h_w, Cout, Cin, &wt);
+    conv_pack_weights(wt.data(), h_scale, Cout, Cin, 4, Cout16, pu.data());
+    POCO_HIP_CHECK(dwu.upload(pu));
+    d.wfrag_wino = dwu.p;
+  }
   d.in = d_in; d.in_cs = Cin; d.in_co = 0;
   d.res = d_res; d.res_cs = Cout; d.res_co = 0;
   d.out = d_out; d.out_cs = Cout; d.out_co = 0;
@@ -119,13 +126,19 @@ extern "C" int poco_tune_conv(int B, int H, int W, int Cin, int Cout, int ks, in
   const float ws = 1.0f / sqrtf((float)(Cin * ks * ks));
   for (auto& v : hw) v = rnd() * ws;
   for (auto& v : hb) v = rnd() * 0.1f;
-  DevBuf din, dw, db, dout;
+  DevBuf din, dw, db, dout, dwu;
+  if (ks == 3 && stride == 1) {
+    std::vector<float> hu((size_t)16 * Cin * Cout);
+    for (auto& v : hu) v = rnd() * ws;
+    POCO_HIP_CHECK(dwu.upload(hu));
+  }
   POCO_HIP_CHECK(din.upload(hin));
   POCO_HIP_CHECK(dw.upload(hw));
   POCO_HIP_CHECK(db.upload(hb));
   POCO_HIP_CHECK(hipMalloc(&dout.p, nout * sizeof(float)));
   ConvDesc d{};
   d.in = din.p; d.in_cs = Cin; d.out = dout.p; d.out_cs = Cout; d.wfrag = dw.p; d.bias = db.p;
+  d.wfrag_wino = dwu.p;
   d.B = B; d.H = H; d.W = W; d.Cin = Cin; d.Cout = Cout; d.ks = ks; d.stride = stride; d.act = 1;
   hipEvent_t e0, e1;
   POCO_HIP_CHECK(hipEventCreate(&e0));

@@ -64,6 +64,23 @@ def candidates(B, H, W, Cin, Cout, ks, stride, lds_cap=150 * 1024) -> List[Tuple
                 if lds1 <= 160 * 1024 and (plane // 64 + WM * WN - 1) // (WM * WN) <= 6:
                     out.add((MT, NT, WM, WN, R, ni, 1))
                     out.add((MT, NT, WM, WN, R, ni, 2))
+    if ks == 3 and stride == 1:          # Winograd F(2x2,3x3): one 16-tile sub-tile per wave
+        TX = (W + 1) // 2
+        for NT, WM, WN in itertools.product((1, 2), range(1, 13), (1, 2, 3, 4, 6, 8)):
+            if WM * WN > (12 if NT == 1 else 8) or nT % NT or WN > nT // NT:
+                continue
+            for R in range(2, (H + 1) // 2 * 2 + 1, 2):
+                tiles = (R // 2) * TX
+                if tiles > WM * 16:
+                    break
+                for ni in {1, max(1, (WM * 16) // tiles)}:
+                    if ni * tiles / (WM * 16) < 0.75 or (ni > 1 and R < H):
+                        continue
+                    npos = ni * (R + 2) * (2 * TX + 2)
+                    plane = (npos + 63) // 64 * 64
+                    lds = (4 * plane + 2 * 16 * WN * NT * 64) * 16
+                    if lds <= 160 * 1024 and (plane // 64 + WM * WN - 1) // (WM * WN) <= 4:
+                        out.add((1, NT, WM, WN, R, ni, 3))
     return sorted(out)
 
 
