@@ -43,6 +43,21 @@ def build_model(variant, max_batch, device):
     return m.finalize()
 
 
+def pmc_traffic(variant, B):
+    """HBM bytes per forward from the committed rocprofv3 --pmc passes of this same command
+    (profiles/r01_pmc_*_summary.json: FETCH_SIZE x2 [gfx950 correction for 16 B/lane streams] + WRITE_SIZE,
+    KB -> bytes, / 5 forwards).  bench.py cannot run the counters itself; null if no profile matches."""
+    f = ROOT / "profiles" / "r01_pmc_w48cliff_b64_summary.json"
+    if variant != "hrnet_w48_cls-cliff" or B != 64 or not f.exists():
+        return None
+    d = json.loads(f.read_text())
+    conv = d.get("conv(all MFMA variants)", {})
+    if "FETCH_SIZE" not in conv:
+        return None
+    tot = sum((2.0 * v.get("FETCH_SIZE", 0.0) + v.get("WRITE_SIZE", 0.0)) for v in d.values())
+    return round(tot * 1024.0 / 5.0)
+
+
 def cpu_baseline(variant, seconds_budget=25.0):
     """The oracle (CPU restatement of the reference path, oracle/poco_ref.py) timed on this host's cores
     on a bounded sample of the same workload.  Reported beside the GPU number; never the product path."""
@@ -89,6 +104,7 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="crops per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--lanes", type=int, default=4, help="HIP streams for independent branches (1 = single stream)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -107,6 +123,7 @@ def main():
     from poco_amd import synth
     B = args.batch
     model = build_model(args.variant, B, device)
+    model.set_num_lanes(args.lanes)
     batch = {k: torch.from_numpy(v).to(device) for k, v in synth.synth_batch(B, 1234 + rank).items()}
     out = model._alloc_outputs(B, want_segm=False)
     from poco_amd import dist as pdist
@@ -156,7 +173,7 @@ def main():
                        "crops_per_gpu": B, "global_batch": world * B,
                        "parallelism": f"dp{world} (crop sharding" + (", RCCL all-gather of 254-float SMPL records)" if world > 1 and not args.no_gather else ")")},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                         "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": pmc_traffic(args.variant, B),
                          "note": f"algorithmic {flops_per_crop/1e9:.3f} GFLOP/crop x {B} crops per forward / mean HIP-event "
                                  f"forward time {ev_ms:.3f} ms on the launch stream; conv_mfma_kernel launches are >97% of it "
                                  "(profiles/)"},
