@@ -37,7 +37,8 @@ struct ConvCfg {
   int R;       // output rows per slab
   int NI;      // slabs (row bands / whole images) per block
   int ALG;     // 0: register-staged single LDS buffer; 1: LDS-DMA double-buffered (patch + weights);
-               // 2: ALG 1 persistent over tiles; 3: Winograd F(2x2,3x3) (MT ignored, NT in {1,2}, R even)
+               // 2: ALG 1 persistent over tiles; 3: Winograd F(2x2,3x3) (MT ignored, NT in {1,2}, R even);
+               // 4: Winograd, half-position waves + pipelined transform (WN = 2 halves, WM <= 4, NT <= 3)
 };
 constexpr int CONV_CFG_INTS = 7;   // ints per configuration in the C ABI / tuning table
 inline ConvCfg conv_cfg_from(const int* c) { return ConvCfg{c[0], c[1], c[2], c[3], c[4], c[5], c[6]}; }

@@ -67,6 +67,71 @@ struct ConvKParams {
   FastDiv dPW, dSlab /*PR*PW*/, dBands, dWo, dRWo;
 };
 
+// Epilogue shared by the direct kernels: shift (+ residual) (activation) -> NHWC channel slice.
+// All loads of an n-tile group (bias, residuals) are issued BEFORE the stores of the previous group and
+// nothing is loaded between stores: on gfx9 loads and stores share the one VM counter, so a load -> wait
+// -> store chain per output (what a naive loop compiles to) serialises every store behind a full memory
+// round trip.  out_pix(m) returns the output pixel index of sub-tile m for this lane or -1.
+template <int MT, int NT, bool HAS_RES>
+__device__ __forceinline__ void conv_store_tile_impl(const ConvKParams& p, f32x4 (&acc)[MT][NT], int nt0, int g,
+                                                     const int (&oo)[MT]) {
+  // residual loads are unconditional (dead lanes read pixel 0) so that hipcc can count them: a load under
+  // a branch makes it fall back to s_waitcnt vmcnt(0) before every store
+  auto load_res = [&](int n, float4* r) {
+    const int co = (min(nt0 + n, p.nT16 - 1)) * 16 + g * 4;
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+      r[m] = *reinterpret_cast<const float4*>(p.res + (size_t)max(oo[m], 0) * p.res_cs + p.res_co + co);
+  };
+  float4 sh[NT];
+#pragma unroll
+  for (int n = 0; n < NT; ++n)
+    sh[n] = *reinterpret_cast<const float4*>(p.bias + (min(nt0 + n, p.nT16 - 1)) * 16 + g * 4);
+  constexpr bool PIPE = MT <= 7;          // register budget: double-buffer the residual group only for small MT
+  float4 rcur[MT], rnext[PIPE ? MT : 1];
+  if constexpr (HAS_RES && PIPE) load_res(0, rcur);
+#pragma unroll
+  for (int n = 0; n < NT; ++n) {
+    if constexpr (HAS_RES) {
+      if constexpr (PIPE) { if (n + 1 < NT) load_res(n + 1, rnext); }
+      else load_res(n, rcur);
+    }
+    const int co = (nt0 + n) * 16 + g * 4;
+    const bool nok = nt0 + n < p.nT16;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      f32x4 v = acc[m][n];
+      v[0] += sh[n].x; v[1] += sh[n].y; v[2] += sh[n].z; v[3] += sh[n].w;
+      float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+      if constexpr (HAS_RES) r = rcur[m];
+      if (!p.res_after_act) { v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w; }
+      if (p.act == 1) {
+        v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+      } else if (p.act == 2) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = 1.f / (1.f + __expf(-v[e]));
+      }
+      if (p.res_after_act) { v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w; }
+      if (nok && oo[m] >= 0)
+        *reinterpret_cast<float4*>(p.out + (size_t)oo[m] * p.out_cs + p.out_co + co) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+    if constexpr (HAS_RES && PIPE) {
+#pragma unroll
+      for (int m = 0; m < MT; ++m) rcur[m] = rnext[m];
+    }
+  }
+}
+
+template <int MT, int NT, typename OutPix>
+__device__ __forceinline__ void conv_store_tile(const ConvKParams& p, f32x4 (&acc)[MT][NT], int nt0, int g,
+                                                OutPix out_pix) {
+  int oo[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) oo[m] = out_pix(m);
+  if (p.res != nullptr) conv_store_tile_impl<MT, NT, true>(p, acc, nt0, g, oo);
+  else conv_store_tile_impl<MT, NT, false>(p, acc, nt0, g, oo);
+}
+
 template <int KS, int STRIDE, int MT, int NT>
 __global__ void __launch_bounds__(512)
 conv_mfma_kernel(const ConvKParams p) {
@@ -184,32 +249,7 @@ conv_mfma_kernel(const ConvKParams p) {
 
   // ---- epilogue: shift (+ residual) (ReLU) -> NHWC channel slice -----------------------------
   if (!nvalid) return;
-#pragma unroll
-  for (int n = 0; n < NT; ++n) {
-    if (nt0 + n >= p.nT16) break;   // partial n-tile group (wave-uniform)
-    const int co = (nt0 + n) * 16 + g * 4;
-    const float4 sh = *reinterpret_cast<const float4*>(p.bias + co);
-#pragma unroll
-    for (int m = 0; m < MT; ++m) {
-      if (ooff[m] >= 0) {
-        f32x4 v = acc[m][n];
-        v[0] += sh.x; v[1] += sh.y; v[2] += sh.z; v[3] += sh.w;
-        float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (p.res) r = *reinterpret_cast<const float4*>(p.res + (size_t)ooff[m] * p.res_cs + p.res_co + co);
-        if (!p.res_after_act) { v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w; }
-        if (p.act == 1) {
-          v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f);
-          v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
-        } else if (p.act == 2) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = 1.f / (1.f + __expf(-v[e]));
-        }
-        if (p.res_after_act) { v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w; }
-        *reinterpret_cast<float4*>(p.out + (size_t)ooff[m] * p.out_cs + p.out_co + co) =
-            make_float4(v[0], v[1], v[2], v[3]);
-      }
-    }
-  }
+  conv_store_tile<MT, NT>(p, acc, nt0, g, [&](int m) { return ooff[m]; });
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -403,32 +443,7 @@ conv_dma_kernel(const ConvKParams p) {
   }
 
   if (nt0 >= p.nT16 || (p.dbg & 1)) return;
-#pragma unroll
-  for (int n = 0; n < NT; ++n) {
-    if (nt0 + n >= p.nT16) break;
-    const int co = (nt0 + n) * 16 + g * 4;
-    const float4 sh = *reinterpret_cast<const float4*>(p.bias + co);
-#pragma unroll
-    for (int m = 0; m < MT; ++m) {
-      if (ooff[m] >= 0) {
-        f32x4 v = acc[m][n];
-        v[0] += sh.x; v[1] += sh.y; v[2] += sh.z; v[3] += sh.w;
-        float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (p.res) r = *reinterpret_cast<const float4*>(p.res + (size_t)ooff[m] * p.res_cs + p.res_co + co);
-        if (!p.res_after_act) { v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w; }
-        if (p.act == 1) {
-          v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f);
-          v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
-        } else if (p.act == 2) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = 1.f / (1.f + __expf(-v[e]));
-        }
-        if (p.res_after_act) { v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w; }
-        *reinterpret_cast<float4*>(p.out + (size_t)ooff[m] * p.out_cs + p.out_co + co) =
-            make_float4(v[0], v[1], v[2], v[3]);
-      }
-    }
-  }
+  conv_store_tile<MT, NT>(p, acc, nt0, g, [&](int m) { return ooff[m]; });
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -635,33 +650,7 @@ conv_dma_persist_kernel(const ConvKParams p) {
       __syncthreads();
     }
     // ---- epilogue of tile t: stores drain while the next tile's MFMAs run ------------------------
-    if (nt0 < p.nT16 && !(p.dbg & 1)) {
-#pragma unroll
-      for (int m = 0; m < MT; ++m) {
-        const int oo = out_pixel(t, m);
-        if (oo < 0) continue;
-#pragma unroll
-        for (int n = 0; n < NT; ++n) {
-          if (nt0 + n >= p.nT16) break;
-          const int co = (nt0 + n) * 16 + g * 4;
-          const float4 sh = *reinterpret_cast<const float4*>(p.bias + co);
-          f32x4 v = acc[m][n];
-          v[0] += sh.x; v[1] += sh.y; v[2] += sh.z; v[3] += sh.w;
-          float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (p.res) r = *reinterpret_cast<const float4*>(p.res + (size_t)oo * p.res_cs + p.res_co + co);
-          if (!p.res_after_act) { v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w; }
-          if (p.act == 1) {
-            v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f);
-            v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
-          } else if (p.act == 2) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = 1.f / (1.f + __expf(-v[e]));
-          }
-          if (p.res_after_act) { v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w; }
-          *reinterpret_cast<float4*>(p.out + (size_t)oo * p.out_cs + p.out_co + co) = make_float4(v[0], v[1], v[2], v[3]);
-        }
-      }
-    }
+    if (nt0 < p.nT16 && !(p.dbg & 1)) conv_store_tile<MT, NT>(p, acc, nt0, g, [&](int m) { return out_pixel(t, m); });
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -770,7 +759,7 @@ static size_t lds_bytes_for(const ConvDesc& d, const ConvCfg& cfg, const Geometr
 }
 
 size_t conv_lds_bytes(const ConvDesc& d, const ConvCfg& cfg) {
-  if (cfg.ALG == 3) return conv_wino_lds_bytes(d, cfg);
+  if (cfg.ALG == 3 || cfg.ALG == 4) return conv_wino_lds_bytes(d, cfg);
   Geometry g;
   if (!geometry(d, cfg, &g)) return 0;
   return lds_bytes_for(d, cfg, g);
@@ -841,7 +830,7 @@ ConvCfg conv_default_cfg(const ConvDesc& d) {
 }
 
 int conv_launch(const ConvDesc& d, const ConvCfg& cfg, hipStream_t stream) {
-  if (cfg.ALG == 3) {
+  if (cfg.ALG == 3 || cfg.ALG == 4) {
     if (d.Cin % 16 || d.Cout % 16 || ((d.in_cs | d.in_co | d.out_cs | d.out_co | d.res_cs | d.res_co) & 3)) {
       poco_set_error("conv: channel counts/strides must be multiples of 16/4");
       return POCO_ERR_ARG;

@@ -25,6 +25,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 #include <vector>
 
 namespace {
@@ -65,15 +66,70 @@ struct WinoParams {
   int PR, PW, npos, planeF4, ngroups;
   int WM, WN, NTB;
   int ubufF4;            // float4 per U buffer = 16 * NTB * 64
+  int nblocks_m, nb_n;   // ALG 4: tile grid walked by the persistent blocks
   int act, res_after_act;
   int dbg;               // profiling experiments: 4 = skip MFMAs, 8 = skip window reads, 16 = skip DMA of slices > 0
   FastDiv dPW, dSlab, dBands, dTX, dTslab /* (R/2)*TX */;
 };
 
-constexpr int WINO_MAXG = 4;
+constexpr int WINO_MAXG = 6;
 
 __device__ __forceinline__ float4 f4sub(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
 __device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+
+// Shared output stage of both Winograd kernels: v[n][k] (k = r'*2 + q', a 2x2 pixel block per lane, 4
+// channels each) + shift (+ residual) (activation) -> NHWC.  Residual loads are batched and unconditional
+// (dead pixels read pixel 0) and nothing is loaded between stores - see conv_store_tile in conv_mfma.hip.
+template <int NT, bool HAS_RES>
+__device__ __forceinline__ void wino_store_impl(const WinoParams& p, f32x4 (&v)[NT][4], int nt0, int g, int ob, int oy,
+                                                int ox) {
+  size_t opix[4];
+  bool ok[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int yy = oy + (k >> 1), xx = ox + (k & 1);
+    ok[k] = (ob >= 0) && yy < p.H && xx < p.W;
+    opix[k] = ok[k] ? ((size_t)ob * p.H + yy) * p.W + xx : 0;
+  }
+  float4 sh[NT];
+#pragma unroll
+  for (int n = 0; n < NT; ++n) sh[n] = *reinterpret_cast<const float4*>(p.bias + min(nt0 + n, p.nT16 - 1) * 16 + g * 4);
+  float4 rr[NT][4];
+  if constexpr (HAS_RES) {
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        rr[n][k] = *reinterpret_cast<const float4*>(p.res + opix[k] * p.res_cs + p.res_co + min(nt0 + n, p.nT16 - 1) * 16 + g * 4);
+  }
+#pragma unroll
+  for (int n = 0; n < NT; ++n) {
+    const bool nok = nt0 + n < p.nT16;
+    const int co = (nt0 + n) * 16 + g * 4;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      f32x4 v4 = v[n][k];
+      v4[0] += sh[n].x; v4[1] += sh[n].y; v4[2] += sh[n].z; v4[3] += sh[n].w;
+      float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+      if constexpr (HAS_RES) r = rr[n][k];
+      if (!p.res_after_act) { v4[0] += r.x; v4[1] += r.y; v4[2] += r.z; v4[3] += r.w; }
+      if (p.act == 1) {
+        v4[0] = fmaxf(v4[0], 0.f); v4[1] = fmaxf(v4[1], 0.f); v4[2] = fmaxf(v4[2], 0.f); v4[3] = fmaxf(v4[3], 0.f);
+      } else if (p.act == 2) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v4[e] = 1.f / (1.f + __expf(-v4[e]));
+      }
+      if (p.res_after_act) { v4[0] += r.x; v4[1] += r.y; v4[2] += r.z; v4[3] += r.w; }
+      if (nok && ok[k])
+        *reinterpret_cast<float4*>(p.out + opix[k] * p.out_cs + p.out_co + co) = make_float4(v4[0], v4[1], v4[2], v4[3]);
+    }
+  }
+}
+template <int NT>
+__device__ __forceinline__ void wino_store(const WinoParams& p, f32x4 (&v)[NT][4], int nt0, int g, int ob, int oy, int ox) {
+  if (p.res != nullptr) wino_store_impl<NT, true>(p, v, nt0, g, ob, oy, ox);
+  else wino_store_impl<NT, false>(p, v, nt0, g, ob, oy, ox);
+}
 
 // NT = 1: up to 12 waves per block (VGPR cap 170), NT = 2: up to 8 waves (cap 256)
 template <int NT>
@@ -233,11 +289,9 @@ conv_wino_kernel(const WinoParams p) {
 
   // ---- Y = A^T M A, epilogue ----------------------------------------------------------------------
   if (ob < 0 || nt0 >= p.nT16) return;
+  f32x4 yv[NT][4];
 #pragma unroll
   for (int n = 0; n < NT; ++n) {
-    if (nt0 + n >= p.nT16) break;
-    const int co = (nt0 + n) * 16 + g * 4;
-    const float4 sh = *reinterpret_cast<const float4*>(p.bias + co);
     f32x4 s[2][4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -246,28 +300,249 @@ conv_wino_kernel(const WinoParams p) {
     }
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
-      const int y = oy + r;
-      if (y >= p.H) continue;
+      yv[n][r * 2] = s[r][0] + s[r][1] + s[r][2];
+      yv[n][r * 2 + 1] = s[r][1] - s[r][2] - s[r][3];
+    }
+  }
+  wino_store<NT>(p, yv, nt0, g, ob, oy, ox);
+}
+
+// ------------------------------------------------------------------------------------------------
+// ALG 4: Winograd with "half-position" waves and a software-pipelined input transform.
+//   * a wave owns one 16-tile sub-tile, NT n-tiles and HALF of the 16 positions (the two transform
+//     columns c in {0,1} or {2,3}): 8*NT accumulators instead of 16*NT, so one wave covers up to 48
+//     output channels with a single window read + transform (V is reused by 3 n-tiles);
+//   * the raw patch is double-buffered: while the MFMAs of slice c issue, the same wave reads the
+//     window of slice c+1 from the other buffer and transforms it (VALU beside MFMA); one barrier per
+//     slice, no barrier-separated read/transform/MFMA phases;
+//   * the two halves of a tile meet once, at the end: the upper half hands its partial 2x2 outputs to
+//     its partner through LDS (the U buffers are dead by then), the lower half adds and stores.
+// ------------------------------------------------------------------------------------------------
+template <int NT>
+__global__ void __launch_bounds__(512)
+conv_wino2_kernel(const WinoParams p) {
+  extern __shared__ float4 smem[];   // [raw buf 0][raw buf 1][U buf 0][U buf 1]
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nwaves = blockDim.x >> 6;
+  const int wm = wave % p.WM;
+  const int half = wave / p.WM;          // 0: positions (r, 0..1); 1: positions (r, 2..3)
+  const int idx = lane & 15;
+  const int g = lane >> 4;
+  const int ntiles = p.nblocks_m * p.nb_n;
+  const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) float4*)smem;
+  const int rawF4 = 4 * p.planeF4;
+  const int nuitems = 16 * NT;
+
+  // Persistent: the block walks tiles t = blockIdx.x, +gridDim.x, ...; slices of consecutive tiles form one
+  // pipeline (running slice counter `it` selects the LDS buffers), so the first fetches of tile k+1 are
+  // in flight during the exchange/epilogue of tile k and its stores drain under tile k+1's MFMAs.
+  auto decode_goff = [&](int tile, int* go) {
+    const int s0 = (tile % p.nblocks_m) * p.NI;
 #pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        const int x = ox + q;
-        if (x >= p.W) continue;
-        f32x4 v4 = (q == 0) ? (s[r][0] + s[r][1] + s[r][2]) : (s[r][1] - s[r][2] - s[r][3]);
-        const size_t opix = ((size_t)ob * p.H + y) * p.W + x;
-        v4[0] += sh.x; v4[1] += sh.y; v4[2] += sh.z; v4[3] += sh.w;
-        float4 rr = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (p.res) rr = *reinterpret_cast<const float4*>(p.res + opix * p.res_cs + p.res_co + co);
-        if (!p.res_after_act) { v4[0] += rr.x; v4[1] += rr.y; v4[2] += rr.z; v4[3] += rr.w; }
-        if (p.act == 1) {
-          v4[0] = fmaxf(v4[0], 0.f); v4[1] = fmaxf(v4[1], 0.f); v4[2] = fmaxf(v4[2], 0.f); v4[3] = fmaxf(v4[3], 0.f);
-        } else if (p.act == 2) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v4[e] = 1.f / (1.f + __expf(-v4[e]));
-        }
-        if (p.res_after_act) { v4[0] += rr.x; v4[1] += rr.y; v4[2] += rr.z; v4[3] += rr.w; }
-        *reinterpret_cast<float4*>(p.out + opix * p.out_cs + p.out_co + co) = make_float4(v4[0], v4[1], v4[2], v4[3]);
+    for (int k = 0; k < WINO_MAXG; ++k) {
+      go[k] = -1;
+      const int grp = wm + k * p.WM;
+      uint32_t pos = (uint32_t)(grp * 64 + lane);
+      asm volatile("" : "+v"(pos));     // opaque: keep the tile-invariant part out of long-lived VGPRs
+      if (grp < p.ngroups && pos < (uint32_t)p.npos) {
+        const uint32_t sl = fdiv(pos, p.dSlab);
+        const uint32_t rem = pos - sl * p.dSlab.d;
+        const uint32_t prow = fdiv(rem, p.dPW);
+        const uint32_t pcol = rem - prow * p.dPW.d;
+        const uint32_t s = s0 + sl;
+        const uint32_t b = fdiv(s, p.dBands);
+        const uint32_t band = s - b * p.dBands.d;
+        const int iy = (int)(band * p.R) - 1 + (int)prow;
+        const int ix = (int)pcol - 1;
+        if (s < (uint32_t)p.S && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
+          go[k] = (int)(((size_t)(b * p.H + iy) * p.W + ix) * p.in_cs + p.in_co);
       }
     }
+  };
+  auto issue_raw = [&](int c, int it, const int* go) {
+    const unsigned rb = lds_base + (unsigned)((it & 1) * rawF4) * 16u;
+#pragma unroll
+    for (int k = 0; k < WINO_MAXG; ++k) {
+      const int grp = wm + k * p.WM;
+      if (grp < p.ngroups) {
+        const float* src0 = p.in + go[k] + c * 16;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const void* src = (go[k] >= 0) ? (const void*)(src0 + q * 4) : (const void*)&g_zero_page_w;
+          lds_dma16(src, (unsigned)__builtin_amdgcn_readfirstlane((int)(rb + (unsigned)(q * p.planeF4 + grp * 64) * 16u)));
+        }
+      }
+    }
+  };
+  auto issue_u = [&](int c, int it, int nt0) {
+    const unsigned ub = lds_base + (unsigned)(2 * rawF4 + (it & 1) * p.ubufF4) * 16u;
+    for (int i = wm; i < nuitems; i += p.WM) {
+      const int xi = i / NT, j = i - xi * NT;
+      const int nt = min(nt0 + j, p.nT16 - 1);
+      const float4* src = p.ufrag + (((size_t)xi * p.nC16 + c) * p.nT16 + nt) * 64 + lane;
+      lds_dma16(src, (unsigned)__builtin_amdgcn_readfirstlane((int)(ub + (unsigned)(i * 64) * 16u)));
+    }
+  };
+
+  // Only the upper-half waves touch the DMA queue (issue + s_waitcnt vmcnt); the lower-half waves own the
+  // epilogue stores and never wait on vmcnt inside the loop, so a tile's output drains to HBM in the
+  // background while the next tile's MFMAs run (on gfx9 stores and loads share the one VM counter).
+  const bool dma_wave = (half == 1);
+  int t = blockIdx.x;
+  if (t >= ntiles) return;
+  int goff[WINO_MAXG], goffN[WINO_MAXG];
+  int it0 = 0;
+  if (dma_wave) {
+    decode_goff(t, goff);
+    const int nt0 = (t / p.nblocks_m) * NT;
+    issue_raw(0, it0, goff);
+    issue_u(0, it0, nt0);
+    if (p.nC16 > 1) issue_raw(1, it0 + 1, goff);
+  }
+
+  for (; t < ntiles; t += gridDim.x) {
+    const int tn = t + gridDim.x;
+    const bool has_next = tn < ntiles;
+    const int nt0 = (t / p.nblocks_m) * NT;
+    // ---- this lane's tile ---------------------------------------------------------------------
+    int base, oy, ox, ob;
+    {
+      const int s0 = (t % p.nblocks_m) * p.NI;
+      uint32_t tidx = (uint32_t)(wm * 16 + idx);
+      asm volatile("" : "+v"(tidx));
+      const uint32_t sl = fdiv(tidx, p.dTslab);
+      const uint32_t rem = tidx - sl * p.dTslab.d;
+      const uint32_t tyl = fdiv(rem, p.dTX);
+      const uint32_t tx = rem - tyl * p.dTX.d;
+      const uint32_t s = s0 + sl;
+      const uint32_t b = fdiv(s, p.dBands);
+      const uint32_t band = s - b * p.dBands.d;
+      const bool valid = (sl < (uint32_t)p.NI) && (s < (uint32_t)p.S);
+      base = valid ? (int)((sl * p.PR + 2 * tyl) * p.PW + 2 * tx) : 0;
+      ob = valid ? (int)b : -1;
+      oy = (int)(band * p.R + 2 * tyl);
+      ox = (int)(2 * tx);
+    }
+    f32x4 acc[8][NT];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int n = 0; n < NT; ++n) acc[i][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    if (dma_wave) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                   // raw(0), U(0) (and raw(1)) of this tile have landed
+
+    // The K loop is instantiated once per half (wave-uniform) so that its body is ONE basic block: hipcc
+    // can then interleave the window reads + transform of slice c+1 with the MFMAs of slice c.
+    auto kloop = [&](auto HC) {
+      constexpr int HALF = decltype(HC)::value;
+      auto load_transform = [&](int it, float4* vout) {
+        const float4* pl = smem + (it & 1) * rawF4 + g * p.planeF4 + base + HALF;
+        float4 d[4][3];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int a = 0; a < 3; ++a) d[r][a] = pl[r * p.PW + a];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+          const float4 d0 = d[0][a], d1 = d[1][a], d2 = d[2][a], d3 = d[3][a];
+          d[0][a] = f4sub(d0, d2); d[1][a] = f4add(d1, d2); d[2][a] = f4sub(d2, d1); d[3][a] = f4sub(d1, d3);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if constexpr (HALF == 0) { vout[r * 2] = f4sub(d[r][0], d[r][2]); vout[r * 2 + 1] = f4add(d[r][1], d[r][2]); }
+          else { vout[r * 2] = f4sub(d[r][1], d[r][0]); vout[r * 2 + 1] = f4sub(d[r][0], d[r][2]); }   // local cols = window cols 1,2,3
+        }
+      };
+      float4 vcur[8];
+      load_transform(it0, vcur);
+      for (int c = 0; c < p.nC16; ++c) {
+        const int it = it0 + c;
+        // raw(c+1) and U(c) landed; everybody is done with slice c-1 (for c == 0: with the window read of
+        // slice 0 above, whose buffer the raw(2) DMA below overwrites)
+        if constexpr (HALF == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if constexpr (HALF == 1) {
+          if (c + 1 < p.nC16) issue_u(c + 1, it + 1, nt0);
+          if (c + 2 < p.nC16) issue_raw(c + 2, it + 2, goff);
+        }
+        float4 vnext[8];
+        load_transform(it + 1, vnext);   // past the last slice this reads stale LDS and is never used
+        const float4* ul = smem + 2 * rawF4 + (it & 1) * p.ubufF4 + (2 * HALF * NT) * 64 + lane;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float4 u0[NT], u1[NT];
+#pragma unroll
+          for (int n = 0; n < NT; ++n) { u0[n] = ul[((4 * r) * NT + n) * 64]; u1[n] = ul[((4 * r + 1) * NT + n) * 64]; }
+          const float a0[4] = {vcur[2 * r].x, vcur[2 * r].y, vcur[2 * r].z, vcur[2 * r].w};
+          const float a1[4] = {vcur[2 * r + 1].x, vcur[2 * r + 1].y, vcur[2 * r + 1].z, vcur[2 * r + 1].w};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+              const float w0 = (j == 0) ? u0[n].x : (j == 1) ? u0[n].y : (j == 2) ? u0[n].z : u0[n].w;
+              const float w1 = (j == 0) ? u1[n].x : (j == 1) ? u1[n].y : (j == 2) ? u1[n].z : u1[n].w;
+              acc[2 * r][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0, a0[j], acc[2 * r][n], 0, 0, 0);
+              acc[2 * r + 1][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1, a1[j], acc[2 * r + 1][n], 0, 0, 0);
+            }
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) vcur[i] = vnext[i];
+      }
+    };
+    if (half == 0) kloop(std::integral_constant<int, 0>{});
+    else kloop(std::integral_constant<int, 1>{});
+
+    // ---- partial inverse transform of this half --------------------------------------------------
+    // s[r'][q] = A^T over r ;  y[.][0] = s0+s1+s2, y[.][1] = s1-s2-s3 ; this half holds q = 2*half + {0,1}
+    f32x4 y[NT][4];   // [n][r'*2 + q']
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      f32x4 sA[2], sB[2];
+      sA[0] = acc[0][n] + acc[2][n] + acc[4][n];  sA[1] = acc[2][n] - acc[4][n] - acc[6][n];
+      sB[0] = acc[1][n] + acc[3][n] + acc[5][n];  sB[1] = acc[3][n] - acc[5][n] - acc[7][n];
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        if (half == 0) { y[n][r * 2] = sA[r] + sB[r]; y[n][r * 2 + 1] = sB[r]; }
+        else           { y[n][r * 2] = sA[r];         y[n][r * 2 + 1] = -sA[r] - sB[r]; }
+      }
+    }
+    const int itl = it0 + p.nC16 - 1;  // last slice of this tile
+    const int itn = itl + 1;           // first slice of the next tile
+    __syncthreads();                   // every wave is done with the raw and U buffers of this tile
+    if (has_next && dma_wave) {
+      decode_goff(tn, goffN);
+      issue_raw(0, itn, goffN);
+      issue_u(0, itn, (tn / p.nblocks_m) * NT);
+      if (p.nC16 > 1) issue_raw(1, itn + 1, goffN);
+    }
+    float4* xch = smem + 2 * rawF4 + (itl & 1) * p.ubufF4;   // the last slice's U buffer: [wm][n][4][lane]
+    if (half == 1) {
+#pragma unroll
+      for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          xch[((wm * NT + n) * 4 + k) * 64 + lane] = make_float4(y[n][k][0], y[n][k][1], y[n][k][2], y[n][k][3]);
+    }
+    __syncthreads();
+    if (half == 0 && !(p.dbg & 1)) {
+#pragma unroll
+      for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float4 o = xch[((wm * NT + n) * 4 + k) * 64 + lane];
+          y[n][k][0] += o.x; y[n][k][1] += o.y; y[n][k][2] += o.z; y[n][k][3] += o.w;
+        }
+      wino_store<NT>(p, y, nt0, g, ob, oy, ox);
+    }
+    if (has_next) {
+#pragma unroll
+      for (int k = 0; k < WINO_MAXG; ++k) goff[k] = goffN[k];
+    }
+    it0 = itn;
   }
 }
 
@@ -275,7 +550,7 @@ struct WGeo {
   int TX, nbands, S, PR, PW, npos, planeF4, nblocks_m;
 };
 bool wgeo(const ConvDesc& d, const ConvCfg& c, WGeo* g) {
-  if (c.R < 2 || (c.R & 1) || c.NI < 1 || c.WM < 1 || c.WN < 1 || c.NT < 1 || c.NT > 2) return false;
+  if (c.R < 2 || (c.R & 1) || c.NI < 1 || c.WM < 1 || c.WN < 1 || c.NT < 1 || c.NT > (c.ALG == 4 ? 3 : 2)) return false;
   g->TX = (d.W + 1) / 2;
   const int Hc = (d.H + 1) / 2 * 2;
   if (c.R > Hc) return false;
@@ -294,6 +569,8 @@ bool wgeo(const ConvDesc& d, const ConvCfg& c, WGeo* g) {
 size_t conv_wino_lds_bytes(const ConvDesc& d, const ConvCfg& cfg) {
   WGeo g;
   if (!wgeo(d, cfg, &g)) return 0;
+  if (cfg.ALG == 4)   // 2 raw buffers + 2 U buffers (the exchange area at the end reuses the U buffers)
+    return ((size_t)8 * g.planeF4 + (size_t)2 * 16 * cfg.NT * 64) * sizeof(float4);
   return ((size_t)4 * g.planeF4 + (size_t)2 * 16 * cfg.WN * cfg.NT * 64) * sizeof(float4);
 }
 
@@ -320,6 +597,45 @@ int conv_wino_launch(const ConvDesc& d, const ConvCfg& cfg, hipStream_t stream) 
   }
   WGeo g;
   if (!wgeo(d, cfg, &g)) { poco_set_error("conv(winograd): invalid tile configuration"); return POCO_ERR_ARG; }
+  if (cfg.ALG == 4) {
+    if (cfg.WN != 2 || cfg.WM > 4) { poco_set_error("conv(winograd/half): WN must be 2 (the two position halves), WM <= 4"); return POCO_ERR_ARG; }
+    if (cfg.NI * (cfg.R / 2) * g.TX > cfg.WM * 16) { poco_set_error("conv(winograd/half): tiles per block exceed WM*16"); return POCO_ERR_ARG; }
+    const int nw = 2 * cfg.WM;
+    if ((g.planeF4 / 64 + cfg.WM - 1) / cfg.WM > WINO_MAXG) { poco_set_error("conv(winograd/half): patch too large"); return POCO_ERR_ARG; }
+    const size_t lds4 = conv_wino_lds_bytes(d, cfg);
+    if (lds4 > 160 * 1024 || (size_t)cfg.WM * cfg.NT * 4 * 64 > (size_t)2 * 16 * cfg.NT * 64) { poco_set_error("conv(winograd/half): LDS budget exceeded"); return POCO_ERR_ARG; }
+    WinoParams p;
+    p.in = d.in; p.res = d.res; p.out = d.out; p.ufrag = reinterpret_cast<const float4*>(d.wfrag_wino); p.bias = d.bias;
+    p.in_cs = d.in_cs; p.in_co = d.in_co; p.res_cs = d.res_cs; p.res_co = d.res_co; p.out_cs = d.out_cs; p.out_co = d.out_co;
+    p.H = d.H; p.W = d.W; p.nC16 = d.Cin / 16; p.nT16 = d.Cout / 16;
+    p.R = cfg.R; p.NI = cfg.NI; p.S = g.S; p.TX = g.TX; p.PR = g.PR; p.PW = g.PW; p.npos = g.npos; p.planeF4 = g.planeF4;
+    p.ngroups = g.planeF4 / 64;
+    p.WM = cfg.WM; p.WN = 2; p.NTB = cfg.NT; p.ubufF4 = 16 * cfg.NT * 64;
+    p.act = d.act; p.res_after_act = d.res_after_act;
+    {
+      static const int dbg4 = [] { const char* e = getenv("POCO_CONV_DBG"); return e ? atoi(e) : 0; }();
+      p.dbg = dbg4;
+    }
+    p.dPW = make_fastdiv(g.PW); p.dSlab = make_fastdiv(g.PR * g.PW); p.dBands = make_fastdiv(g.nbands);
+    p.dTX = make_fastdiv(g.TX); p.dTslab = make_fastdiv((cfg.R / 2) * g.TX);
+    p.nblocks_m = g.nblocks_m; p.nb_n = (p.nT16 + cfg.NT - 1) / cfg.NT;
+    const long tiles4 = (long)p.nblocks_m * p.nb_n;
+    const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(2, (160 * 1024) / std::max<size_t>(lds4, 1)));
+    dim3 grid4((unsigned)std::min<long>(tiles4, 256L * per_cu), 1);
+    auto fn4 = cfg.NT == 3 ? conv_wino2_kernel<3> : cfg.NT == 2 ? conv_wino2_kernel<2> : conv_wino2_kernel<1>;
+    if (lds4 > 64 * 1024) {
+      static thread_local bool configured4[4] = {false, false, false, false};
+      if (!configured4[cfg.NT]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn4), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) { poco_set_error(std::string("hipFuncSetAttribute: ") + hipGetErrorString(e)); return POCO_ERR_HIP; }
+        configured4[cfg.NT] = true;
+      }
+    }
+    hipLaunchKernelGGL(fn4, grid4, dim3(nw * 64), lds4, stream, p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { poco_set_error(std::string("conv(winograd/half) launch: ") + hipGetErrorString(e)); return POCO_ERR_HIP; }
+    return POCO_OK;
+  }
   const int nwaves = cfg.WM * cfg.WN;
   if (nwaves > (cfg.NT == 1 ? 12 : 8)) { poco_set_error("conv(winograd): at most 12 (NT=1) / 8 (NT=2) waves per block"); return POCO_ERR_ARG; }
   if (cfg.NI * (cfg.R / 2) * g.TX > cfg.WM * 16) { poco_set_error("conv(winograd): tiles per block exceed WM*16"); return POCO_ERR_ARG; }

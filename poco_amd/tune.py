@@ -79,8 +79,23 @@ def candidates(B, H, W, Cin, Cout, ks, stride, lds_cap=150 * 1024) -> List[Tuple
                     npos = ni * (R + 2) * (2 * TX + 2)
                     plane = (npos + 63) // 64 * 64
                     lds = (4 * plane + 2 * 16 * WN * NT * 64) * 16
-                    if lds <= 160 * 1024 and (plane // 64 + WM * WN - 1) // (WM * WN) <= 4:
+                    if lds <= 160 * 1024 and (plane // 64 + WM * WN - 1) // (WM * WN) <= 6:
                         out.add((1, NT, WM, WN, R, ni, 3))
+        for NT, WM in itertools.product((1, 2, 3), (1, 2, 3, 4)):
+            if nT % NT and NT > 1 and nT > NT:
+                pass
+            for R in range(2, (H + 1) // 2 * 2 + 1, 2):
+                tiles = (R // 2) * TX
+                if tiles > WM * 16:
+                    break
+                for ni in {1, max(1, (WM * 16) // tiles)}:
+                    if ni * tiles / (WM * 16) < 0.7 or (ni > 1 and R < H):
+                        continue
+                    npos = ni * (R + 2) * (2 * TX + 2)
+                    plane = (npos + 63) // 64 * 64
+                    lds = (8 * plane + 2 * 16 * NT * 64) * 16
+                    if lds <= 160 * 1024 and (plane // 64 + WM - 1) // WM <= 6 and (nT % NT == 0 or nT < NT):
+                        out.add((1, NT, WM, 2, R, ni, 4))
     return sorted(out)
 
 

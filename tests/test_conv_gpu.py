@@ -97,16 +97,17 @@ def test_conv_parity_lds_dma(case, alg, cuda):
     assert np.abs(out - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max())
 
 
-@pytest.mark.parametrize("nt", [1, 2])
+@pytest.mark.parametrize("alg,nt", [(3, 1), (3, 2), (4, 1), (4, 2), (4, 3)])
 @pytest.mark.parametrize("case", [c for c in CASES if c[5] == 3 and c[6] == 1 and c[3] % 16 == 0] +
                          [(3, 7, 7, 32, 32, 3, 1, True, True), (2, 28, 28, 96, 96, 3, 1, True, False)],
                          ids=lambda c: "x".join(map(str, c)))
-def test_conv_parity_winograd(case, nt, cuda):
+def test_conv_parity_winograd(case, alg, nt, cuda):
     """ALG 3: Winograd F(2x2,3x3) on fp32 MFMA; odd planes (7x7, 13x9, 1x1) exercise the tile overhang."""
     from poco_amd import ops
     B, H, W, Cin, Cout, ks, stride, use_res, relu = case
-    if (Cout // 16) % nt:
+    if (Cout // 16) % nt and alg == 3:
         pytest.skip("n-tiles not divisible")
+    cap = 128 if alg == 3 else 64
     rng = np.random.default_rng(hash(case) % (2**32))
     x = rng.standard_normal((B, H, W, Cin)).astype(np.float32)
     w = (rng.standard_normal((Cout, Cin, 3, 3)) / np.sqrt(Cin * 9)).astype(np.float32)
@@ -116,12 +117,12 @@ def test_conv_parity_winograd(case, nt, cuda):
     ref = _ref(x, w, scale, shift, 1, res, relu)
     TX, Hc = (W + 1) // 2, (H + 1) // 2 * 2
     R = 2
-    while R + 2 <= Hc and ((R + 2) // 2) * TX <= 128:
+    while R + 2 <= Hc and ((R + 2) // 2) * TX <= cap:
         R += 2
     tiles = (R // 2) * TX
     WM = -(-tiles // 16)
     NI = min(B, max(1, (WM * 16) // tiles)) if R >= H else 1
-    cfg = (1, nt, WM, 1, R, NI, 3)
+    cfg = (1, nt, WM, 1 if alg == 3 else 2, R, NI, alg)
     out = ops.conv2d_nhwc(torch.from_numpy(x).to(cuda), w, scale, shift, 1,
                           torch.from_numpy(res).to(cuda) if use_res else None, relu, cfg=cfg).cpu().numpy()
     assert np.abs(out - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max())

@@ -12,7 +12,7 @@ torch.cuda.set_device(0)
 L = lib()
 L.poco_tune_conv.argtypes = [C.c_int] * 7 + [C.POINTER(C.c_int), C.c_int, C.c_int, C.POINTER(C.c_float), C.c_void_p]
 for shp in [(64, 56, 56, 48, 48, 3, 1), (64, 28, 28, 96, 96, 3, 1), (64, 14, 14, 192, 192, 3, 1), (64, 7, 7, 384, 384, 3, 1)]:
-    cands = [c for c in candidates(*shp) if c[6] == 3]
+    cands = [c for c in candidates(*shp) if c[6] in (3, 4)]
     flat = (C.c_int * (7 * len(cands)))(*[v for c in cands for v in c])
     ms = (C.c_float * len(cands))()
     check(L.poco_tune_conv(*shp, flat, len(cands), 10, ms, None), "tune")
