@@ -105,6 +105,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--lanes", type=int, default=4, help="HIP streams for independent branches (1 = single stream)")
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay of the forward")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -131,7 +132,10 @@ def main():
     flops_per_crop = sum(f for _, f, _ in model.ops())
 
     def step():
-        model(batch, out=out)
+        if args.no_graph:
+            model(batch, out=out)
+        else:
+            model.graph_forward(batch, out)
         if world > 1 and not args.no_gather:
             dist.all_gather_into_tensor(gathered, pdist.pack_records(out))
 

@@ -246,6 +246,7 @@ struct Builder {
         for (int o = 0; o < Cout; ++o)
           for (int k = 0; k < Cin_real; ++k) {
             const int dst = kperm ? (*kperm)[k] : k;
+            if (dst < 0) continue;      // column handled by another (split) GEMM
             wsrc[(size_t)o * Cin + dst] = wp[(size_t)o * Cin_real + k];
           }
         wp = wsrc.data();
@@ -625,11 +626,21 @@ bool build_graph(Engine& e, bool declare) {
       decB.data = dpb->data; decB.data.insert(decB.data.end(), dsb->data.begin(), dsb->data.end());
       decB.data.insert(decB.data.end(), dcb->data.begin(), dcb->data.end());
     }
+    // fc1 is linear and [feat, bbox] never change over the 3 iterations (cliff_head.py:103-113): its
+    // 2048-column feature part (+bias) is evaluated once, each iteration only adds the 176-column
+    // [bbox | pose | shape | cam] part on top (residual epilogue).
+    std::vector<int> perm_feat(2208, -1), perm_state(2208, -1);
+    for (int k = 0; k < 2048; ++k) perm_feat[k] = k;
+    for (int k = 2048; k < 2208; ++k) perm_state[k] = perm[k] - 2048;
+    int h0 = b.conv(hp + "fc1.feat", hp + "fc1", "", Builder::R(xc, 0), 2208, 1024, 1, 1, 0, true, Ref(), 0, Ref(),
+                    &perm_feat, 2048, true);
+    e.ops.back().flops = 2.0 * 1024 * 2048;
     int h2 = -1;
     for (int it = 0; it < 3; ++it) {
       const std::string sfx = "#" + std::to_string(it);
-      int h1 = b.conv(hp + "fc1" + sfx, hp + "fc1", "", Builder::R(xc), 2208, 1024, 1, 1, 0, true, Ref(), 0, Ref(),
-                      &perm, XC_DIM, true);
+      int h1 = b.conv(hp + "fc1.state" + sfx, hp + "fc1", "", Builder::R(xc, 2048), 2208, 1024, 1, 1, 0, false, Builder::R(h0), 0,
+                      Ref(), &perm_state, XC_DIM - 2048, true);
+      e.ops.back().flops = 2.0 * 1024 * 160;
       h2 = b.conv(hp + "fc2" + sfx, hp + "fc2", "", Builder::R(h1), 1024, 1024, 1, 1, 0, true, Ref(), 0, Ref(),
                   nullptr, 0, true);
       // fused decoder: state += dec(h2)  (in place on the state slice of xc)

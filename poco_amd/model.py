@@ -250,6 +250,31 @@ class POCO:
 
     forward = __call__
 
+    def graph_forward(self, batch: Dict[str, torch.Tensor], out: Dict[str, torch.Tensor]) -> Dict[str, object]:
+        """Replay the forward as a hipGraph (captured on first use for these exact input/output tensors:
+        the kernels read/write the same device addresses on every replay, so refill `batch` in place).
+        Removes ~375 launches + the fork/join events of the lanes from the host critical path."""
+        key = (tuple(sorted((k, v.data_ptr()) for k, v in batch.items())), tuple(sorted((k, v.data_ptr()) for k, v in out.items())))
+        cache = self.__dict__.setdefault("_graphs", {})
+        if key not in cache:
+            self(batch, out=out)                      # warm-up on the capture stream's pool (tuning table, attributes)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                self(batch, out=out)
+                s.synchronize()
+                with torch.cuda.graph(g, stream=s):
+                    self(batch, out=out)
+            torch.cuda.current_stream().wait_stream(s)
+            cache[key] = g
+        cache[key].replay()
+        res = dict(out)
+        res["log_phi"] = None
+        res["gt_pose_cond_idx"] = []
+        return res
+
     # ---- introspection / stand-alone ops -----------------------------------------------------------
     def ops(self):
         name = C.create_string_buffer(256)
