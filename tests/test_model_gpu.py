@@ -83,6 +83,27 @@ def test_lanes_equivalent(variant, cuda):
                 assert torch.equal(v, b[k]), (lanes, k)
 
 
+@pytest.mark.parametrize("variant,B", [("hrnet_w48_cls-cliff", 64), ("hrnet_w32-pare", 32), ("resnet50-cliff", 64)])
+def test_bench_batch_with_tuned_table(variant, B, cuda):
+    """The batch sizes bench.py runs use the measured tile table (Winograd / LDS-DMA / persistent variants,
+    poco_amd/tuned/gfx950.json): same 1e-3 gate, checked on the first and last crops of the batch."""
+    from poco_amd import tune
+    torch.set_num_threads(16)
+    assert any(k.startswith(f"{B}x") for k in tune.load_table()), "tuned table missing for the bench batch size"
+    bnp = synth.synth_batch(B, 2024)
+    pick = np.r_[0:3, B - 3:B]
+    ref = util.oracle_forward(variant, {k: v[pick] for k, v in bnp.items()})
+    m = util.make_engine(variant, max_batch=B)
+    out = m(util.cuda_batch(bnp, cuda))
+    torch.cuda.synchronize()
+    worst = 0.0
+    for k in ("pred_pose", "pred_shape", "pred_cam", "var_pose", "smpl_vertices", "smpl_joints3d"):
+        err = float(np.abs(_np(out[k])[pick] - ref[k].numpy()).max())
+        worst = max(worst, err)
+        assert err < TOL, (k, err)
+    print(variant, B, "max-abs deviation with tuned kernels", worst)
+
+
 def test_graph_replay_matches_eager(cuda):
     """hipGraph replay of the forward (with the forked lanes captured) is bit-identical to eager launches,
     also after the inputs were refilled in place."""
