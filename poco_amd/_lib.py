@@ -10,7 +10,9 @@ import re
 from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent
-LIB_PATH = ROOT / "lib" / "libpoco_hip.so"
+import os
+# POCO_HIP_LIB: developer override (timing experiments with alternative builds); default = in-tree build
+LIB_PATH = Path(os.environ.get("POCO_HIP_LIB") or (ROOT / "lib" / "libpoco_hip.so"))
 HEADER = ROOT.parent / "include" / "poco_hip.h"
 
 _lib = None

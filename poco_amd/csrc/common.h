@@ -53,8 +53,9 @@ struct ConvDesc {
   const float* bias;                      // [Cout_padded] folded BN shift / conv bias
   int B, H, W, Cin, Cout;                 // Cout = padded to a multiple of 16
   int ks, stride;                         // ks in {1,3}; pad = (ks-1)/2; stride in {1,2}
-  int act;             // 0 none, 1 ReLU, 2 sigmoid
+  int act;             // 0 none, 1 ReLU, 2 sigmoid, 3 ReLU on output channels >= relu_from only
   int res_after_act;   // residual added after the activation instead of before
+  int relu_from;       // act == 3: first output channel (multiple of 16) that gets the ReLU (merged convs)
 };
 
 // Size (floats) of the packed weight buffer for a conv.

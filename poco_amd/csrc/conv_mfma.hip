@@ -62,7 +62,8 @@ struct ConvKParams {
   int nblocks_m, nb_n;   // ALG 2: tile grid walked by the persistent blocks
   int dbg;            // profiling experiments: bit0 = skip the epilogue, bit1 = skip the DMA prologue wait
   int repeat;         // K-loop repetitions (1; >1 = profiling experiment, results meaningless)
-  int act;            // 0 none, 1 ReLU, 2 sigmoid
+  int act;            // 0 none, 1 ReLU, 2 sigmoid, 3 ReLU for channels >= relu_from
+  int relu_from;
   int res_after_act;  // add the residual after the activation (hrnet_cls.py:475-477)
   FastDiv dPW, dSlab /*PR*PW*/, dBands, dWo, dRWo;
 };
@@ -105,7 +106,7 @@ __device__ __forceinline__ void conv_store_tile_impl(const ConvKParams& p, f32x4
       float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
       if constexpr (HAS_RES) r = rcur[m];
       if (!p.res_after_act) { v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w; }
-      if (p.act == 1) {
+      if (p.act == 1 || (p.act == 3 && co >= p.relu_from)) {
         v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
       } else if (p.act == 2) {
 #pragma unroll
@@ -835,6 +836,7 @@ int conv_launch(const ConvDesc& d, const ConvCfg& cfg, hipStream_t stream) {
       poco_set_error("conv: channel counts/strides must be multiples of 16/4");
       return POCO_ERR_ARG;
     }
+    if (d.act == 3) { poco_set_error("conv: the Winograd kernels have no per-channel ReLU split"); return POCO_ERR_ARG; }
     return conv_wino_launch(d, cfg, stream);
   }
   if (!(d.ks == 1 || d.ks == 3) || !(d.stride == 1 || d.stride == 2)) {
@@ -891,7 +893,7 @@ int conv_launch(const ConvDesc& d, const ConvCfg& cfg, hipStream_t stream) {
   kp.NTB = cfg.WN * cfg.NT;
   kp.bufF4 = 4 * g.planeF4 + d.ks * d.ks * kp.NTB * 64;
   kp.ngroups = g.planeF4 / 64;
-  kp.act = d.act; kp.res_after_act = d.res_after_act;
+  kp.act = d.act; kp.res_after_act = d.res_after_act; kp.relu_from = d.relu_from;
   {
     static const int rep = [] { const char* e = getenv("POCO_CONV_REPEAT"); return e ? atoi(e) : 1; }();
     kp.repeat = rep >= 0 ? rep : 1;

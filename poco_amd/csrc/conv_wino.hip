@@ -41,7 +41,7 @@ inline FastDiv make_fastdiv(uint32_t d) {
 }
 __device__ __forceinline__ uint32_t fdiv(uint32_t n, FastDiv f) { return f.d == 1 ? n : __umulhi(n, f.magic); }
 
-__device__ float4 g_zero_page_w;
+__device__ float4 g_zero_page_w[4];   // 64 B of zeros: source of the padding lanes of a 16-channel slice
 
 __device__ __forceinline__ void lds_dma16(const void* gsrc, unsigned lds_dst) {
   unsigned keep;
@@ -49,6 +49,16 @@ __device__ __forceinline__ void lds_dma16(const void* gsrc, unsigned lds_dst) {
       "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
       : "=&s"(keep)
       : "v"(gsrc), "s"(lds_dst)
+      : "memory");
+}
+
+// Same, wave-uniform base (SGPR pair) + per-lane 32-bit byte offset: no 64-bit VALU address arithmetic.
+__device__ __forceinline__ void lds_dma16_sv(const void* sbase, unsigned voff, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voff), "s"(sbase), "s"(lds_dst)
       : "memory");
 }
 
@@ -196,12 +206,10 @@ conv_wino_kernel(const WinoParams p) {
     for (int k = 0; k < WINO_MAXG; ++k) {
       const int grp = wave + k * nwaves;
       if (grp < p.ngroups) {
-        const float* src0 = p.in + goff[k] + c * 16;
+        const float* src0 = (goff[k] >= 0) ? p.in + goff[k] + c * 16 : (const float*)g_zero_page_w;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const void* src = (goff[k] >= 0) ? (const void*)(src0 + q * 4) : (const void*)&g_zero_page_w;
-          lds_dma16(src, (unsigned)__builtin_amdgcn_readfirstlane((int)(lds_base + (unsigned)(q * p.planeF4 + grp * 64) * 16u)));
-        }
+        for (int q = 0; q < 4; ++q)
+          lds_dma16(src0 + q * 4, (unsigned)__builtin_amdgcn_readfirstlane((int)(lds_base + (unsigned)(q * p.planeF4 + grp * 64) * 16u)));
       }
     }
   };
@@ -318,6 +326,9 @@ conv_wino_kernel(const WinoParams p) {
 //   * the two halves of a tile meet once, at the end: the upper half hands its partial 2x2 outputs to
 //     its partner through LDS (the U buffers are dead by then), the lower half adds and stores.
 // ------------------------------------------------------------------------------------------------
+#ifndef WINO_EXP
+#define WINO_EXP 0     // timing experiments only (tools/build_exp.sh); non-zero values compute garbage
+#endif
 template <int NT>
 __global__ void __launch_bounds__(512)
 conv_wino2_kernel(const WinoParams p) {
@@ -328,6 +339,8 @@ conv_wino2_kernel(const WinoParams p) {
   const int nwaves = blockDim.x >> 6;
   const int wm = wave % p.WM;
   const int half = wave / p.WM;          // 0: positions (r, 0..1); 1: positions (r, 2..3)
+  const int dw = (WINO_EXP & 64) ? wave : wm;                 // DMA issue: this wave's index / count among the issuers
+  const int dn = (WINO_EXP & 64) ? (int)(blockDim.x >> 6) : p.WM;
   const int idx = lane & 15;
   const int g = lane >> 4;
   const int ntiles = p.nblocks_m * p.nb_n;
@@ -343,7 +356,7 @@ conv_wino2_kernel(const WinoParams p) {
 #pragma unroll
     for (int k = 0; k < WINO_MAXG; ++k) {
       go[k] = -1;
-      const int grp = wm + k * p.WM;
+      const int grp = dw + k * dn;
       uint32_t pos = (uint32_t)(grp * 64 + lane);
       asm volatile("" : "+v"(pos));     // opaque: keep the tile-invariant part out of long-lived VGPRs
       if (grp < p.ngroups && pos < (uint32_t)p.npos) {
@@ -365,31 +378,36 @@ conv_wino2_kernel(const WinoParams p) {
     const unsigned rb = lds_base + (unsigned)((it & 1) * rawF4) * 16u;
 #pragma unroll
     for (int k = 0; k < WINO_MAXG; ++k) {
-      const int grp = wm + k * p.WM;
+      const int grp = dw + k * dn;
       if (grp < p.ngroups) {
-        const float* src0 = p.in + go[k] + c * 16;
+        const float* src0 = (go[k] >= 0) ? p.in + go[k] + c * 16 : (const float*)g_zero_page_w;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const void* src = (go[k] >= 0) ? (const void*)(src0 + q * 4) : (const void*)&g_zero_page_w;
-          lds_dma16(src, (unsigned)__builtin_amdgcn_readfirstlane((int)(rb + (unsigned)(q * p.planeF4 + grp * 64) * 16u)));
-        }
+        for (int q = 0; q < 4; ++q)
+          lds_dma16(src0 + q * 4, (unsigned)__builtin_amdgcn_readfirstlane((int)(rb + (unsigned)(q * p.planeF4 + grp * 64) * 16u)));
       }
     }
   };
   auto issue_u = [&](int c, int it, int nt0) {
-    const unsigned ub = lds_base + (unsigned)(2 * rawF4 + (it & 1) * p.ubufF4) * 16u;
-    for (int i = wm; i < nuitems; i += p.WM) {
-      const int xi = i / NT, j = i - xi * NT;
-      const int nt = min(nt0 + j, p.nT16 - 1);
-      const float4* src = p.ufrag + (((size_t)xi * p.nC16 + c) * p.nT16 + nt) * 64 + lane;
-      lds_dma16(src, (unsigned)__builtin_amdgcn_readfirstlane((int)(ub + (unsigned)(i * 64) * 16u)));
+    // item i = (position xi, n-tile j) lives at ((xi*nC16 + c)*nT16 + nt) KiB of the packed buffer: a wave-uniform
+    // base for the slice + a 32-bit per-item offset stepped incrementally (scalar ALU only, one v_add per DMA)
+    unsigned ub = lds_base + (unsigned)(2 * rawF4 + (it & 1) * p.ubufF4) * 16u + (unsigned)dw * 1024u;
+    const char* sb = reinterpret_cast<const char*>(p.ufrag) + (size_t)((unsigned)c * (unsigned)p.nT16) * 1024u;
+    const unsigned xstride = (unsigned)(p.nC16 * p.nT16) * 1024u;
+    const int dxi = dn / NT, dj = dn - dxi * NT;
+    int xi = dw / NT, j = dw - xi * NT;
+    for (int i = dw; i < nuitems; i += dn) {
+      const unsigned off = (unsigned)xi * xstride + (unsigned)min(nt0 + j, p.nT16 - 1) * 1024u;
+      lds_dma16_sv(sb, off + (unsigned)lane * 16u, (unsigned)__builtin_amdgcn_readfirstlane((int)ub));
+      ub += (unsigned)dn * 1024u;
+      xi += dxi; j += dj;
+      if (j >= NT) { j -= NT; ++xi; }
     }
   };
 
   // Only the upper-half waves touch the DMA queue (issue + s_waitcnt vmcnt); the lower-half waves own the
   // epilogue stores and never wait on vmcnt inside the loop, so a tile's output drains to HBM in the
   // background while the next tile's MFMAs run (on gfx9 stores and loads share the one VM counter).
-  const bool dma_wave = (half == 1);
+  const bool dma_wave = (WINO_EXP & 64) ? true : (half == 1);
   int t = blockIdx.x;
   if (t >= ntiles) return;
   int goff[WINO_MAXG], goffN[WINO_MAXG];
@@ -462,20 +480,39 @@ conv_wino2_kernel(const WinoParams p) {
         const int it = it0 + c;
         // raw(c+1) and U(c) landed; everybody is done with slice c-1 (for c == 0: with the window read of
         // slice 0 above, whose buffer the raw(2) DMA below overwrites)
-        if constexpr (HALF == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr (HALF == 1 || (WINO_EXP & 64)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#if !(WINO_EXP & 8)
         __syncthreads();
-        if constexpr (HALF == 1) {
+#endif
+#if !(WINO_EXP & 4)
+        if constexpr (HALF == 1 || (WINO_EXP & 64)) {
+#if !(WINO_EXP & 16)
           if (c + 1 < p.nC16) issue_u(c + 1, it + 1, nt0);
+#endif
+#if !(WINO_EXP & 32)
           if (c + 2 < p.nC16) issue_raw(c + 2, it + 2, goff);
+#endif
         }
+#endif
         float4 vnext[8];
+#if WINO_EXP & 1
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { vnext[i] = vcur[i]; asm volatile("" : "+v"(vnext[i].x), "+v"(vnext[i].y), "+v"(vnext[i].z), "+v"(vnext[i].w)); }
+#else
         load_transform(it + 1, vnext);   // past the last slice this reads stale LDS and is never used
+#endif
         const float4* ul = smem + 2 * rawF4 + (it & 1) * p.ubufF4 + (2 * HALF * NT) * 64 + lane;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           float4 u0[NT], u1[NT];
 #pragma unroll
-          for (int n = 0; n < NT; ++n) { u0[n] = ul[((4 * r) * NT + n) * 64]; u1[n] = ul[((4 * r + 1) * NT + n) * 64]; }
+          for (int n = 0; n < NT; ++n) {
+#if WINO_EXP & 2
+            u0[n] = vcur[(r + n) & 7]; u1[n] = vcur[(r + n + 3) & 7];
+#else
+            u0[n] = ul[((4 * r) * NT + n) * 64]; u1[n] = ul[((4 * r + 1) * NT + n) * 64];
+#endif
+          }
           const float a0[4] = {vcur[2 * r].x, vcur[2 * r].y, vcur[2 * r].z, vcur[2 * r].w};
           const float a1[4] = {vcur[2 * r + 1].x, vcur[2 * r + 1].y, vcur[2 * r + 1].z, vcur[2 * r + 1].w};
 #pragma unroll

@@ -68,12 +68,12 @@ struct Op {
   double flops = 0;     // per crop
   Ref in, in2, res, out, out2;
   // conv
-  int Cin = 0, Cout = 0, ks = 1, stride = 1, actfn = 0, res_after = 0;
+  int Cin = 0, Cout = 0, ks = 1, stride = 1, actfn = 0, res_after = 0, relu_from = 0;
   float* wdev = nullptr;
   float* bdev = nullptr;
   float* wdev_wino = nullptr;   // 3x3 stride-1 convs: Winograd-transformed weights (ALG 3)
   // fuse
-  Ref fsrc[4];
+  Ref fsrc[4];        // terms may be channel slices of wider (merged-conv) buffers
   int fshift[4] = {0, 0, 0, 0};
   int fn = 0, frelu = 1;
   // misc ints
@@ -311,11 +311,59 @@ struct Builder {
     return out;
   }
 
-  void fuse_sum(const std::string& name, const std::vector<std::pair<int, int>>& terms, Ref out, int relu) {
-    Op op; op.type = OP_FUSE; op.name = name; op.fn = (int)terms.size(); op.frelu = relu;
-    for (size_t k = 0; k < terms.size(); ++k) { op.fsrc[k] = R(terms[k].first); op.fshift[k] = terms[k].second; }
+  void fuse_sum(const std::string& name, const std::vector<std::pair<Ref, int>>& terms, int C, Ref out, int relu) {
+    Op op; op.type = OP_FUSE; op.name = name; op.fn = (int)terms.size(); op.frelu = relu; op.C = C;
+    for (size_t k = 0; k < terms.size(); ++k) { op.fsrc[k] = terms[k].first; op.fshift[k] = terms[k].second; }
     op.out = out;
     push(std::move(op));
+  }
+
+  // Several convs of the same geometry reading the SAME input, run as one launch: weights / folded BN are
+  // concatenated along the output channels and the result is one wide tensor whose channel slices the
+  // consumers read in place.  ReLU members must come last (act 3 = ReLU for channels >= relu_from).
+  struct SubConv { std::string convp, bnp; int Cout; int relu; };
+  int conv_multi(const std::string& name, const std::vector<SubConv>& subs, Ref in, int Cin, int ks, int stride,
+                 std::vector<int>* offsets) {
+    const Act ain = e.acts[in.act];
+    const int pad = (ks - 1) / 2;
+    const int Ho = (ain.H + 2 * pad - ks) / stride + 1, Wo = (ain.W + 2 * pad - ks) / stride + 1;
+    int Ctot = 0, relu_from = -1;
+    offsets->clear();
+    for (const SubConv& sc : subs) {
+      if (sc.Cout % 16) { ok = false; e.err += "conv_multi: member widths must be multiples of 16; "; }
+      if (sc.relu && relu_from < 0) relu_from = Ctot;
+      if (!sc.relu && relu_from >= 0) { ok = false; e.err += "conv_multi: ReLU members must come last; "; }
+      offsets->push_back(Ctot);
+      Ctot += sc.Cout;
+    }
+    const size_t per = (size_t)Cin * ks * ks;
+    std::vector<float> wcat, scat, hcat;
+    bool have = !declare;
+    for (const SubConv& sc : subs) {
+      const HostParam* w = P(sc.convp + ".weight", {sc.Cout, Cin, ks, ks});
+      std::vector<float> scale, shift;
+      bn_fold(sc.bnp, nullptr, sc.Cout, scale, shift);
+      if (declare || !w) { have = false; continue; }
+      wcat.insert(wcat.end(), w->data.begin(), w->data.begin() + (size_t)sc.Cout * per);
+      scat.insert(scat.end(), scale.begin(), scale.end());
+      hcat.insert(hcat.end(), shift.begin(), shift.end());
+    }
+    Op op;
+    op.type = OP_CONV; op.name = name;
+    op.in = in; op.Cin = Cin; op.Cout = Ctot; op.ks = ks; op.stride = stride;
+    op.actfn = relu_from < 0 ? 0 : (relu_from == 0 ? 1 : 3);
+    op.relu_from = std::max(relu_from, 0);
+    op.flops = 2.0 * Ho * Wo * (double)Ctot * Cin * ks * ks;
+    const int out_act = new_act(Ctot, Ho, Wo);
+    op.out = R(out_act);
+    if (have) {
+      std::vector<float> packed(conv_packed_weight_floats(Cin, Ctot, ks));
+      conv_pack_weights(wcat.data(), scat.data(), Ctot, Cin, ks, Ctot, packed.data());
+      op.wdev = upload(packed);
+      op.bdev = upload(hcat);
+    }
+    push(std::move(op));
+    return out_act;
   }
 
   // HighResolutionModule.forward, hrnet.py:248-266.  last_into: write branch-0 output into a wider
@@ -329,27 +377,52 @@ struct Builder {
       for (int k = 0; k < 4; ++k) xs[i] = basic_block(p + ".branches." + std::to_string(i) + "." + std::to_string(k), xs[i], ch[i]);
     }
     end_parallel();
-    // phase 2: every cross-resolution term (i,j) is an independent conv chain
-    std::vector<std::vector<std::pair<int, int>>> terms(nb);
+    // phase 2: cross-resolution terms.  All first convs that read the same branch output xs[j] run as ONE
+    // launch each (the 1x1 up-path convs j -> i<j, and the first 3x3 stride-2 convs of the down paths
+    // j -> i>j): the input is read once and the small per-path launches disappear.
+    std::vector<std::vector<std::pair<Ref, int>>> terms(nb);
+    std::vector<std::vector<Ref>> chain(nb, std::vector<Ref>(nb));   // [i][j]: running tensor of down path j -> i
+    for (int i = 0; i < nb; ++i) terms[i].resize(nb);
+    auto fl = [&](int i, int j) { return p + ".fuse_layers." + std::to_string(i) + "." + std::to_string(j); };
     begin_parallel();
     int rr = 0;
-    for (int i = 0; i < nb; ++i) {
-      for (int j = 0; j < nb; ++j) {
-        const std::string q = p + ".fuse_layers." + std::to_string(i) + "." + std::to_string(j);
-        if (j == i) { terms[i].push_back({xs[j], 0}); continue; }
+    for (int j = 0; j < nb; ++j) {
+      if (j > 0) {                       // up paths: 1x1 conv + BN (hrnet.py:196-207), upsampled inside the sum
+        std::vector<SubConv> subs;
+        for (int i = 0; i < j; ++i) subs.push_back({fl(i, j) + ".0", fl(i, j) + ".1", ch[i], 0});
+        std::vector<int> off;
         lane(rr++);
-        if (j > i) terms[i].push_back({conv_bn(q + ".0", q + ".1", xs[j], ch[j], ch[i], 1, 1, 0), j - i});
-        else {
-          int t = xs[j];
-          for (int k = 0; k < i - j; ++k) {
-            const bool lastk = (k == i - j - 1);
-            const std::string qq = q + "." + std::to_string(k);
-            t = conv_bn(qq + ".0", qq + ".1", t, ch[j], lastk ? ch[i] : ch[j], 3, 2, lastk ? 0 : 1);
-          }
-          terms[i].push_back({t, 0});
+        const int t = conv_multi(p + ".fuse_up." + std::to_string(j), subs, R(xs[j]), ch[j], 1, 1, &off);
+        for (int i = 0; i < j; ++i) terms[i][j] = {R(t, off[i]), j - i};
+      }
+      if (j + 1 < nb) {                  // down paths: first 3x3 stride-2 conv of every chain (hrnet.py:208-236)
+        std::vector<SubConv> subs;
+        for (int i = j + 1; i < nb; ++i) {
+          const bool last = (i == j + 1);
+          subs.push_back({fl(i, j) + ".0.0", fl(i, j) + ".0.1", last ? ch[i] : ch[j], last ? 0 : 1});
         }
+        std::vector<int> off;
+        lane(rr++);
+        const int t = conv_multi(p + ".fuse_down." + std::to_string(j), subs, R(xs[j]), ch[j], 3, 2, &off);
+        for (int i = j + 1; i < nb; ++i) chain[i][j] = R(t, off[i - j - 1]);
       }
     }
+    end_parallel();
+    // phase 2b: the rest of the down chains (different inputs -> separate launches), one lane per chain
+    begin_parallel();
+    rr = 0;
+    for (int i = 0; i < nb; ++i)
+      for (int j = 0; j < i; ++j) {
+        if (i - j > 1) lane(rr++);
+        Ref t = chain[i][j];
+        for (int k = 1; k < i - j; ++k) {
+          const bool lastk = (k == i - j - 1);
+          const std::string qq = fl(i, j) + "." + std::to_string(k);
+          const int y = conv(qq + ".0", qq + ".0", qq + ".1", t, ch[j], lastk ? ch[i] : ch[j], 3, 2, lastk ? 0 : 1, false);
+          t = R(y);
+        }
+        terms[i][j] = {t, 0};
+      }
     end_parallel();
     // phase 3: the sums (+ReLU), one lane per output branch
     std::vector<int> outs(nb);
@@ -357,8 +430,9 @@ struct Builder {
     for (int i = 0; i < nb; ++i) {
       lane(i);
       const Act a = e.acts[xs[i]];
-      if (i == 0 && out0.act >= 0) { outs[i] = out0.act; fuse_sum(p + ".fuse" + std::to_string(i), terms[i], out0, 1); }
-      else { outs[i] = new_act(a.C, a.H, a.W); fuse_sum(p + ".fuse" + std::to_string(i), terms[i], R(outs[i]), 1); }
+      terms[i][i] = {R(xs[i]), 0};
+      if (i == 0 && out0.act >= 0) { outs[i] = out0.act; fuse_sum(p + ".fuse" + std::to_string(i), terms[i], ch[i], out0, 1); }
+      else { outs[i] = new_act(a.C, a.H, a.W); fuse_sum(p + ".fuse" + std::to_string(i), terms[i], ch[i], R(outs[i]), 1); }
     }
     end_parallel();
     return outs;
@@ -863,7 +937,7 @@ int run_op(Engine& e, Op& op, int B, const IO& io, hipStream_t s) {
       d.out = aptr(e, op.out); d.out_cs = ao.C; d.out_co = 0;
       d.wfrag = op.wdev; d.bias = op.bdev; d.wfrag_wino = op.wdev_wino;
       d.B = B; d.H = ai.H; d.W = ai.W; d.Cin = op.Cin; d.Cout = op.Cout; d.ks = op.ks; d.stride = op.stride;
-      d.act = op.actfn; d.res_after_act = op.res_after;
+      d.act = op.actfn; d.res_after_act = op.res_after; d.relu_from = op.relu_from;
       auto it = op.cfg.find(B);
       if (it == op.cfg.end()) it = op.cfg.emplace(B, conv_default_cfg(d)).first;
       return conv_launch(d, it->second, s);
@@ -881,13 +955,15 @@ int run_op(Engine& e, Op& op, int B, const IO& io, hipStream_t s) {
     case OP_FUSE: {
       FuseArgs fa{};
       fa.n = op.fn;
-      for (int k = 0; k < op.fn; ++k) { fa.src[k] = aptr(e, op.fsrc[k]); fa.shift[k] = op.fshift[k]; }
+      for (int k = 0; k < op.fn; ++k) {
+        fa.src[k] = aptr(e, op.fsrc[k]); fa.shift[k] = op.fshift[k]; fa.src_cs[k] = e.acts[op.fsrc[k].act].C;
+      }
       const Act& ao = e.acts[op.out.act];
-      // the i-th term (shift 0, identity branch) defines the output geometry
-      int H = 0, W = 0, C = 0;
+      // the identity term (first with shift 0 that is a whole tensor) defines the output plane; op.C the width
+      int H = 0, W = 0;
       for (int k = 0; k < op.fn; ++k)
-        if (op.fshift[k] == 0) { const Act& a = e.acts[op.fsrc[k].act]; H = a.H; W = a.W; C = a.C; }
-      launch_fuse_sum(fa, aptr(e, op.out), B, H, W, C, ao.C, op.frelu, s);
+        if (op.fshift[k] == 0) { const Act& a = e.acts[op.fsrc[k].act]; H = a.H; W = a.W; }
+      launch_fuse_sum(fa, aptr(e, op.out), B, H, W, op.C, ao.C, op.frelu, s);
       return POCO_OK;
     }
     case OP_AVGPOOL: {

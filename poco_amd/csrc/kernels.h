@@ -14,8 +14,9 @@ void launch_maxpool3x3s2(const float* in, float* out, int B, int H, int W, int C
 void launch_bilinear_up2x(const float* in, float* out, int B, int H, int W, int C, hipStream_t s);
 // out = ReLU( sum_k addend_k[b, y >> shift_k, x >> shift_k, :] )  (HRNet fuse, hrnet.py:257-264).
 struct FuseArgs {
-  const float* src[4];
-  int shift[4];
+  const float* src[4];   // first channel of each term
+  int shift[4];          // nearest-neighbour upsampling: the term's plane is (H >> shift) x (W >> shift)
+  int src_cs[4];         // channels per pixel of each term's buffer (a term may be a channel slice)
   int n;
 };
 // `out` points at the first output channel; out_cs = channels per pixel of the destination buffer.

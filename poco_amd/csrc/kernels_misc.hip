@@ -122,7 +122,7 @@ __global__ void fuse_sum_kernel(FuseArgs a, float4* __restrict__ out, int B, int
     if (k < a.n) {
       const int sh = a.shift[k];
       const int hs = H >> sh, wsz = W >> sh;
-      const float4 v = reinterpret_cast<const float4*>(a.src[k])[(((size_t)b * hs + (y >> sh)) * wsz + (x >> sh)) * C4 + c];
+      const float4 v = reinterpret_cast<const float4*>(a.src[k])[(((size_t)b * hs + (y >> sh)) * wsz + (x >> sh)) * (a.src_cs[k] >> 2) + c];
       if (k == 0) acc = v;
       else { acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }
     }

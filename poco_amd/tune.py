@@ -117,7 +117,7 @@ def tune_shape(L, B, H, W, Cin, Cout, ks, stride, iters=8):
     return cands2[best_i], float(ms2[best_i]), float(base), len(cands)
 
 
-def tune_model(model, B: int, verbose=True) -> Dict[str, dict]:
+def tune_model(model, B: int, verbose=True, skip=()) -> Dict[str, dict]:
     from ._lib import lib
     L = lib()
     L.poco_tune_conv.argtypes = [C.c_int] * 7 + [C.POINTER(C.c_int), C.c_int, C.c_int, C.POINTER(C.c_float), C.c_void_p]
@@ -131,8 +131,10 @@ def tune_model(model, B: int, verbose=True) -> Dict[str, dict]:
     out = {}
     t0 = time.time()
     for (H, W, Cin, Cout, ks, stride), idxs in sorted(shapes.items(), key=lambda kv: -len(kv[1])):
-        cfg, ms, base, n = tune_shape(L, B, H, W, Cin, Cout, ks, stride)
         key = shape_key(B, H, W, Cin, Cout, ks, stride)
+        if key in skip:
+            continue
+        cfg, ms, base, n = tune_shape(L, B, H, W, Cin, Cout, ks, stride)
         fl = 2.0 * B * ((H + 2 * ((ks - 1) // 2) - ks) // stride + 1) ** 2 * Cout * Cin * ks * ks if H == W else 0
         out[key] = {"cfg": list(cfg), "ms": round(ms, 5), "heuristic_ms": round(base, 5), "uses": len(idxs),
                     "tflops": round(fl / ms / 1e9, 1) if ms > 0 else 0}
@@ -165,16 +167,21 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--variant", default="hrnet_w48_cls-cliff")
     ap.add_argument("--batch", type=int, nargs="+", default=[64])
+    ap.add_argument("--only-missing", action="store_true", help="keep existing table entries, tune new shapes only")
+    ap.add_argument("--out", default=str(TABLE), help="where to write the merged table")
     args = ap.parse_args()
     torch.cuda.set_device(0)
     fl = {"hrnet_w32-pare": 3, "hrnet_w48_cls-cliff": 1, "resnet50-cliff": 1}[args.variant]
     m = POCO(backbone=args.variant, num_flow_layers=fl, max_batch=1)   # declarations only: shapes, no weights
     full = json.loads(TABLE.read_text()) if TABLE.exists() else {}
     for B in args.batch:
-        full.update({k: v for k, v in tune_model(m, B).items() if v["cfg"][0] > 0})
-    TABLE.parent.mkdir(exist_ok=True)
+        full.update({k: v for k, v in tune_model(m, B, skip=set(full) if args.only_missing else ()).items()
+                     if v["cfg"][0] > 0})
+    out = Path(args.out)
+    out.parent.mkdir(exist_ok=True, parents=True)
+    out.write_text(json.dumps(full, indent=0, sort_keys=True))
     TABLE.write_text(json.dumps(full, indent=0, sort_keys=True))
-    print("wrote", TABLE, len(full), "entries")
+    print("wrote", out, len(full), "entries")
 
 
 if __name__ == "__main__":
