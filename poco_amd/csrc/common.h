@@ -39,6 +39,7 @@ struct ConvCfg {
   int ALG;     // 0: register-staged single LDS buffer; 1: LDS-DMA double-buffered (patch + weights);
                // 2: ALG 1 persistent over tiles; 3: Winograd F(2x2,3x3) (MT ignored, NT in {1,2}, R even);
                // 4: Winograd, half-position waves + pipelined transform (WN = 2 halves, WM <= 4, NT <= 3)
+               // 5: small-M linear (H = W = 1, ks = 1): K split over WM waves per 16 outputs (linear_mfma.hip)
 };
 constexpr int CONV_CFG_INTS = 7;   // ints per configuration in the C ABI / tuning table
 inline ConvCfg conv_cfg_from(const int* c) { return ConvCfg{c[0], c[1], c[2], c[3], c[4], c[5], c[6]}; }
@@ -70,6 +71,10 @@ ConvCfg conv_default_cfg(const ConvDesc& d);
 int conv_launch(const ConvDesc& d, const ConvCfg& cfg, hipStream_t stream);
 // LDS bytes a configuration needs (0 if invalid).
 size_t conv_lds_bytes(const ConvDesc& d, const ConvCfg& cfg);
+
+// ---- small-M linear layers (linear_mfma.hip), ALG 5 -------------------------------------------------
+bool linear_cfg_valid(const ConvDesc& d, const ConvCfg& cfg);
+int linear_launch(const ConvDesc& d, const ConvCfg& cfg, hipStream_t stream);
 
 // ---- Winograd F(2x2,3x3) variant (conv_wino.hip) --------------------------------------------------
 #include <vector>

@@ -760,6 +760,7 @@ static size_t lds_bytes_for(const ConvDesc& d, const ConvCfg& cfg, const Geometr
 }
 
 size_t conv_lds_bytes(const ConvDesc& d, const ConvCfg& cfg) {
+  if (cfg.ALG == 5) return linear_cfg_valid(d, cfg) ? (size_t)cfg.WM * 4 * 64 * sizeof(float4) : 0;
   if (cfg.ALG == 3 || cfg.ALG == 4) return conv_wino_lds_bytes(d, cfg);
   Geometry g;
   if (!geometry(d, cfg, &g)) return 0;
@@ -771,6 +772,10 @@ ConvCfg conv_default_cfg(const ConvDesc& d) {
   const int Ho = (d.H + 2 * pad - d.ks) / d.stride + 1;
   const int Wo = (d.W + 2 * pad - d.ks) / d.stride + 1;
   const int nT16 = d.Cout / 16;
+  if (d.H == 1 && d.W == 1 && d.ks == 1 && d.Cin % 16 == 0) {   // Linear layer on B rows: latency-bound, split K
+    const int nC16 = d.Cin / 16;
+    return ConvCfg{1, 1, nC16 >= 32 ? 8 : nC16 >= 8 ? 4 : nC16 >= 2 ? 2 : 1, 1, 1, 1, 5};
+  }
   ConvCfg best{};
   double best_cost = 1e300;
   const int mts[3] = {4, 7, 13};
@@ -831,6 +836,7 @@ ConvCfg conv_default_cfg(const ConvDesc& d) {
 }
 
 int conv_launch(const ConvDesc& d, const ConvCfg& cfg, hipStream_t stream) {
+  if (cfg.ALG == 5) return linear_launch(d, cfg, stream);
   if (cfg.ALG == 3 || cfg.ALG == 4) {
     if (d.Cin % 16 || d.Cout % 16 || ((d.in_cs | d.in_co | d.out_cs | d.out_co | d.res_cs | d.res_co) & 3)) {
       poco_set_error("conv: channel counts/strides must be multiples of 16/4");

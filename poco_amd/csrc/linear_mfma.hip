@@ -1,0 +1,130 @@
+// Small-M linear layers (H = W = 1 "convs": the CLIFF regressor fc1/fc2/dec and the poco_head MLPs,
+// pocolib/models/head/cliff_head.py:104-118, head/poco_head.py:96-154) — ALG 5.
+//
+// With 32..128 crops per forward these GEMMs have M = B rows only: 0.1 GFLOP against 4..9 MB of weights, so
+// they are latency-bound, not MFMA-bound.  The implicit-GEMM conv kernel runs them as Cout/16 blocks that
+// each walk the whole K dimension serially (60..230 us); here one block still owns 16 output features, but
+// the K dimension is split over the block's waves, every wave has all of its loads in flight before the
+// first MFMA, and the partial sums meet once in LDS:  ~2 dependent memory round trips per layer.
+//
+// Operand roles as in the conv kernels: weights = MFMA A operand (packed fragment order of
+// conv_pack_weights, ks = 1), activation rows = B operand (lane (idx, g) reads x[row idx][16c + 4g .. +3]
+// as one float4), so a lane ends up with 4 consecutive output features of one row -> 16-B stores.
+#include "common.h"
+
+namespace {
+
+struct LinParams {
+  const float* in;  int in_cs, in_co;
+  const float* res; int res_cs, res_co;
+  float* out;       int out_cs, out_co;
+  const float4* wfrag;   // [Cin/16][Cout16/16][64] float4
+  const float* bias;
+  int B, nC16, nT16;
+  int act, res_after_act, relu_from;
+};
+
+constexpr int LIN_MB = 4;      // 16-row sub-tiles per block (64 rows); grid.y walks larger batches
+constexpr int LIN_UNROLL = 4;  // K slices whose loads are issued together
+
+__global__ void __launch_bounds__(1024)
+linear_mfma_kernel(const LinParams p) {
+  extern __shared__ float4 red[];          // [wave][LIN_MB][64] partial accumulators
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nwaves = blockDim.x >> 6;
+  const int idx = lane & 15, g = lane >> 4;
+  const int nt = blockIdx.x;
+  const int row0 = blockIdx.y * (LIN_MB * 16);
+
+  const float* xrow[LIN_MB];
+#pragma unroll
+  for (int m = 0; m < LIN_MB; ++m) {
+    const int r = min(row0 + m * 16 + idx, p.B - 1);               // dead rows re-read the last one
+    xrow[m] = p.in + (size_t)r * p.in_cs + p.in_co + 4 * g;
+  }
+  f32x4 acc[LIN_MB];
+#pragma unroll
+  for (int m = 0; m < LIN_MB; ++m) acc[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const float4* wl = p.wfrag + (size_t)nt * 64 + lane;
+  const size_t wstride = (size_t)p.nT16 * 64;                        // float4 per K slice
+  for (int c0 = wave; c0 < p.nC16; c0 += nwaves * LIN_UNROLL) {
+    float4 a[LIN_UNROLL], b[LIN_UNROLL][LIN_MB];
+#pragma unroll
+    for (int u = 0; u < LIN_UNROLL; ++u) {
+      const int c = min(c0 + u * nwaves, p.nC16 - 1);                // clamped duplicates are masked below
+      a[u] = wl[(size_t)c * wstride];
+#pragma unroll
+      for (int m = 0; m < LIN_MB; ++m) b[u][m] = *reinterpret_cast<const float4*>(xrow[m] + c * 16);
+    }
+#pragma unroll
+    for (int u = 0; u < LIN_UNROLL; ++u) {
+      if (c0 + u * nwaves < p.nC16) {
+        const float av[4] = {a[u].x, a[u].y, a[u].z, a[u].w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int m = 0; m < LIN_MB; ++m) {
+            const float bv = (j == 0) ? b[u][m].x : (j == 1) ? b[u][m].y : (j == 2) ? b[u][m].z : b[u][m].w;
+            acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], bv, acc[m], 0, 0, 0);
+          }
+      }
+    }
+  }
+#pragma unroll
+  for (int m = 0; m < LIN_MB; ++m)
+    red[(wave * LIN_MB + m) * 64 + lane] = make_float4(acc[m][0], acc[m][1], acc[m][2], acc[m][3]);
+  __syncthreads();
+  // wave m (m < LIN_MB) finishes sub-tile m: sum over the K-split waves in a fixed order, then the epilogue
+  for (int m = wave; m < LIN_MB; m += nwaves) {
+    float4 s = red[m * 64 + lane];
+    for (int w = 1; w < nwaves; ++w) {
+      const float4 t = red[(w * LIN_MB + m) * 64 + lane];
+      s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+    }
+    const int r = row0 + m * 16 + idx;
+    if (r >= p.B) continue;
+    const int co = nt * 16 + g * 4;
+    const float4 sh = *reinterpret_cast<const float4*>(p.bias + co);
+    float v[4] = {s.x + sh.x, s.y + sh.y, s.z + sh.z, s.w + sh.w};
+    float4 rr = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.res) rr = *reinterpret_cast<const float4*>(p.res + (size_t)r * p.res_cs + p.res_co + co);
+    if (!p.res_after_act) { v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w; }
+    if (p.act == 1 || (p.act == 3 && co >= p.relu_from)) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+    } else if (p.act == 2) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = 1.f / (1.f + __expf(-v[e]));
+    }
+    if (p.res_after_act) { v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w; }
+    *reinterpret_cast<float4*>(p.out + (size_t)r * p.out_cs + p.out_co + co) = make_float4(v[0], v[1], v[2], v[3]);
+  }
+}
+
+}  // namespace
+
+bool linear_cfg_valid(const ConvDesc& d, const ConvCfg& cfg) {
+  return d.H == 1 && d.W == 1 && d.ks == 1 && cfg.WM >= 1 && cfg.WM <= 16 && d.Cin % 16 == 0 && d.Cout % 16 == 0;
+}
+
+int linear_launch(const ConvDesc& d, const ConvCfg& cfg, hipStream_t stream) {
+  if (!linear_cfg_valid(d, cfg)) {
+    poco_set_error("linear: ALG 5 needs a 1x1 plane, ks = 1, WM (K-split waves) in 1..16");
+    return POCO_ERR_ARG;
+  }
+  LinParams p{};
+  p.in = d.in; p.in_cs = d.in_cs; p.in_co = d.in_co;
+  p.res = d.res; p.res_cs = d.res_cs; p.res_co = d.res_co;
+  p.out = d.out; p.out_cs = d.out_cs; p.out_co = d.out_co;
+  p.wfrag = reinterpret_cast<const float4*>(d.wfrag); p.bias = d.bias;
+  p.B = d.B; p.nC16 = d.Cin / 16; p.nT16 = d.Cout / 16;
+  p.act = d.act; p.res_after_act = d.res_after_act; p.relu_from = d.relu_from;
+  const int nwaves = cfg.WM;
+  const size_t lds = (size_t)nwaves * LIN_MB * 64 * sizeof(float4);
+  const dim3 grid(p.nT16, (d.B + LIN_MB * 16 - 1) / (LIN_MB * 16));
+  hipLaunchKernelGGL(linear_mfma_kernel, grid, dim3(nwaves * 64), lds, stream, p);
+  POCO_HIP_CHECK(hipGetLastError());
+  return POCO_OK;
+}

@@ -139,3 +139,25 @@ def test_conv_explicit_tiles(cfg, cuda):
     ref = _ref(x, w, None, None, 1, None, False)
     out = ops.conv2d_nhwc(torch.from_numpy(x).to(cuda), w, cfg=cfg).cpu().numpy()
     assert np.abs(out - ref).max() <= 2e-5 * np.abs(ref).max()
+
+
+LINEAR = [(64, 2224, 1024), (64, 1024, 160), (37, 176, 1024), (1, 2048, 224), (100, 3296, 512), (129, 448, 32)]
+
+
+@pytest.mark.parametrize("wm", [0, 1, 4, 8, 16])
+@pytest.mark.parametrize("case", LINEAR, ids=lambda c: "x".join(map(str, c)))
+def test_linear_small_m(case, wm, cuda):
+    """ALG 5: Linear layers (cliff_head.py:104-118, poco_head.py:96-154) as B-row GEMMs with the K dimension
+    split over the waves of a block; wm = 0 checks that the heuristic picks it for 1x1 planes."""
+    from poco_amd import ops
+    B, Cin, Cout = case
+    rng = np.random.default_rng(B * 7 + Cin)
+    x = rng.standard_normal((B, 1, 1, Cin)).astype(np.float32)
+    w = (rng.standard_normal((Cout, Cin, 1, 1)) / np.sqrt(Cin)).astype(np.float32)
+    shift = rng.uniform(-0.5, 0.5, Cout).astype(np.float32)
+    res = rng.standard_normal((B, 1, 1, Cout)).astype(np.float32)
+    ref = _ref(x, w, None, shift, 1, res, True)
+    cfg = None if wm == 0 else (1, 1, wm, 1, 1, 1, 5)
+    out = ops.conv2d_nhwc(torch.from_numpy(x).to(cuda), w, None, shift, 1, torch.from_numpy(res).to(cuda), True,
+                          cfg=cfg).cpu().numpy()
+    assert np.abs(out - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max())
