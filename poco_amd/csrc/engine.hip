@@ -1236,7 +1236,20 @@ extern "C" int poco_set_conv_cfg(poco_handle_t h, int op_index, int B, const int
     poco_set_error("poco_set_conv_cfg: bad arguments");
     return POCO_ERR_ARG;
   }
-  e->ops[op_index].cfg[B] = conv_cfg_from(cfg6);
+  // validate against this op's geometry at batch B (a table entry measured at another batch size may not fit)
+  const Op& op = e->ops[op_index];
+  const Act& ai = e->acts[op.in.act];
+  ConvDesc d{};
+  d.B = B; d.H = ai.H; d.W = ai.W; d.Cin = op.Cin; d.Cout = op.Cout; d.ks = op.ks; d.stride = op.stride;
+  d.in_cs = ai.C; d.out_cs = e->acts[op.out.act].C; d.act = op.actfn;
+  const ConvCfg c = conv_cfg_from(cfg6);
+  const size_t lds = conv_lds_bytes(d, c);
+  if (B < 1 || lds == 0 || lds > 160 * 1024 || ((c.ALG == 3 || c.ALG == 4) && (op.wdev_wino == nullptr && e->finalized)) ||
+      ((c.ALG == 3 || c.ALG == 4) && op.actfn == 3)) {
+    poco_set_error("poco_set_conv_cfg: configuration does not fit op '" + op.name + "' at this batch size");
+    return POCO_ERR_ARG;
+  }
+  e->ops[op_index].cfg[B] = c;
   return POCO_OK;
 }
 

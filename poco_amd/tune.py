@@ -13,6 +13,7 @@ import argparse
 import ctypes as C
 import itertools
 import json
+import math
 import time
 from pathlib import Path
 from typing import Dict, List, Tuple
@@ -148,16 +149,30 @@ def tune_model(model, B: int, verbose=True, skip=()) -> Dict[str, dict]:
 
 
 def apply_table(model, B: int, table=None) -> int:
+    """Set the measured configuration of every conv op for batch size B.  Without an entry for exactly B the
+    entry of the nearest tuned batch size is used if it is valid for B (tiles are per image / row band, so
+    they transfer; the library validates and the built-in heuristic stays in place otherwise)."""
+    from ._lib import PocoHipError
     table = load_table() if table is None else table
+    by_shape: Dict[str, List[Tuple[int, List[int]]]] = {}
+    for k, cfg in table.items():
+        b, rest = k.split("x", 1)
+        by_shape.setdefault(rest, []).append((int(b), cfg))
     n = 0
     for i, _ in enumerate(model.ops()):
         d = model.conv_desc(i)
         if d is None:
             continue
-        cfg = table.get(shape_key(B, *d[:6]))
-        if cfg and cfg[0] > 0:
-            model.set_conv_cfg(i, B, cfg)
-            n += 1
+        rest = shape_key(B, *d[:6]).split("x", 1)[1]
+        for b, cfg in sorted(by_shape.get(rest, []), key=lambda bc: (abs(math.log(bc[0] / B)), bc[0])):
+            if not cfg or cfg[0] <= 0:
+                continue
+            try:
+                model.set_conv_cfg(i, B, cfg)
+                n += 1
+                break
+            except PocoHipError:
+                continue
     return n
 
 

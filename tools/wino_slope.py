@@ -10,8 +10,8 @@ from poco_amd._lib import check, lib  # noqa: E402
 torch.cuda.set_device(0)
 L = lib()
 L.poco_tune_conv.argtypes = [C.c_int] * 7 + [C.POINTER(C.c_int), C.c_int, C.c_int, C.POINTER(C.c_float), C.c_void_p]
-CASES = [((64, 56, 56, 48, 3, 1), [(1, 1, 4, 3, 4, 1, 3), (1, 3, 4, 2, 4, 1, 4), (1, 3, 2, 2, 2, 1, 4), (7, 3, 4, 1, 8, 1, 1)]),
-         ((64, 14, 14, 192, 3, 1), [(1, 1, 4, 1, 14, 1, 3), (1, 3, 4, 2, 14, 1, 4), (4, 3, 4, 1, 7, 2, 2)])]
+CASES = [((64, 56, 56, 48, 3, 1), [(1, 1, 4, 3, 4, 1, 3), (1, 1, 4, 2, 4, 1, 4), (1, 2, 4, 2, 4, 1, 4), (1, 3, 4, 2, 4, 1, 4), (1, 3, 2, 2, 2, 1, 4), (7, 3, 4, 1, 8, 1, 1)]),
+         ((64, 14, 14, 192, 3, 1), [(1, 1, 4, 1, 14, 1, 3), (1, 1, 4, 2, 14, 1, 4), (1, 2, 4, 2, 14, 1, 4), (1, 3, 4, 2, 14, 1, 4), (4, 3, 4, 1, 7, 2, 2)])]
 for (B, H, W, Cout, ks, st), cfgs in CASES:
     for cfg in cfgs:
         ts = []
