@@ -408,8 +408,17 @@ conv_wino2_kernel(const WinoParams p) {
   // epilogue stores and never wait on vmcnt inside the loop, so a tile's output drains to HBM in the
   // background while the next tile's MFMAs run (on gfx9 stores and loads share the one VM counter).
   const bool dma_wave = (WINO_EXP & 64) ? true : (half == 1);
-  int t = blockIdx.x;
-  if (t >= ntiles) return;
+  // XCD-aware walk: workgroup b runs on XCD b % 8 (round-robin dispatch), so XCD x owns the contiguous tile
+  // range [x*per, (x+1)*per) and its gridDim/8 blocks stride through it: neighbouring row bands (shared halo
+  // rows) and the same tiles of consecutive layers meet in one L2 instead of eight.  dbg & 64 = plain walk.
+  int t = blockIdx.x, tstep = gridDim.x, tend = ntiles;
+  if (!(p.dbg & 64) && (gridDim.x & 7) == 0 && ntiles >= (int)gridDim.x) {
+    const int per = (ntiles + 7) >> 3;
+    t = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    tstep = gridDim.x >> 3;
+    tend = min(ntiles, ((int)(blockIdx.x & 7) + 1) * per);
+  }
+  if (t >= tend) return;
   int goff[WINO_MAXG], goffN[WINO_MAXG];
   int it0 = 0;
   if (dma_wave) {
@@ -420,9 +429,9 @@ conv_wino2_kernel(const WinoParams p) {
     if (p.nC16 > 1) issue_raw(1, it0 + 1, goff);
   }
 
-  for (; t < ntiles; t += gridDim.x) {
-    const int tn = t + gridDim.x;
-    const bool has_next = tn < ntiles;
+  for (; t < tend; t += tstep) {
+    const int tn = t + tstep;
+    const bool has_next = tn < tend;
     const int nt0 = (t / p.nblocks_m) * NT;
     // ---- this lane's tile ---------------------------------------------------------------------
     int base, oy, ox, ob;
