@@ -179,9 +179,12 @@ struct Builder {
   // Outside a parallel region every op is its own single-lane phase.
   int cur_phase = -1, cur_lane = 0;
   bool in_parallel = false;
-  void begin_parallel() { ++cur_phase; cur_lane = 0; in_parallel = true; }
+  // POCO_SEQ_PHASES (bit mask, experiments): run the tagged kind of parallel region on one lane
+  int seq_mask = [] { const char* v = getenv("POCO_SEQ_PHASES"); return v ? atoi(v) : 0; }();
+  bool region_seq = false;
+  void begin_parallel(int kind = 0) { ++cur_phase; cur_lane = 0; in_parallel = true; region_seq = (seq_mask >> kind) & 1; }
   void end_parallel() { in_parallel = false; }
-  void lane(int k) { cur_lane = k % 4; }
+  void lane(int k) { cur_lane = region_seq ? 0 : k % 4; }
   void push(Op&& op) {
     if (!in_parallel) { ++cur_phase; cur_lane = 0; }
     op.phase = cur_phase;
@@ -371,9 +374,10 @@ struct Builder {
   std::vector<int> hr_module(const std::string& p, std::vector<int> xs, const std::vector<int>& ch, Ref out0 = Ref()) {
     const int nb = (int)xs.size();
     // phase 1: the branches are independent chains of 8 convs -> one lane (HIP stream) each
-    begin_parallel();
+    begin_parallel(1);
+    static const std::string lmap = [] { const char* v = getenv("POCO_BRANCH_LANES"); return std::string(v ? v : "0123"); }();
     for (int i = 0; i < nb; ++i) {
-      lane(i);
+      lane(i < (int)lmap.size() ? lmap[i] - '0' : i);
       for (int k = 0; k < 4; ++k) xs[i] = basic_block(p + ".branches." + std::to_string(i) + "." + std::to_string(k), xs[i], ch[i]);
     }
     end_parallel();
@@ -384,7 +388,7 @@ struct Builder {
     std::vector<std::vector<Ref>> chain(nb, std::vector<Ref>(nb));   // [i][j]: running tensor of down path j -> i
     for (int i = 0; i < nb; ++i) terms[i].resize(nb);
     auto fl = [&](int i, int j) { return p + ".fuse_layers." + std::to_string(i) + "." + std::to_string(j); };
-    begin_parallel();
+    begin_parallel(2);
     int rr = 0;
     for (int j = 0; j < nb; ++j) {
       if (j > 0) {                       // up paths: 1x1 conv + BN (hrnet.py:196-207), upsampled inside the sum
@@ -409,7 +413,7 @@ struct Builder {
     }
     end_parallel();
     // phase 2b: the rest of the down chains (different inputs -> separate launches), one lane per chain
-    begin_parallel();
+    begin_parallel(3);
     rr = 0;
     for (int i = 0; i < nb; ++i)
       for (int j = 0; j < i; ++j) {
@@ -426,7 +430,7 @@ struct Builder {
     end_parallel();
     // phase 3: the sums (+ReLU), one lane per output branch
     std::vector<int> outs(nb);
-    begin_parallel();
+    begin_parallel(4);
     for (int i = 0; i < nb; ++i) {
       lane(i);
       const Act a = e.acts[xs[i]];
@@ -452,7 +456,10 @@ struct Builder {
       for (int i = 0; i < nb; ++i) ch[i] = w << i;
       const std::string t = p + "transition" + std::to_string(s + 1);
       std::vector<int> xs(nb);
-      begin_parallel();
+      // the transition convs are few and large (each fills the chip on its own): measured faster back to back
+      // on one stream than as concurrent lanes (19.0-19.2 vs 19.35 ms per 64-crop forward)
+      begin_parallel(5);
+      region_seq = !((seq_mask >> 6) & 1);
       for (int i = 0; i < nb; ++i) {
         lane(i);
         const std::string ti = t + "." + std::to_string(i);

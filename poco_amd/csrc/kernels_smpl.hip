@@ -4,7 +4,7 @@
 // smplcam_head.py:48-53; algorithm: SURVEY.md 3.5) as three batched small-matrix kernels:
 //   1. smpl_chain_kernel   : J(betas), 24-joint kinematic chain of 3x4 affines, A_i = G_i * [I|-J_i]
 //   2. smpl_skin_kernel    : per vertex: shape blend (10), pose blend (207), skinning (24x12), apply.
-//                            A block owns 256 vertices x CB crops so posedirs (17 MB, the only large
+//                            A block owns SKIN_T vertices x CB crops so posedirs (17 MB, the only large
 //                            operand) is streamed once per CB crops with 12-byte coalesced reads.
 //   3. smpl_joints_kernel  : 9 regressed extra joints (block reduction over 6890 vertices), 21 vertex
 //                            picks, 49-joint gather (smpl_head.py:25-27).
@@ -13,67 +13,64 @@
 
 namespace {
 
-constexpr int CB = 8;   // crops per skinning block
+constexpr int CB = 8;    // crops per skinning block (posedirs is re-read once per CB crops)
+constexpr int SKIN_T = 256;  // vertices (threads) per skinning block
 
-__global__ void __launch_bounds__(128)
+// One wave per crop.  The chain is serial over the 24 joints (each needs its parent), but the 12 entries of a
+// joint's 3x4 affine are independent: lanes 0..11 compute one entry each from LDS, one barrier per joint.
+__global__ void __launch_bounds__(64)
 smpl_chain_kernel(SmplDev m, SmplIO io, int B) {
   __shared__ float J[24][3];
   __shared__ float R[24][9];
+  __shared__ float G[24][12];   // row-major 3x4 world transforms
   const int b = blockIdx.x, t = threadIdx.x;
   const float* betas = io.betas + (size_t)b * io.betas_stride;
-  if (t < 72) {
-    float acc = m.J_template[t];
-    for (int l = 0; l < 10; ++l) acc = fmaf(m.J_shapedirs[t * 10 + l], betas[l], acc);
-    J[t / 3][t % 3] = acc;
+  for (int i = t; i < 72; i += 64) {
+    float acc = m.J_template[i];
+    for (int l = 0; l < 10; ++l) acc = fmaf(m.J_shapedirs[i * 10 + l], betas[l], acc);
+    J[i / 3][i % 3] = acc;
   }
-  for (int i = t; i < 216; i += 128) R[i / 9][i % 9] = io.rotmat[(size_t)b * io.rot_stride + i];
+  for (int i = t; i < 216; i += 64) R[i / 9][i % 9] = io.rotmat[(size_t)b * io.rot_stride + i];
   __syncthreads();
-  if (t == 0) {
-    float G[24][12];   // row-major 3x4
-    for (int i = 0; i < 24; ++i) {
-      const int p = m.parents[i];
-      float T[12];
-      for (int r = 0; r < 3; ++r) {
-        T[r * 4 + 0] = R[i][r * 3 + 0]; T[r * 4 + 1] = R[i][r * 3 + 1]; T[r * 4 + 2] = R[i][r * 3 + 2];
-        T[r * 4 + 3] = (i == 0) ? J[0][r] : J[i][r] - J[p][r];
+  const int r = t >> 2, c = t & 3;          // entry (r, c) of the 3x4 affine, lanes 0..11
+  for (int i = 0; i < 24; ++i) {
+    const int p = m.parents[i];
+    if (t < 12) {
+      // local transform T_i = [R_i | J_i - J_parent]
+      auto T = [&](int rr, int cc) { return cc < 3 ? R[i][rr * 3 + cc] : (i == 0 ? J[0][rr] : J[i][rr] - J[p][rr]); };
+      float v;
+      if (i == 0) v = T(r, c);
+      else {
+        v = G[p][r * 4 + 0] * T(0, c) + G[p][r * 4 + 1] * T(1, c) + G[p][r * 4 + 2] * T(2, c);
+        if (c == 3) v += G[p][r * 4 + 3];
       }
-      if (i == 0) {
-        for (int k = 0; k < 12; ++k) G[0][k] = T[k];
-      } else {
-        for (int r = 0; r < 3; ++r) {
-          for (int c = 0; c < 4; ++c) {
-            float v = G[p][r * 4 + 0] * T[0 * 4 + c] + G[p][r * 4 + 1] * T[1 * 4 + c] + G[p][r * 4 + 2] * T[2 * 4 + c];
-            if (c == 3) v += G[p][r * 4 + 3];
-            G[i][r * 4 + c] = v;
-          }
-        }
-      }
+      G[i][t] = v;
     }
-    float* A = io.A + (size_t)b * 288;
-    float* j24 = io.joints24 + (size_t)b * 72;
-    for (int i = 0; i < 24; ++i) {
-      for (int r = 0; r < 3; ++r) {
-        const float gj = G[i][r * 4 + 0] * J[i][0] + G[i][r * 4 + 1] * J[i][1] + G[i][r * 4 + 2] * J[i][2];
-        A[i * 12 + r * 4 + 0] = G[i][r * 4 + 0];
-        A[i * 12 + r * 4 + 1] = G[i][r * 4 + 1];
-        A[i * 12 + r * 4 + 2] = G[i][r * 4 + 2];
-        A[i * 12 + r * 4 + 3] = G[i][r * 4 + 3] - gj;
-        j24[i * 3 + r] = G[i][r * 4 + 3];
-      }
+    __syncthreads();
+  }
+  float* A = io.A + (size_t)b * 288;
+  float* j24 = io.joints24 + (size_t)b * 72;
+  for (int k = t; k < 288; k += 64) {
+    const int i = k / 12, e = k % 12, rr = e >> 2, cc = e & 3;
+    float v = G[i][e];
+    if (cc == 3) {
+      v -= G[i][rr * 4 + 0] * J[i][0] + G[i][rr * 4 + 1] * J[i][1] + G[i][rr * 4 + 2] * J[i][2];
+      j24[i * 3 + rr] = G[i][e];
     }
+    A[k] = v;
   }
 }
 
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(SKIN_T)
 smpl_skin_kernel(SmplDev m, SmplIO io, int B) {
   __shared__ float pf[CB][208];
   __shared__ float bt[CB][12];
-  __shared__ float As[CB][288];
+  __shared__ __attribute__((aligned(16))) float As[CB][288];
   const int tid = threadIdx.x;
-  const int v = blockIdx.x * 256 + tid;
+  const int v = blockIdx.x * SKIN_T + tid;
   const int b0 = blockIdx.y * CB;
   const int nb = min(CB, B - b0);
-  for (int i = tid; i < CB * 207; i += 256) {
+  for (int i = tid; i < CB * 207; i += SKIN_T) {
     const int cb = i / 207, k = i % 207;
     float val = 0.f;
     if (cb < nb) {
@@ -82,11 +79,11 @@ smpl_skin_kernel(SmplDev m, SmplIO io, int B) {
     }
     pf[cb][k] = val;
   }
-  for (int i = tid; i < CB * 10; i += 256) {
+  for (int i = tid; i < CB * 10; i += SKIN_T) {
     const int cb = i / 10, l = i % 10;
     bt[cb][l] = (cb < nb) ? io.betas[(size_t)(b0 + cb) * io.betas_stride + l] : 0.f;
   }
-  for (int i = tid; i < CB * 288; i += 256) {
+  for (int i = tid; i < CB * 288; i += SKIN_T) {
     const int cb = i / 288, k = i % 288;
     As[cb][k] = (cb < nb) ? io.A[(size_t)(b0 + cb) * 288 + k] : 0.f;
   }
@@ -112,14 +109,22 @@ smpl_skin_kernel(SmplDev m, SmplIO io, int B) {
   float po[CB][3];
 #pragma unroll
   for (int cb = 0; cb < CB; ++cb) po[cb][0] = po[cb][1] = po[cb][2] = 0.f;
-#pragma unroll 3
-  for (int k = 0; k < 207; ++k) {
-    const float* pd = m.posedirs + (size_t)k * V3 + v * 3;
-    const float d0 = pd[0], d1 = pd[1], d2 = pd[2];
+  // 207 = 9 x 23: the 23 row loads of a chunk are issued together (the loop is latency-bound: < 1 wave per SIMD)
+#pragma unroll 1
+  for (int k0 = 0; k0 < 207; k0 += 23) {
+    float d[23][3];
 #pragma unroll
-    for (int cb = 0; cb < CB; ++cb) {
-      const float f = pf[cb][k];
-      po[cb][0] = fmaf(f, d0, po[cb][0]); po[cb][1] = fmaf(f, d1, po[cb][1]); po[cb][2] = fmaf(f, d2, po[cb][2]);
+    for (int u = 0; u < 23; ++u) {
+      const float* pd = m.posedirs + (size_t)(k0 + u) * V3 + v * 3;
+      d[u][0] = pd[0]; d[u][1] = pd[1]; d[u][2] = pd[2];
+    }
+#pragma unroll
+    for (int u = 0; u < 23; ++u) {
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb) {
+        const float f = pf[cb][k0 + u];
+        po[cb][0] = fmaf(f, d[u][0], po[cb][0]); po[cb][1] = fmaf(f, d[u][1], po[cb][1]); po[cb][2] = fmaf(f, d[u][2], po[cb][2]);
+      }
     }
   }
   float w[24];
@@ -131,35 +136,42 @@ smpl_skin_kernel(SmplDev m, SmplIO io, int B) {
       w[q * 4] = t.x; w[q * 4 + 1] = t.y; w[q * 4 + 2] = t.z; w[q * 4 + 3] = t.w;
     }
   }
-#pragma unroll 1
-  for (int cb = 0; cb < nb; ++cb) {
+#pragma unroll     // fully unrolled (vp/po stay in registers); the tail of a ragged last block is predicated
+  for (int cb = 0; cb < CB; ++cb) {
+    if (cb < nb) {
     float T[12];
 #pragma unroll
     for (int k = 0; k < 12; ++k) T[k] = 0.f;
 #pragma unroll
     for (int j = 0; j < 24; ++j) {
       const float wj = w[j];
+      const float4* a4 = reinterpret_cast<const float4*>(&As[cb][j * 12]);
 #pragma unroll
-      for (int k = 0; k < 12; ++k) T[k] = fmaf(wj, As[cb][j * 12 + k], T[k]);
+      for (int q = 0; q < 3; ++q) {
+        const float4 a = a4[q];
+        T[q * 4] = fmaf(wj, a.x, T[q * 4]); T[q * 4 + 1] = fmaf(wj, a.y, T[q * 4 + 1]);
+        T[q * 4 + 2] = fmaf(wj, a.z, T[q * 4 + 2]); T[q * 4 + 3] = fmaf(wj, a.w, T[q * 4 + 3]);
+      }
     }
     const float x = vp[cb][0] + po[cb][0], y = vp[cb][1] + po[cb][1], z = vp[cb][2] + po[cb][2];
     float* o = io.verts + ((size_t)(b0 + cb) * m.V + v) * 3;
     o[0] = T[0] * x + T[1] * y + T[2] * z + T[3];
     o[1] = T[4] * x + T[5] * y + T[6] * z + T[7];
     o[2] = T[8] * x + T[9] * y + T[10] * z + T[11];
+    }
   }
 }
 
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(1024)
 smpl_joints_kernel(SmplDev m, SmplIO io, int B) {
-  __shared__ float red[4][27];
+  __shared__ float red[16][27];
   __shared__ float extra[27];
   const int b = blockIdx.x, tid = threadIdx.x;
   const float* vb = io.verts + (size_t)b * m.V * 3;
   float acc[27];
 #pragma unroll
   for (int k = 0; k < 27; ++k) acc[k] = 0.f;
-  for (int v = tid; v < m.V; v += 256) {
+  for (int v = tid; v < m.V; v += 1024) {
     const float x = vb[v * 3], y = vb[v * 3 + 1], z = vb[v * 3 + 2];
 #pragma unroll
     for (int j = 0; j < 9; ++j) {
@@ -175,7 +187,11 @@ smpl_joints_kernel(SmplDev m, SmplIO io, int B) {
     if ((tid & 63) == 0) red[tid >> 6][k] = v;
   }
   __syncthreads();
-  if (tid < 27) extra[tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+  if (tid < 27) {
+    float s = 0.f;
+    for (int w = 0; w < 16; ++w) s += red[w][tid];
+    extra[tid] = s;
+  }
   __syncthreads();
   if (tid < 49 * 3) {
     const int t = tid / 3, k = tid % 3;
@@ -226,9 +242,9 @@ __global__ void camera_kernel(CamArgs a, int B) {
 }  // namespace
 
 void launch_smpl_lbs(const SmplDev& m, const SmplIO& io, int B, hipStream_t s) {
-  hipLaunchKernelGGL(smpl_chain_kernel, dim3(B), dim3(128), 0, s, m, io, B);
-  hipLaunchKernelGGL(smpl_skin_kernel, dim3((m.V + 255) / 256, (B + CB - 1) / CB), dim3(256), 0, s, m, io, B);
-  hipLaunchKernelGGL(smpl_joints_kernel, dim3(B), dim3(256), 0, s, m, io, B);
+  hipLaunchKernelGGL(smpl_chain_kernel, dim3(B), dim3(64), 0, s, m, io, B);
+  hipLaunchKernelGGL(smpl_skin_kernel, dim3((m.V + SKIN_T - 1) / SKIN_T, (B + CB - 1) / CB), dim3(SKIN_T), 0, s, m, io, B);
+  hipLaunchKernelGGL(smpl_joints_kernel, dim3(B), dim3(1024), 0, s, m, io, B);
 }
 
 void launch_camera(const CamArgs& a, int B, hipStream_t s) {
