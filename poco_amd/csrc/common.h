@@ -44,8 +44,15 @@ struct ConvCfg {
 constexpr int CONV_CFG_INTS = 7;   // ints per configuration in the C ABI / tuning table
 inline ConvCfg conv_cfg_from(const int* c) { return ConvCfg{c[0], c[1], c[2], c[3], c[4], c[5], c[6]}; }
 
+// Activation layout ("L16", channel-slice-major NHWC): element (b, y, x, c) of a buffer with C channels lives at
+//   ((b*H + y) * (C/16) + c/16) * (W*16) + x*16 + c%16
+// i.e. a 16-channel slice of an image row is one contiguous run of W*64 bytes, so the per-slice halo-patch
+// fetches of the conv kernels read whole cache lines.  For vectors (H = W = 1) this is plain [B][C].
+// Channel offset `co` of a slice inside a wider buffer -> float offset (co/16)*W*16 + co%16.
+inline size_t l16_chan_off(int co, int W) { return (size_t)(co >> 4) * W * 16 + (co & 15); }
+
 struct ConvDesc {
-  // activations: NHWC, each buffer may be a channel slice of a wider buffer
+  // activations: L16 (see above), each buffer may be a channel slice of a wider buffer
   const float* in;  int in_cs,  in_co;    // channel stride (channels per pixel of the buffer), offset
   const float* res; int res_cs, res_co;   // optional residual (same spatial shape as the output)
   float*       out; int out_cs, out_co;

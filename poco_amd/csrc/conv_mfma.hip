@@ -47,7 +47,8 @@ struct ConvKParams {
   float* out;
   const float4* wfrag;
   const float* bias;
-  int in_cs, in_co, res_cs, res_co, out_cs, out_co;
+  int in_rs, in_ss;      // input: floats per image row (C*W) and per 16-channel slice of a row (W*16)
+  int res_rs, out_rs, out_ss;   // output / residual: row stride (C*Wo), slice stride (Wo*16); slice offsets folded into the pointers
   int H, W, Ho, Wo;
   int nC16;    // Cin / 16
   int nT16;    // Cout16 / 16
@@ -78,11 +79,20 @@ __device__ __forceinline__ void conv_store_tile_impl(const ConvKParams& p, f32x4
                                                      const int (&oo)[MT]) {
   // residual loads are unconditional (dead lanes read pixel 0) so that hipcc can count them: a load under
   // a branch makes it fall back to s_waitcnt vmcnt(0) before every store
+  // L16 offsets of this lane's pixels: row*rs + x*16 = pix*16 + row*(rs - 16*Wo)
+  int ob[MT], rb[HAS_RES ? MT : 1];   // ob < 0: dead lane
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    const uint32_t pix = (uint32_t)max(oo[m], 0);
+    const uint32_t row = fdiv(pix, p.dWo);
+    ob[m] = oo[m] >= 0 ? (int)(pix * 16u + row * (uint32_t)(p.out_rs - 16 * p.Wo)) : -1;
+    if constexpr (HAS_RES) rb[m] = (int)(pix * 16u + row * (uint32_t)(p.res_rs - 16 * p.Wo));
+  }
   auto load_res = [&](int n, float4* r) {
-    const int co = (min(nt0 + n, p.nT16 - 1)) * 16 + g * 4;
+    const int co = (min(nt0 + n, p.nT16 - 1)) * p.out_ss + g * 4;
 #pragma unroll
     for (int m = 0; m < MT; ++m)
-      r[m] = *reinterpret_cast<const float4*>(p.res + (size_t)max(oo[m], 0) * p.res_cs + p.res_co + co);
+      r[m] = *reinterpret_cast<const float4*>(p.res + rb[m] + co);
   };
   float4 sh[NT];
 #pragma unroll
@@ -113,8 +123,8 @@ __device__ __forceinline__ void conv_store_tile_impl(const ConvKParams& p, f32x4
         for (int e = 0; e < 4; ++e) v[e] = 1.f / (1.f + __expf(-v[e]));
       }
       if (p.res_after_act) { v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w; }
-      if (nok && oo[m] >= 0)
-        *reinterpret_cast<float4*>(p.out + (size_t)oo[m] * p.out_cs + p.out_co + co) = make_float4(v[0], v[1], v[2], v[3]);
+      if (nok && ob[m] >= 0)
+        *reinterpret_cast<float4*>(p.out + ob[m] + (nt0 + n) * p.out_ss + g * 4) = make_float4(v[0], v[1], v[2], v[3]);
     }
     if constexpr (HAS_RES && PIPE) {
 #pragma unroll
@@ -199,7 +209,7 @@ conv_mfma_kernel(const ConvKParams p) {
         const int ix = (int)pcol - PAD;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (s < (uint32_t)p.S && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) {
-          const size_t off = ((size_t)(b * p.H + iy) * p.W + ix) * p.in_cs + p.in_co + c * 16 + q * 4;
+          const size_t off = (size_t)(b * p.H + iy) * p.in_rs + (size_t)c * p.in_ss + ix * 16 + q * 4;
           v = *reinterpret_cast<const float4*>(p.in + off);
         }
         patch[q * p.planeF4 + pos] = v;
@@ -329,7 +339,7 @@ conv_dma_kernel(const ConvKParams p) {
       const int iy = (int)(band * p.R) * STRIDE - PAD + (int)prow;
       const int ix = (int)pcol - PAD;
       if (s < (uint32_t)p.S && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
-        goff[k] = (int)(((size_t)(b * p.H + iy) * p.W + ix) * p.in_cs + p.in_co);
+        goff[k] = (int)((size_t)(b * p.H + iy) * p.in_rs + ix * 16);
     }
   }
 
@@ -342,7 +352,7 @@ conv_dma_kernel(const ConvKParams p) {
     for (int k = 0; k < DMA_MAXG; ++k) {
       const int grp = wave + k * nwaves;
       if (grp < p.ngroups) {
-        const float* src0 = p.in + goff[k] + c * 16;
+        const float* src0 = p.in + goff[k] + c * p.in_ss;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const void* src = (goff[k] >= 0) ? (const void*)(src0 + q * 4) : (const void*)&g_zero_page;
@@ -529,7 +539,7 @@ conv_dma_persist_kernel(const ConvKParams p) {
         const int iy = (int)(band * p.R) * STRIDE - PAD + (int)prow;
         const int ix = (int)pcol - PAD;
         if (s < (uint32_t)p.S && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
-          go[k] = (int)(((size_t)(b * p.H + iy) * p.W + ix) * p.in_cs + p.in_co);
+          go[k] = (int)((size_t)(b * p.H + iy) * p.in_rs + ix * 16);
       }
     }
   };
@@ -539,7 +549,7 @@ conv_dma_persist_kernel(const ConvKParams p) {
     for (int k = 0; k < DMA_MAXG; ++k) {
       const int grp = wave + k * nwaves;
       if (grp < p.ngroups) {
-        const float* src0 = p.in + go[k] + c * 16;
+        const float* src0 = p.in + go[k] + c * p.in_ss;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const void* src = (go[k] >= 0) ? (const void*)(src0 + q * 4) : (const void*)&g_zero_page;
@@ -885,12 +895,13 @@ int conv_launch(const ConvDesc& d, const ConvCfg& cfg, hipStream_t stream) {
     return POCO_ERR_ARG;
   }
   ConvKParams kp;
-  kp.in = d.in; kp.res = d.res; kp.out = d.out;
+  kp.in = d.in + l16_chan_off(d.in_co, d.W);
+  kp.res = d.res ? d.res + l16_chan_off(d.res_co, g.Wo) : nullptr;
+  kp.out = d.out + l16_chan_off(d.out_co, g.Wo);
   kp.wfrag = reinterpret_cast<const float4*>(d.wfrag);
   kp.bias = d.bias;
-  kp.in_cs = d.in_cs; kp.in_co = d.in_co;
-  kp.res_cs = d.res_cs; kp.res_co = d.res_co;
-  kp.out_cs = d.out_cs; kp.out_co = d.out_co;
+  kp.in_rs = d.in_cs * d.W; kp.in_ss = d.W * 16;
+  kp.res_rs = d.res_cs * g.Wo; kp.out_rs = d.out_cs * g.Wo; kp.out_ss = g.Wo * 16;
   kp.H = d.H; kp.W = d.W; kp.Ho = g.Ho; kp.Wo = g.Wo;
   kp.nC16 = d.Cin / 16; kp.nT16 = d.Cout / 16;
   kp.R = cfg.R; kp.NI = cfg.NI; kp.S = g.S;

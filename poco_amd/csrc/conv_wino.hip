@@ -68,7 +68,7 @@ struct WinoParams {
   float* out;
   const float4* ufrag;   // [16][Cin/16][Cout16/16][64] float4
   const float* bias;
-  int in_cs, in_co, res_cs, res_co, out_cs, out_co;
+  int in_rs, in_ss, res_rs, out_rs, out_ss;   // L16 strides (floats): image row (C*W), 16-channel slice of a row (W*16)
   int H, W;              // == Ho, Wo
   int nC16, nT16;
   int R, NI, S;          // output rows per slab (even), slabs per block, total slabs
@@ -93,13 +93,14 @@ __device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4
 template <int NT, bool HAS_RES>
 __device__ __forceinline__ void wino_store_impl(const WinoParams& p, f32x4 (&v)[NT][4], int nt0, int g, int ob, int oy,
                                                 int ox) {
-  size_t opix[4];
+  int orow[4], ocol[4];      // image row (b*H + y) and 16*x of the lane's 2x2 output pixels
   bool ok[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const int yy = oy + (k >> 1), xx = ox + (k & 1);
     ok[k] = (ob >= 0) && yy < p.H && xx < p.W;
-    opix[k] = ok[k] ? ((size_t)ob * p.H + yy) * p.W + xx : 0;
+    orow[k] = ok[k] ? ob * p.H + yy : 0;
+    ocol[k] = ok[k] ? xx * 16 : 0;
   }
   float4 sh[NT];
 #pragma unroll
@@ -110,7 +111,7 @@ __device__ __forceinline__ void wino_store_impl(const WinoParams& p, f32x4 (&v)[
     for (int n = 0; n < NT; ++n)
 #pragma unroll
       for (int k = 0; k < 4; ++k)
-        rr[n][k] = *reinterpret_cast<const float4*>(p.res + opix[k] * p.res_cs + p.res_co + min(nt0 + n, p.nT16 - 1) * 16 + g * 4);
+        rr[n][k] = *reinterpret_cast<const float4*>(p.res + (size_t)orow[k] * p.res_rs + ocol[k] + min(nt0 + n, p.nT16 - 1) * p.out_ss + g * 4);
   }
 #pragma unroll
   for (int n = 0; n < NT; ++n) {
@@ -131,7 +132,7 @@ __device__ __forceinline__ void wino_store_impl(const WinoParams& p, f32x4 (&v)[
       }
       if (p.res_after_act) { v4[0] += r.x; v4[1] += r.y; v4[2] += r.z; v4[3] += r.w; }
       if (nok && ok[k])
-        *reinterpret_cast<float4*>(p.out + opix[k] * p.out_cs + p.out_co + co) = make_float4(v4[0], v4[1], v4[2], v4[3]);
+        *reinterpret_cast<float4*>(p.out + (size_t)orow[k] * p.out_rs + ocol[k] + (nt0 + n) * p.out_ss + g * 4) = make_float4(v4[0], v4[1], v4[2], v4[3]);
     }
   }
 }
@@ -195,7 +196,7 @@ conv_wino_kernel(const WinoParams p) {
       const int iy = (int)(band * p.R) - 1 + (int)prow;
       const int ix = (int)pcol - 1;
       if (s < (uint32_t)p.S && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
-        goff[k] = (int)(((size_t)(b * p.H + iy) * p.W + ix) * p.in_cs + p.in_co);
+        goff[k] = (int)((size_t)(b * p.H + iy) * p.in_rs + ix * 16);
     }
   }
   const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) float4*)smem;
@@ -206,7 +207,7 @@ conv_wino_kernel(const WinoParams p) {
     for (int k = 0; k < WINO_MAXG; ++k) {
       const int grp = wave + k * nwaves;
       if (grp < p.ngroups) {
-        const float* src0 = (goff[k] >= 0) ? p.in + goff[k] + c * 16 : (const float*)g_zero_page_w;
+        const float* src0 = (goff[k] >= 0) ? p.in + goff[k] + c * p.in_ss : (const float*)g_zero_page_w;
 #pragma unroll
         for (int q = 0; q < 4; ++q)
           lds_dma16(src0 + q * 4, (unsigned)__builtin_amdgcn_readfirstlane((int)(lds_base + (unsigned)(q * p.planeF4 + grp * 64) * 16u)));
@@ -370,7 +371,7 @@ conv_wino2_kernel(const WinoParams p) {
         const int iy = (int)(band * p.R) - 1 + (int)prow;
         const int ix = (int)pcol - 1;
         if (s < (uint32_t)p.S && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
-          go[k] = (int)(((size_t)(b * p.H + iy) * p.W + ix) * p.in_cs + p.in_co);
+          go[k] = (int)((size_t)(b * p.H + iy) * p.in_rs + ix * 16);
       }
     }
   };
@@ -380,7 +381,7 @@ conv_wino2_kernel(const WinoParams p) {
     for (int k = 0; k < WINO_MAXG; ++k) {
       const int grp = dw + k * dn;
       if (grp < p.ngroups) {
-        const float* src0 = (go[k] >= 0) ? p.in + go[k] + c * 16 : (const float*)g_zero_page_w;
+        const float* src0 = (go[k] >= 0) ? p.in + go[k] + c * p.in_ss : (const float*)g_zero_page_w;
 #pragma unroll
         for (int q = 0; q < 4; ++q)
           lds_dma16(src0 + q * 4, (unsigned)__builtin_amdgcn_readfirstlane((int)(rb + (unsigned)(q * p.planeF4 + grp * 64) * 16u)));
@@ -651,8 +652,9 @@ int conv_wino_launch(const ConvDesc& d, const ConvCfg& cfg, hipStream_t stream) 
     const size_t lds4 = conv_wino_lds_bytes(d, cfg);
     if (lds4 > 160 * 1024 || (size_t)cfg.WM * cfg.NT * 4 * 64 > (size_t)2 * 16 * cfg.NT * 64) { poco_set_error("conv(winograd/half): LDS budget exceeded"); return POCO_ERR_ARG; }
     WinoParams p;
-    p.in = d.in; p.res = d.res; p.out = d.out; p.ufrag = reinterpret_cast<const float4*>(d.wfrag_wino); p.bias = d.bias;
-    p.in_cs = d.in_cs; p.in_co = d.in_co; p.res_cs = d.res_cs; p.res_co = d.res_co; p.out_cs = d.out_cs; p.out_co = d.out_co;
+    p.in = d.in + l16_chan_off(d.in_co, d.W); p.res = d.res ? d.res + l16_chan_off(d.res_co, d.W) : nullptr; p.out = d.out + l16_chan_off(d.out_co, d.W);
+    p.ufrag = reinterpret_cast<const float4*>(d.wfrag_wino); p.bias = d.bias;
+    p.in_rs = d.in_cs * d.W; p.in_ss = d.W * 16; p.res_rs = d.res_cs * d.W; p.out_rs = d.out_cs * d.W; p.out_ss = d.W * 16;
     p.H = d.H; p.W = d.W; p.nC16 = d.Cin / 16; p.nT16 = d.Cout / 16;
     p.R = cfg.R; p.NI = cfg.NI; p.S = g.S; p.TX = g.TX; p.PR = g.PR; p.PW = g.PW; p.npos = g.npos; p.planeF4 = g.planeF4;
     p.ngroups = g.planeF4 / 64;
@@ -689,8 +691,9 @@ int conv_wino_launch(const ConvDesc& d, const ConvCfg& cfg, hipStream_t stream) 
   const size_t lds = conv_wino_lds_bytes(d, cfg);
   if (lds > 160 * 1024) { poco_set_error("conv(winograd): LDS budget exceeded"); return POCO_ERR_ARG; }
   WinoParams p;
-  p.in = d.in; p.res = d.res; p.out = d.out; p.ufrag = reinterpret_cast<const float4*>(d.wfrag_wino); p.bias = d.bias;
-  p.in_cs = d.in_cs; p.in_co = d.in_co; p.res_cs = d.res_cs; p.res_co = d.res_co; p.out_cs = d.out_cs; p.out_co = d.out_co;
+  p.in = d.in + l16_chan_off(d.in_co, d.W); p.res = d.res ? d.res + l16_chan_off(d.res_co, d.W) : nullptr; p.out = d.out + l16_chan_off(d.out_co, d.W);
+    p.ufrag = reinterpret_cast<const float4*>(d.wfrag_wino); p.bias = d.bias;
+  p.in_rs = d.in_cs * d.W; p.in_ss = d.W * 16; p.res_rs = d.res_cs * d.W; p.out_rs = d.out_cs * d.W; p.out_ss = d.W * 16;
   p.H = d.H; p.W = d.W; p.nC16 = d.Cin / 16; p.nT16 = d.Cout / 16;
   p.R = cfg.R; p.NI = cfg.NI; p.S = g.S; p.TX = g.TX; p.PR = g.PR; p.PW = g.PW; p.npos = g.npos; p.planeF4 = g.planeF4;
   p.ngroups = g.planeF4 / 64;

@@ -923,7 +923,11 @@ float* ext_out(const IO& io, int slot) {
 }
 
 // e.b0 = first crop of the sub-batch being enqueued (batch-split execution)
-inline float* aptr(Engine& e, const Ref& r) { const Act& a = e.acts[r.act]; return e.ws + a.off + (size_t)e.b0 * a.per_crop() + r.co; }
+// activations are L16 (common.h): a channel offset inside a wider buffer is a slice-row offset
+inline float* aptr(Engine& e, const Ref& r) {
+  const Act& a = e.acts[r.act];
+  return e.ws + a.off + (size_t)e.b0 * a.per_crop() + l16_chan_off(r.co, a.W);
+}
 inline float* sptr(Engine& e, int act) { const Act& a = e.acts[act]; return e.ws + a.off + (size_t)e.b0 * a.per_crop(); }
 inline int astride(Engine& e, const Ref& r) { return e.acts[r.act].C; }   // valid for vector acts (H=W=1)
 
@@ -975,14 +979,14 @@ int run_op(Engine& e, Op& op, int B, const IO& io, hipStream_t s) {
     }
     case OP_AVGPOOL: {
       const Act& a = e.acts[op.in.act];
-      launch_avgpool(aptr(e, op.in), aptr(e, op.out), B, a.H * a.W, a.C, astride(e, op.out), s);
+      launch_avgpool(aptr(e, op.in), aptr(e, op.out), B, a.H, a.W, a.C, astride(e, op.out), s);
       return POCO_OK;
     }
     case OP_ATTN: {
       const Act& ah = e.acts[op.in.act];
       // scratch act was sized for one crop of C=128; its buffer is max_batch x that
       launch_part_attention_pool_ws(aptr(e, op.in), ah.C, aptr(e, op.in2), op.C, aptr(e, op.out), astride(e, op.out), B,
-                                    ah.H * ah.W, sptr(e, e.a_attn_scratch), s);
+                                    ah.H, ah.W, sptr(e, e.a_attn_scratch), s);
       return POCO_OK;
     }
     case OP_LC2D:
@@ -1040,7 +1044,7 @@ int run_op(Engine& e, Op& op, int B, const IO& io, hipStream_t s) {
       float* y = ext_out(io, op.out.ext);
       if (!y) return POCO_OK;
       const Act& a = e.acts[op.in.act];
-      launch_nhwc_to_nchw(aptr(e, op.in), a.C, y, B, a.H * a.W, op.C, s);
+      launch_nhwc_to_nchw(aptr(e, op.in), a.C, y, B, a.H, a.W, op.C, s);
       return POCO_OK;
     }
   }

@@ -1,5 +1,8 @@
 // Launchers of the non-GEMM kernels (all enqueue on `stream`, no allocation, no sync).
 #pragma once
+// float4 index of (row = b*H + y, x, channel quad c4) in the L16 activation layout (csrc/common.h): a buffer of
+// C channels has C/16 slice rows of W*16 floats per image row.  Usable from host and device code.
+#define L16_F4(row, x, c4, W, C16) ((((size_t)(row) * (C16)) + ((c4) >> 2)) * (size_t)(W) * 4 + (size_t)(x) * 4 + ((c4) & 3))
 #include "common.h"
 
 // ---- backbone side kernels (kernels_misc.hip) ---------------------------------------------------
@@ -22,7 +25,7 @@ struct FuseArgs {
 // `out` points at the first output channel; out_cs = channels per pixel of the destination buffer.
 void launch_fuse_sum(const FuseArgs& a, float* out, int B, int H, int W, int C, int out_cs, int relu, hipStream_t s);
 // Global average pool NHWC [B,HW,C] -> dst[b*dst_stride + c] (hrnet_cls.py:482, cliff_head.py:96).
-void launch_avgpool(const float* in, float* dst, int B, int HW, int C, int dst_stride, hipStream_t s);
+void launch_avgpool(const float* in, float* dst, int B, int H, int W, int C, int dst_stride, hipStream_t s);
 
 // ---- head kernels (kernels_head.hip) ---------------------------------------------------------------
 // Part attention pooling (KeypointAttention, layers/keypoint_attention.py:34-48):
@@ -31,7 +34,7 @@ void launch_avgpool(const float* in, float* dst, int B, int HW, int C, int dst_s
 // scratch: part_attention_scratch_floats(B, C) floats.  C <= 128.
 size_t part_attention_scratch_floats(int B, int C);
 void launch_part_attention_pool_ws(const float* heat, int heat_cs, const float* feat, int C, float* dst,
-                                   int dst_stride, int B, int HW, float* scratch, hipStream_t s);
+                                   int dst_stride, int B, int H, int W, float* scratch, hipStream_t s);
 // LocallyConnected2d 128->6 per joint (layers/locallyconnected2d.py:27-37):
 //   pose6d[b, j, o] = sum_c x[b*x_stride + c*24 + j] * w[o][c][j]
 void launch_lc2d_pose(const float* x, int x_stride, const float* w /*[6][128][24]*/, float* pose6d /*[B,144]*/,
@@ -46,7 +49,7 @@ void launch_copy_rows(const float* src, int src_stride, float* dst, int dst_stri
 // dst[b*dst_stride + i] = src[i] (broadcast an init vector into every crop's row).
 void launch_broadcast_rows(const float* src, float* dst, int dst_stride, int n, int B, hipStream_t s);
 // NHWC [B,HW,cs] (first C channels) -> NCHW [B,C,HW]
-void launch_nhwc_to_nchw(const float* in, int cs, float* out, int B, int HW, int C, hipStream_t s);
+void launch_nhwc_to_nchw(const float* in, int cs, float* out, int B, int H, int W, int C, hipStream_t s);
 
 // ---- SMPL (kernels_smpl.hip) -------------------------------------------------------------------------
 struct SmplDev {

@@ -12,23 +12,29 @@ constexpr int PTILE = 64;   // pixels per LDS weight tile
 // scratch layout per (b,s): m[24] | l[24] | acc[C][24]
 __global__ void __launch_bounds__(256)
 attn_pool_partial_kernel(const float* __restrict__ heat, int heat_cs, const float* __restrict__ feat, int C,
-                         float* __restrict__ scratch, int HW, int nsplit) {
+                         float* __restrict__ scratch, int H, int W, int nsplit) {
+  const int HW = H * W;
+  // L16 float offset of (pixel p of crop b, channel ch) in a buffer with cs channels
+  auto at = [&](int b, int p, int ch, int cs) {
+    const int y = p / W, x = p - y * W;
+    return (((size_t)b * H + y) * (cs >> 4) + (ch >> 4)) * (size_t)(W * 16) + (size_t)x * 16 + (ch & 15);
+  };
   __shared__ float red[256 / 64][NPART];
   __shared__ float mloc[NPART];
   __shared__ float wt[PTILE][NPART];
   const int b = blockIdx.x, s = blockIdx.y, tid = threadIdx.x;
   const int per = (HW + nsplit - 1) / nsplit;
   const int p0 = s * per, p1 = min(HW, p0 + per);
-  const float* hb = heat + (size_t)b * HW * heat_cs;
-  const float* fb = feat + (size_t)b * HW * C;
   // ---- local max per part ----
   float mx[NPART];
 #pragma unroll
   for (int j = 0; j < NPART; ++j) mx[j] = -INFINITY;
   for (int p = p0 + tid; p < p1; p += 256) {
-    const float* h = hb + (size_t)p * heat_cs + 1;   // channel 0 = background (pare_head.py:794-796)
+    // channel 0 = background (pare_head.py:794-796); parts 1..24 straddle the two 16-channel slices
+    const float* h0 = heat + at(b, p, 0, heat_cs);
+    const float* h1 = heat + at(b, p, 16, heat_cs);
 #pragma unroll
-    for (int j = 0; j < NPART; ++j) mx[j] = fmaxf(mx[j], h[j]);
+    for (int j = 0; j < NPART; ++j) mx[j] = fmaxf(mx[j], (j + 1 < 16) ? h0[j + 1] : h1[j + 1 - 16]);
   }
 #pragma unroll
   for (int j = 0; j < NPART; ++j) {
@@ -50,14 +56,14 @@ attn_pool_partial_kernel(const float* __restrict__ heat, int heat_cs, const floa
     const int np = min(PTILE, p1 - t0);
     for (int i = tid; i < PTILE * NPART; i += 256) {
       const int pp = i / NPART, j = i - pp * NPART;
-      wt[pp][j] = (pp < np) ? __expf(hb[(size_t)(t0 + pp) * heat_cs + 1 + j] - mloc[j]) : 0.f;
+      wt[pp][j] = (pp < np) ? __expf(heat[at(b, t0 + pp, 1 + j, heat_cs)] - mloc[j]) : 0.f;
     }
     __syncthreads();
     if (tid < NPART)
       for (int pp = 0; pp < np; ++pp) lsum += wt[pp][tid];
     if (pg < groups)
       for (int pp = pg; pp < np; pp += groups) {
-        const float f = fb[(size_t)(t0 + pp) * C + c];
+        const float f = feat[at(b, t0 + pp, c, C)];
 #pragma unroll
         for (int j = 0; j < NPART; ++j) acc[j] = fmaf(wt[pp][j], f, acc[j]);
       }
@@ -143,12 +149,14 @@ __global__ void copy_rows_kernel(const float* __restrict__ src, int src_stride, 
   dst[(size_t)b * dst_stride + k] = src[(bcast ? 0 : (size_t)b * src_stride) + k];
 }
 
-__global__ void nhwc_to_nchw_kernel(const float* __restrict__ in, int cs, float* __restrict__ out, int B, int HW,
+__global__ void nhwc_to_nchw_kernel(const float* __restrict__ in, int cs, float* __restrict__ out, int B, int H, int W,
                                     int C) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int HW = H * W;
   if (i >= (long)B * C * HW) return;
   const int p = (int)(i % HW), c = (int)((i / HW) % C), b = (int)(i / ((long)HW * C));
-  out[i] = in[((size_t)b * HW + p) * cs + c];
+  const int y = p / W, x = p - y * W;
+  out[i] = in[(((size_t)b * H + y) * (cs >> 4) + (c >> 4)) * (size_t)(W * 16) + (size_t)x * 16 + (c & 15)];
 }
 
 inline int nblk(long n, int t) { return (int)((n + t - 1) / t); }
@@ -161,9 +169,9 @@ size_t part_attention_scratch_floats(int B, int C) {
 }
 
 void launch_part_attention_pool_ws(const float* heat, int heat_cs, const float* feat, int C, float* dst,
-                                   int dst_stride, int B, int HW, float* scratch, hipStream_t s) {
+                                   int dst_stride, int B, int H, int W, float* scratch, hipStream_t s) {
   hipLaunchKernelGGL(attn_pool_partial_kernel, dim3(B, ATTN_NSPLIT), dim3(256), 0, s, heat, heat_cs, feat, C,
-                     scratch, HW, ATTN_NSPLIT);
+                     scratch, H, W, ATTN_NSPLIT);
   hipLaunchKernelGGL(attn_pool_combine_kernel, dim3(nblk((long)B * C * NPART, 256)), dim3(256), 0, s, scratch, dst,
                      dst_stride, B, C, ATTN_NSPLIT);
 }
@@ -188,6 +196,6 @@ void launch_broadcast_rows(const float* src, float* dst, int dst_stride, int n, 
                      1);
 }
 
-void launch_nhwc_to_nchw(const float* in, int cs, float* out, int B, int HW, int C, hipStream_t s) {
-  hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(nblk((long)B * C * HW, 256)), dim3(256), 0, s, in, cs, out, B, HW, C);
+void launch_nhwc_to_nchw(const float* in, int cs, float* out, int B, int H, int W, int C, hipStream_t s) {
+  hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(nblk((long)B * C * H * W, 256)), dim3(256), 0, s, in, cs, out, B, H, W, C);
 }

@@ -1,5 +1,6 @@
 // Backbone side kernels: stem conv (Cin=3), max pool, bilinear x2, HRNet fuse-sum, global avg pool.
-// All HBM-bound elementwise / small-reduction work on NHWC fp32 with 16-byte accesses.
+// All HBM-bound elementwise / small-reduction work on L16 (channel-slice-major NHWC, common.h) fp32 with 16-byte
+// accesses; threads are ordered like the output memory.
 #include "kernels.h"
 
 namespace {
@@ -46,7 +47,8 @@ stem_conv_kernel(const float* __restrict__ img, const float* __restrict__ w, con
       }
     }
   }
-  float4* o = reinterpret_cast<float4*>(out + (size_t)pix * 64 + g * 16);
+  // L16: the 16 channels of group g are slice g of the 64-channel row
+  float4* o = reinterpret_cast<float4*>(out) + L16_F4((size_t)b * Ho + yo, xo, g * 4, Wo, 4);
 #pragma unroll
   for (int i = 0; i < 4; ++i)
     o[i] = make_float4(fmaxf(acc[i].x, 0.f), fmaxf(acc[i].y, 0.f), fmaxf(acc[i].z, 0.f), fmaxf(acc[i].w, 0.f));
@@ -57,11 +59,15 @@ __global__ void maxpool_kernel(const float4* __restrict__ in, float4* __restrict
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const long n = (long)B * Ho * Wo * C4;
   if (i >= n) return;
-  const int c = (int)(i % C4);
-  long t = i / C4;
+  // thread order = L16 memory order of the output: quad, x, slice, y, b
+  const int C16 = C4 >> 2;
+  const int q = (int)(i & 3);
+  long t = i >> 2;
   const int xo = (int)(t % Wo); t /= Wo;
+  const int cb = (int)(t % C16); t /= C16;
   const int yo = (int)(t % Ho);
   const int b = (int)(t / Ho);
+  const int c = cb * 4 + q;
   float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
   for (int r = 0; r < 3; ++r) {
     const int iy = yo * 2 - 1 + r;
@@ -69,7 +75,7 @@ __global__ void maxpool_kernel(const float4* __restrict__ in, float4* __restrict
     for (int s = 0; s < 3; ++s) {
       const int ix = xo * 2 - 1 + s;
       if ((unsigned)ix >= (unsigned)W) continue;
-      const float4 v = in[(((size_t)b * H + iy) * W + ix) * C4 + c];
+      const float4 v = in[L16_F4((size_t)b * H + iy, ix, c, W, C16)];
       m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
     }
   }
@@ -83,11 +89,14 @@ __global__ void bilinear_up2x_kernel(const float4* __restrict__ in, float4* __re
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const long n = (long)B * Ho * Wo * C4;
   if (i >= n) return;
-  const int c = (int)(i % C4);
-  long t = i / C4;
+  const int C16 = C4 >> 2;
+  const int q = (int)(i & 3);
+  long t = i >> 2;
   const int xo = (int)(t % Wo); t /= Wo;
+  const int cb = (int)(t % C16); t /= C16;
   const int yo = (int)(t % Ho);
   const int b = (int)(t / Ho);
+  const int c = cb * 4 + q;
   const float sh = (Ho > 1) ? (float)(H - 1) / (float)(Ho - 1) : 0.f;
   const float sw = (Wo > 1) ? (float)(W - 1) / (float)(Wo - 1) : 0.f;
   const float fy = sh * yo, fx = sw * xo;
@@ -95,9 +104,9 @@ __global__ void bilinear_up2x_kernel(const float4* __restrict__ in, float4* __re
   const int y1 = y0 + (y0 < H - 1), x1 = x0 + (x0 < W - 1);
   const float ly1 = fy - y0, lx1 = fx - x0;
   const float ly0 = 1.f - ly1, lx0 = 1.f - lx1;
-  const float4* ib = in + (size_t)b * H * W * C4 + c;
-  const float4 v00 = ib[((size_t)y0 * W + x0) * C4], v01 = ib[((size_t)y0 * W + x1) * C4];
-  const float4 v10 = ib[((size_t)y1 * W + x0) * C4], v11 = ib[((size_t)y1 * W + x1) * C4];
+  const size_t r0 = (size_t)b * H + y0, r1 = (size_t)b * H + y1;
+  const float4 v00 = in[L16_F4(r0, x0, c, W, C16)], v01 = in[L16_F4(r0, x1, c, W, C16)];
+  const float4 v10 = in[L16_F4(r1, x0, c, W, C16)], v11 = in[L16_F4(r1, x1, c, W, C16)];
   float4 o;
   o.x = ly0 * (lx0 * v00.x + lx1 * v01.x) + ly1 * (lx0 * v10.x + lx1 * v11.x);
   o.y = ly0 * (lx0 * v00.y + lx1 * v01.y) + ly1 * (lx0 * v10.y + lx1 * v11.y);
@@ -111,38 +120,43 @@ __global__ void fuse_sum_kernel(FuseArgs a, float4* __restrict__ out, int B, int
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const long n = (long)B * H * W * C4;
   if (i >= n) return;
-  const int c = (int)(i % C4);
-  long t = i / C4;
+  const int C16 = C4 >> 2;
+  const int q = (int)(i & 3);
+  long t = i >> 2;
   const int x = (int)(t % W); t /= W;
+  const int cb = (int)(t % C16); t /= C16;
   const int y = (int)(t % H);
   const int b = (int)(t / H);
+  const int c = cb * 4 + q;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     if (k < a.n) {
       const int sh = a.shift[k];
       const int hs = H >> sh, wsz = W >> sh;
-      const float4 v = reinterpret_cast<const float4*>(a.src[k])[(((size_t)b * hs + (y >> sh)) * wsz + (x >> sh)) * (a.src_cs[k] >> 2) + c];
+      const float4 v = reinterpret_cast<const float4*>(a.src[k])[L16_F4((size_t)b * hs + (y >> sh), x >> sh, c, wsz, a.src_cs[k] >> 4)];
       if (k == 0) acc = v;
       else { acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }
     }
   }
   if (relu) { acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f); }
-  out[(((size_t)b * H + y) * W + x) * outC4 + c] = acc;
+  out[L16_F4((size_t)b * H + y, x, c, W, outC4 >> 2)] = acc;
 }
 
-__global__ void avgpool_kernel(const float4* __restrict__ in, float* __restrict__ dst, int B, int HW, int C4,
+__global__ void avgpool_kernel(const float4* __restrict__ in, float* __restrict__ dst, int B, int H, int W, int C4,
                                int dst_stride) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B * C4) return;
   const int c = i % C4, b = i / C4;
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-  const float4* p = in + (size_t)b * HW * C4 + c;
-  for (int k = 0; k < HW; ++k) {
-    const float4 v = p[(size_t)k * C4];
-    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  for (int y = 0; y < H; ++y) {
+    const float4* p = in + L16_F4((size_t)b * H + y, 0, c, W, C4 >> 2);
+    for (int x = 0; x < W; ++x) {
+      const float4 v = p[(size_t)x * 4];
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
   }
-  const float inv = 1.f / (float)HW;
+  const float inv = 1.f / (float)(H * W);
   *reinterpret_cast<float4*>(dst + (size_t)b * dst_stride + c * 4) = make_float4(s.x * inv, s.y * inv, s.z * inv, s.w * inv);
 }
 
@@ -180,9 +194,9 @@ void launch_fuse_sum(const FuseArgs& a, float* out, int B, int H, int W, int C, 
                      relu);
 }
 
-void launch_avgpool(const float* in, float* dst, int B, int HW, int C, int dst_stride, hipStream_t s) {
+void launch_avgpool(const float* in, float* dst, int B, int H, int W, int C, int dst_stride, hipStream_t s) {
   const int n = B * (C / 4);
-  hipLaunchKernelGGL(avgpool_kernel, dim3(nblk(n, 256)), dim3(256), 0, s, (const float4*)in, dst, B, HW, C / 4,
+  hipLaunchKernelGGL(avgpool_kernel, dim3(nblk(n, 256)), dim3(256), 0, s, (const float4*)in, dst, B, H, W, C / 4,
                      dst_stride);
 }
 

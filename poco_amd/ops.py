@@ -16,6 +16,19 @@ def _cfg(cfg):
     return C.cast(arr, C.c_void_p), arr
 
 
+def to_l16(x: torch.Tensor) -> torch.Tensor:
+    """NHWC [B,H,W,C] (C % 16 == 0) -> the library's activation layout [B,H,C/16,W,16] (csrc/common.h)."""
+    B, H, W, C = x.shape
+    assert C % 16 == 0
+    return x.view(B, H, W, C // 16, 16).permute(0, 1, 3, 2, 4).contiguous()
+
+
+def from_l16(y: torch.Tensor) -> torch.Tensor:
+    """[B,H,C/16,W,16] -> NHWC [B,H,W,C]."""
+    B, H, C16, W, _ = y.shape
+    return y.permute(0, 1, 3, 2, 4).reshape(B, H, W, C16 * 16).contiguous()
+
+
 def conv2d_nhwc(x: torch.Tensor, weight: np.ndarray, scale=None, shift=None, stride=1, residual=None,
                 relu=False, cfg=None) -> torch.Tensor:
     """x [B,H,W,Cin] cuda fp32 NHWC; weight OIHW numpy fp32 (host). Returns NHWC output."""
@@ -26,15 +39,20 @@ def conv2d_nhwc(x: torch.Tensor, weight: np.ndarray, scale=None, shift=None, str
     pad = (ks - 1) // 2
     Ho = (H + 2 * pad - ks) // stride + 1
     Wo = (W + 2 * pad - ks) // stride + 1
-    out = torch.empty((B, Ho, Wo, Cout), device=x.device, dtype=torch.float32)
+    # the operator works on the library's L16 layout; Cin/Cout are padded to multiples of 16 inside the op,
+    # so NHWC tensors are converted here (tests / tuning only - the engine never leaves L16)
+    assert Cin % 16 == 0 and Cout % 16 == 0, "conv2d_nhwc: channel counts must be multiples of 16"
+    out = torch.empty((B, Ho, Cout // 16, Wo, 16), device=x.device, dtype=torch.float32)
     weight = np.ascontiguousarray(weight, dtype=np.float32)
     scale = None if scale is None else np.ascontiguousarray(scale, dtype=np.float32)
     shift = None if shift is None else np.ascontiguousarray(shift, dtype=np.float32)
     cptr, _keep = _cfg(cfg)
-    rc = lib().poco_op_conv2d(fptr(x), B, H, W, Cin, fptr(weight), fptr(scale), fptr(shift), Cout, ks,
-                              stride, fptr(residual), int(relu), fptr(out), cptr, current_stream())
+    xl = to_l16(x)
+    rl = None if residual is None else to_l16(residual)
+    rc = lib().poco_op_conv2d(fptr(xl), B, H, W, Cin, fptr(weight), fptr(scale), fptr(shift), Cout, ks,
+                              stride, fptr(rl), int(relu), fptr(out), cptr, current_stream())
     check(rc, "poco_op_conv2d")
-    return out
+    return from_l16(out)
 
 
 def bench_conv2d(x: torch.Tensor, weight: np.ndarray, stride=1, cfg=None, iters=20):
