@@ -1,5 +1,6 @@
 // Small-M linear layers (H = W = 1 "convs": the CLIFF regressor fc1/fc2/dec and the poco_head MLPs,
-// pocolib/models/head/cliff_head.py:104-118, head/poco_head.py:96-154) — ALG 5.
+// pocolib/models/head/cliff_head.py:104-118, head/poco_head.py:96-154) and small-plane 1x1 stride-1 convs
+// (the HRNet up-path fuse convs, hrnet.py:196-207) — ALG 5.
 //
 // With 32..128 crops per forward these GEMMs have M = B rows only: 0.1 GFLOP against 4..9 MB of weights, so
 // they are latency-bound, not MFMA-bound.  The implicit-GEMM conv kernel runs them as Cout/16 blocks that
@@ -15,12 +16,14 @@
 namespace {
 
 struct LinParams {
-  const float* in;  int in_cs, in_co;
-  const float* res; int res_cs, res_co;
-  float* out;       int out_cs, out_co;
+  const float* in;       // slice offsets are folded into the pointers
+  const float* res;
+  float* out;
   const float4* wfrag;   // [Cin/16][Cout16/16][64] float4
   const float* bias;
-  int B, nC16, nT16;
+  int P, W, nC16, nT16;        // P = B*H*W rows ("pixels"), W = plane width (1 for Linear layers)
+  int in_rs, in_ss, res_rs, out_rs, out_ss;   // L16 strides: image row / 16-channel slice of a row
+  uint32_t w_magic;            // fast division by W
   int act, res_after_act, relu_from;
 };
 
@@ -35,13 +38,19 @@ linear_mfma_kernel(const LinParams p) {
   const int nwaves = blockDim.x >> 6;
   const int idx = lane & 15, g = lane >> 4;
   const int nt = blockIdx.x;
-  const int row0 = blockIdx.y * (LIN_MB * 16);
+  const int row0 = blockIdx.y * (LIN_MB * 16);     // first pixel of this block
 
+  // pixel -> (image row, x); L16: slice c of pixel (row, x) starts at row*in_rs + c*in_ss + x*16
+  auto split = [&](int pix, int* row, int* x) {
+    *row = p.W == 1 ? pix : (int)__umulhi((uint32_t)pix, p.w_magic);
+    *x = pix - *row * p.W;
+  };
   const float* xrow[LIN_MB];
 #pragma unroll
   for (int m = 0; m < LIN_MB; ++m) {
-    const int r = min(row0 + m * 16 + idx, p.B - 1);               // dead rows re-read the last one
-    xrow[m] = p.in + (size_t)r * p.in_cs + p.in_co + 4 * g;
+    int row, x;
+    split(min(row0 + m * 16 + idx, p.P - 1), &row, &x);             // dead rows re-read the last one
+    xrow[m] = p.in + (size_t)row * p.in_rs + x * 16 + 4 * g;
   }
   f32x4 acc[LIN_MB];
 #pragma unroll
@@ -56,7 +65,7 @@ linear_mfma_kernel(const LinParams p) {
       const int c = min(c0 + u * nwaves, p.nC16 - 1);                // clamped duplicates are masked below
       a[u] = wl[(size_t)c * wstride];
 #pragma unroll
-      for (int m = 0; m < LIN_MB; ++m) b[u][m] = *reinterpret_cast<const float4*>(xrow[m] + c * 16);
+      for (int m = 0; m < LIN_MB; ++m) b[u][m] = *reinterpret_cast<const float4*>(xrow[m] + (size_t)c * p.in_ss);
     }
 #pragma unroll
     for (int u = 0; u < LIN_UNROLL; ++u) {
@@ -84,12 +93,15 @@ linear_mfma_kernel(const LinParams p) {
       s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
     }
     const int r = row0 + m * 16 + idx;
-    if (r >= p.B) continue;
+    if (r >= p.P) continue;
+    int orow, ox;
+    split(r, &orow, &ox);
     const int co = nt * 16 + g * 4;
+    const size_t so = (size_t)nt * p.out_ss + ox * 16 + g * 4;       // slice + pixel offset inside an image row
     const float4 sh = *reinterpret_cast<const float4*>(p.bias + co);
     float v[4] = {s.x + sh.x, s.y + sh.y, s.z + sh.z, s.w + sh.w};
     float4 rr = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (p.res) rr = *reinterpret_cast<const float4*>(p.res + (size_t)r * p.res_cs + p.res_co + co);
+    if (p.res) rr = *reinterpret_cast<const float4*>(p.res + (size_t)orow * p.res_rs + so);
     if (!p.res_after_act) { v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w; }
     if (p.act == 1 || (p.act == 3 && co >= p.relu_from)) {
 #pragma unroll
@@ -99,31 +111,35 @@ linear_mfma_kernel(const LinParams p) {
       for (int e = 0; e < 4; ++e) v[e] = 1.f / (1.f + __expf(-v[e]));
     }
     if (p.res_after_act) { v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w; }
-    *reinterpret_cast<float4*>(p.out + (size_t)r * p.out_cs + p.out_co + co) = make_float4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<float4*>(p.out + (size_t)orow * p.out_rs + so) = make_float4(v[0], v[1], v[2], v[3]);
   }
 }
 
 }  // namespace
 
 bool linear_cfg_valid(const ConvDesc& d, const ConvCfg& cfg) {
-  return d.H == 1 && d.W == 1 && d.ks == 1 && cfg.WM >= 1 && cfg.WM <= 16 && d.Cin % 16 == 0 && d.Cout % 16 == 0;
+  return d.ks == 1 && d.stride == 1 && cfg.WM >= 1 && cfg.WM <= 16 && d.Cin % 16 == 0 && d.Cout % 16 == 0 &&
+         (long)d.B * d.H * d.W < (1L << 30);
 }
 
 int linear_launch(const ConvDesc& d, const ConvCfg& cfg, hipStream_t stream) {
   if (!linear_cfg_valid(d, cfg)) {
-    poco_set_error("linear: ALG 5 needs a 1x1 plane, ks = 1, WM (K-split waves) in 1..16");
+    poco_set_error("linear: ALG 5 needs ks = 1, stride 1, WM (K-split waves) in 1..16");
     return POCO_ERR_ARG;
   }
   LinParams p{};
-  p.in = d.in; p.in_cs = d.in_cs; p.in_co = d.in_co;
-  p.res = d.res; p.res_cs = d.res_cs; p.res_co = d.res_co;
-  p.out = d.out; p.out_cs = d.out_cs; p.out_co = d.out_co;
+  p.in = d.in + l16_chan_off(d.in_co, d.W);
+  p.res = d.res ? d.res + l16_chan_off(d.res_co, d.W) : nullptr;
+  p.out = d.out + l16_chan_off(d.out_co, d.W);
   p.wfrag = reinterpret_cast<const float4*>(d.wfrag); p.bias = d.bias;
-  p.B = d.B; p.nC16 = d.Cin / 16; p.nT16 = d.Cout / 16;
+  p.P = d.B * d.H * d.W; p.W = d.W; p.nC16 = d.Cin / 16; p.nT16 = d.Cout / 16;
+  p.in_rs = d.in_cs * d.W; p.in_ss = d.W * 16;
+  p.res_rs = d.res_cs * d.W; p.out_rs = d.out_cs * d.W; p.out_ss = d.W * 16;
+  p.w_magic = d.W > 1 ? (uint32_t)(((1ull << 32) + d.W - 1) / d.W) : 0;   // exact for pix < 2^30 / W-sized planes
   p.act = d.act; p.res_after_act = d.res_after_act; p.relu_from = d.relu_from;
   const int nwaves = cfg.WM;
   const size_t lds = (size_t)nwaves * LIN_MB * 64 * sizeof(float4);
-  const dim3 grid(p.nT16, (d.B + LIN_MB * 16 - 1) / (LIN_MB * 16));
+  const dim3 grid(p.nT16, (p.P + LIN_MB * 16 - 1) / (LIN_MB * 16));
   hipLaunchKernelGGL(linear_mfma_kernel, grid, dim3(nwaves * 64), lds, stream, p);
   POCO_HIP_CHECK(hipGetLastError());
   return POCO_OK;

@@ -161,3 +161,22 @@ def test_linear_small_m(case, wm, cuda):
     out = ops.conv2d_nhwc(torch.from_numpy(x).to(cuda), w, None, shift, 1, torch.from_numpy(res).to(cuda), True,
                           cfg=cfg).cpu().numpy()
     assert np.abs(out - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max())
+
+
+@pytest.mark.parametrize("wm", [1, 2, 4, 8])
+@pytest.mark.parametrize("case", [(2, 56, 56, 64, 256), (3, 14, 14, 192, 144), (5, 7, 7, 384, 336), (1, 13, 9, 32, 16)],
+                         ids=lambda c: "x".join(map(str, c)))
+def test_conv1x1_split_k(case, wm, cuda):
+    """ALG 5 on spatial planes: 1x1 stride-1 convs as a split-K GEMM over the L16 pixel rows (hrnet.py:196-207)."""
+    from poco_amd import ops
+    B, H, W, Cin, Cout = case
+    rng = np.random.default_rng(B * 131 + Cin)
+    x = rng.standard_normal((B, H, W, Cin)).astype(np.float32)
+    w = (rng.standard_normal((Cout, Cin, 1, 1)) / np.sqrt(Cin)).astype(np.float32)
+    scale = rng.uniform(0.5, 1.5, Cout).astype(np.float32)
+    shift = rng.uniform(-0.5, 0.5, Cout).astype(np.float32)
+    res = rng.standard_normal((B, H, W, Cout)).astype(np.float32)
+    ref = _ref(x, w, scale, shift, 1, res, True)
+    out = ops.conv2d_nhwc(torch.from_numpy(x).to(cuda), w, scale, shift, 1, torch.from_numpy(res).to(cuda), True,
+                          cfg=(1, 1, wm, 1, 1, 1, 5)).cpu().numpy()
+    assert np.abs(out - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max())
