@@ -11,7 +11,10 @@
  *   - all functions return 0 (POCO_OK) or a positive error code; poco_last_error() returns the
  *     message of the last failure on the calling thread.  Nothing throws across the ABI.
  *   - "d_" pointers are device (HBM) pointers owned by the caller, "h_" pointers are host memory.
- *   - activations handed to the stand-alone operators are NHWC fp32 unless stated otherwise.
+ *   - activations handed to the stand-alone conv operators are fp32 in the library's internal layout "L16"
+ *     (channel-slice-major NHWC): [B][H][C/16][W][16], i.e. element (b,y,x,c) at
+ *     ((b*H + y)*(C/16) + c/16)*W*16 + x*16 + c%16; for H = W = 1 this is plain [B][C].
+ *     poco_forward itself takes the reference's NCHW image batch and returns the reference's tensors.
  *   - `stream` is a hipStream_t (NULL = default stream).  Operators enqueue on it; the
  *     poco_op_* test entry points additionally synchronise it before returning.
  */
@@ -95,7 +98,7 @@ int poco_profile_ops(poco_handle_t h, int B, const poco_inputs_t* in, const poco
                      float* ms_per_op, int cap, void* stream);
 size_t poco_workspace_bytes(poco_handle_t h);
 int poco_uncert_feat_dim(poco_handle_t h);
-int poco_set_conv_cfg(poco_handle_t h, int op_index, int B, const int* cfg6);
+int poco_set_conv_cfg(poco_handle_t h, int op_index, int B, const int* cfg7);
 int poco_get_conv_desc(poco_handle_t h, int op_index, int* desc8);
 
 /* SMPL linear blend skinning with the engine's loaded body model: replaces
@@ -114,17 +117,18 @@ int poco_realnvp(poco_handle_t h, int N, const float* d_x, const float* d_ctx, f
 /* conv(ks x ks, stride, pad=(ks-1)/2, no groups/dilation) * scale[co] + shift[co] (+ residual) (ReLU)
  * == nn.Conv2d -> nn.BatchNorm2d(eval) [-> "+= residual"] [-> ReLU] of
  * pocolib/models/backbone/hrnet.py:42-58,79-99 / hrnet_cls.py / resnet.py:101-121.
- * d_in  [B,H,W,Cin] NHWC, h_weight [Cout,Cin,ks,ks] (host, torch OIHW order),
- * h_scale/h_shift [Cout] (host, nullable), d_res [B,Ho,Wo,Cout] NHWC (nullable), d_out NHWC.
- * Cin and Cout must be multiples of 16.  cfg6 = {MT,NT,WM,WN,R,NI} or NULL for the heuristic. */
+ * d_in  [B,H,Cin/16,W,16] (L16), h_weight [Cout,Cin,ks,ks] (host, torch OIHW order),
+ * h_scale/h_shift [Cout] (host, nullable), d_res / d_out [B,Ho,Cout/16,Wo,16] (L16; d_res nullable).
+ * Cin and Cout must be multiples of 16.  cfg = 7 ints {MT,NT,WM,WN,R,NI,ALG} (csrc/common.h) or NULL for the
+ * heuristic. */
 int poco_op_conv2d(const float* d_in, int B, int H, int W, int Cin, const float* h_weight,
                    const float* h_scale, const float* h_shift, int Cout, int ks, int stride,
-                   const float* d_res, int relu, float* d_out, const int* cfg6, void* stream);
+                   const float* d_res, int relu, float* d_out, const int* cfg7, void* stream);
 
 /* Time `iters` launches of the same conv (+ReLU) with hipEvents; ms_out = mean ms per launch.
  * cfg_used6 (nullable) receives the tile configuration that ran. */
 int poco_bench_conv2d(const float* d_in, int B, int H, int W, int Cin, const float* h_weight, int Cout,
-                      int ks, int stride, float* d_out, const int* cfg6, int iters, float* ms_out,
+                      int ks, int stride, float* d_out, const int* cfg7, int iters, float* ms_out,
                       int* cfg_used6, void* stream);
 
 /* GPU-side crop + normalise: replaces the per-detection CPU loop cv2.warpAffine(INTER_LINEAR,

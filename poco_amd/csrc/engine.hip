@@ -1241,9 +1241,9 @@ extern "C" size_t poco_workspace_bytes(poco_handle_t h) { return h ? H(h)->ws_fl
 
 extern "C" int poco_uncert_feat_dim(poco_handle_t h) { return h ? H(h)->uncert_feat_dim : -1; }
 
-extern "C" int poco_set_conv_cfg(poco_handle_t h, int op_index, int B, const int* cfg6) {
+extern "C" int poco_set_conv_cfg(poco_handle_t h, int op_index, int B, const int* cfg7) {
   Engine* e = H(h);
-  if (!e || op_index < 0 || op_index >= (int)e->ops.size() || !cfg6 || e->ops[op_index].type != OP_CONV) {
+  if (!e || op_index < 0 || op_index >= (int)e->ops.size() || !cfg7 || e->ops[op_index].type != OP_CONV) {
     poco_set_error("poco_set_conv_cfg: bad arguments");
     return POCO_ERR_ARG;
   }
@@ -1253,7 +1253,7 @@ extern "C" int poco_set_conv_cfg(poco_handle_t h, int op_index, int B, const int
   ConvDesc d{};
   d.B = B; d.H = ai.H; d.W = ai.W; d.Cin = op.Cin; d.Cout = op.Cout; d.ks = op.ks; d.stride = op.stride;
   d.in_cs = ai.C; d.out_cs = e->acts[op.out.act].C; d.act = op.actfn;
-  const ConvCfg c = conv_cfg_from(cfg6);
+  const ConvCfg c = conv_cfg_from(cfg7);
   const size_t lds = conv_lds_bytes(d, c);
   if (B < 1 || lds == 0 || lds > 160 * 1024 || ((c.ALG == 3 || c.ALG == 4) && (op.wdev_wino == nullptr && e->finalized)) ||
       ((c.ALG == 3 || c.ALG == 4) && op.actfn == 3)) {

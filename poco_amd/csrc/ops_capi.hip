@@ -28,7 +28,7 @@ struct DevBuf {
 
 static int conv_common(const float* d_in, int B, int H, int W, int Cin, const float* h_w,
                        const float* h_scale, const float* h_shift, int Cout, int ks, int stride,
-                       const float* d_res, int relu, float* d_out, const int* cfg6, int iters,
+                       const float* d_res, int relu, float* d_out, const int* cfg7, int iters,
                        float* ms_out, hipStream_t stream) {
   if (!d_in || !h_w || !d_out) {
     poco_set_error("conv2d: null pointer");
@@ -62,7 +62,7 @@ static int conv_common(const float* d_in, int B, int H, int W, int Cin, const fl
   d.B = B; d.H = H; d.W = W; d.Cin = Cin; d.Cout = Cout16;
   d.ks = ks; d.stride = stride; d.act = relu; d.res_after_act = 0;
   ConvCfg cfg = conv_default_cfg(d);
-  if (cfg6 && cfg6[0] > 0) cfg = conv_cfg_from(cfg6);
+  if (cfg7 && cfg7[0] > 0) cfg = conv_cfg_from(cfg7);
   int rc = conv_launch(d, cfg, stream);
   if (rc != POCO_OK) return rc;
   if (iters > 0 && ms_out) {
@@ -86,24 +86,24 @@ static int conv_common(const float* d_in, int B, int H, int W, int Cin, const fl
 
 extern "C" int poco_op_conv2d(const float* d_in, int B, int H, int W, int Cin, const float* h_weight,
                               const float* h_scale, const float* h_shift, int Cout, int ks, int stride,
-                              const float* d_res, int relu, float* d_out, const int* cfg6,
+                              const float* d_res, int relu, float* d_out, const int* cfg7,
                               void* stream) {
   return conv_common(d_in, B, H, W, Cin, h_weight, h_scale, h_shift, Cout, ks, stride, d_res, relu,
-                     d_out, cfg6, 0, nullptr, (hipStream_t)stream);
+                     d_out, cfg7, 0, nullptr, (hipStream_t)stream);
 }
 
 extern "C" int poco_bench_conv2d(const float* d_in, int B, int H, int W, int Cin, const float* h_weight,
-                                 int Cout, int ks, int stride, float* d_out, const int* cfg6, int iters,
+                                 int Cout, int ks, int stride, float* d_out, const int* cfg7, int iters,
                                  float* ms_out, int* cfg_used6, void* stream) {
   if (cfg_used6) {
     ConvDesc d{};
     d.B = B; d.H = H; d.W = W; d.Cin = Cin; d.Cout = Cout; d.ks = ks; d.stride = stride;
-    ConvCfg c = (cfg6 && cfg6[0] > 0) ? conv_cfg_from(cfg6) : conv_default_cfg(d);
+    ConvCfg c = (cfg7 && cfg7[0] > 0) ? conv_cfg_from(cfg7) : conv_default_cfg(d);
     cfg_used6[0] = c.MT; cfg_used6[1] = c.NT; cfg_used6[2] = c.WM;
     cfg_used6[3] = c.WN; cfg_used6[4] = c.R;  cfg_used6[5] = c.NI; cfg_used6[6] = c.ALG;
   }
   return conv_common(d_in, B, H, W, Cin, h_weight, nullptr, nullptr, Cout, ks, stride, nullptr, 1, d_out,
-                     cfg6, iters, ms_out, (hipStream_t)stream);
+                     cfg7, iters, ms_out, (hipStream_t)stream);
 }
 
 // Time a list of tile configurations for one conv shape (weights/activations allocated and filled
