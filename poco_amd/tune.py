@@ -41,7 +41,7 @@ def candidates(B, H, W, Cin, Cout, ks, stride, lds_cap=150 * 1024) -> List[Tuple
         return [(1, 1, wm, 1, 1, 1, 5) for wm in (1, 2, 4, 8, 16)] + [(4, 1, 1, 1, 1, min(B, 64), 1)]
     if ks == 1 and stride == 1:          # split-K GEMM straight from global memory (small planes / few pixels)
         out.update((1, 1, wm, 1, 1, 1, 5) for wm in (1, 2, 4, 8))
-    for MT, NT, WM, WN in itertools.product((4, 7, 13), (1, 2, 3, 4), (1, 2, 4, 8), (1, 2, 4, 8)):
+    for MT, NT, WM, WN in itertools.product((4, 7, 13), (1, 2, 3, 4), (1, 2, 4, 8), (1, 2, 3, 4, 6, 8)):
         if WM * WN > 8 or (MT == 13 and NT > (2 if ks == 3 else 3)) or nT % NT:
             continue
         if (nT // NT) % WN and WN > 1 and (nT // NT) > WN:

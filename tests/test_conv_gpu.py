@@ -71,7 +71,7 @@ def test_conv_parity(case, cuda):
 
 
 TILES = [(4, 2, 2, 1, 2, 1), (7, 2, 4, 1, 8, 1), (7, 1, 1, 2, 2, 1), (13, 2, 1, 1, 3, 1), (7, 2, 2, 2, 4, 1),
-         (4, 1, 2, 4, 1, 2)]
+         (4, 1, 2, 4, 1, 2), (4, 1, 2, 3, 1, 2), (7, 1, 1, 6, 2, 1)]
 
 
 @pytest.mark.parametrize("alg", [1, 2])
