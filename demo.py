@@ -32,7 +32,12 @@ def parse_args(argv=None):
     p.add_argument("--no_render", action="store_true", help="(rendering is out of scope; always off)")
     p.add_argument("--no_kinematic_uncert", action="store_false",
                    help="Do not use SMPL Kinematic for uncert (same store_false semantics as the reference)")
-    p.add_argument("--smooth", action="store_true")
+    p.add_argument("--smooth", action="store_true", help="one-euro smoothing of each track (video mode)")
+    p.add_argument("--min_cutoff", type=float, default=0.004)
+    p.add_argument("--beta", type=float, default=1.5)
+    p.add_argument("--tracking", type=str, default=None,
+                   help="video mode: json {person_id: {'bbox': [[cx,cy,w,h],...], 'frames': [idx,...]}} "
+                        "(multi_person_tracker output); default = one centred track over all frames")
     p.add_argument("--skip_frame", type=int, default=1)
     p.add_argument("--detections", type=str, default=None, help="json: {image name: [[cx,cy,w,h],...]}")
     p.add_argument("--smpl", type=str, default="data/smpl/SMPL_NEUTRAL.npz",
@@ -48,8 +53,11 @@ def main(args):
     if not folder or not os.path.isdir(folder):
         sys.exit(f"input folder not found: {folder}")
     tester = POCOTester(args)
-    stats = tester.run_on_image_folder(folder, load_detections(args.detections),
-                                       os.path.join(args.output_folder, os.path.basename(os.path.normpath(folder)) + "_"))
+    out_dir = os.path.join(args.output_folder, os.path.basename(os.path.normpath(folder)) + "_")
+    if args.mode == "video":
+        stats = tester.run_on_video_folder(folder, args.tracking, out_dir)
+    else:
+        stats = tester.run_on_image_folder(folder, load_detections(args.detections), out_dir)
     print(json.dumps({"poco_fps": round(stats["fps"], 2), **stats}))     # reference logs 'poco FPS' (demo.py:136-145)
 
 

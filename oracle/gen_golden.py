@@ -7,6 +7,7 @@ pin oracle/poco_ref.py against them.
 What is recorded (data only - inputs are re-derived from seeds by poco_amd/synth.py):
   tests/golden/spec_<variant>.json     state_dict key -> shape of the reference modules
   tests/golden/model_<variant>.npz     reference outputs for B=2 (pose/shape/cam/var/features ...)
+  tests/golden/smooth.npz              One Euro filtered rotation tracks (one_euro_filter.py via smooth_pose.py)
   tests/golden/ops.npz                 per-op vectors (KeypointAttention, LocallyConnected2d,
                                        rot6d_to_rotmat, camera conversions, RealNVP, uncert post-proc)
 The SMPL step cannot be run through the reference (smplx + SMPL assets absent): the vertices /
@@ -211,6 +212,39 @@ def run_ops():
     print("ops fixtures written; oracle small-function pins OK")
 
 
+def run_smooth():
+    """tests/golden/smooth.npz: the reference's OneEuroFilter (one_euro_filter.py) driven exactly like
+    smooth_pose.py:28-61 on a seeded rotation-matrix track; pins oracle/smooth_np.smooth_rotmats."""
+    import importlib.util
+    from oracle import smooth_np
+    spec = importlib.util.spec_from_file_location(
+        "ref_one_euro", os.path.join(ref_import.REFERENCE, "pocolib/utils/one_euro_filter.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    r = np.random.default_rng(2024)
+    T = 17
+    # a smooth random walk of rotations + jitter, as rotation matrices [T,24,3,3]
+    aa = np.cumsum(0.05 * r.standard_normal((T, 24, 3)), 0) + 0.02 * r.standard_normal((T, 24, 3))
+    th = np.linalg.norm(aa, axis=-1, keepdims=True) + 1e-12
+    k = aa / th
+    K = np.zeros((T, 24, 3, 3))
+    K[..., 0, 1], K[..., 0, 2], K[..., 1, 0] = -k[..., 2], k[..., 1], k[..., 2]
+    K[..., 1, 2], K[..., 2, 0], K[..., 2, 1] = -k[..., 0], -k[..., 1], k[..., 0]
+    pose = (np.eye(3) + np.sin(th)[..., None] * K + (1 - np.cos(th))[..., None] * (K @ K)).astype(np.float32)
+    out = {}
+    for tag, (mc, be) in {"default": (0.004, 0.7), "demo": (0.004, 1.5)}.items():   # smooth_pose.py:25, demo.py:289-292
+        f = m.OneEuroFilter(np.zeros_like(pose[0]), pose[0], min_cutoff=mc, beta=be)
+        hat = np.zeros_like(pose)
+        hat[0] = pose[0]
+        for idx in range(1, T):
+            hat[idx] = f(np.ones_like(pose[idx]) * idx, pose[idx])
+        out[f"hat_{tag}"] = hat
+        assert np.abs(smooth_np.smooth_rotmats(pose, mc, be) - hat).max() < 1e-6
+    out["pose"] = pose
+    np.savez_compressed(GOLD / "smooth.npz", **out)
+    print("smooth fixture written; oracle pinned")
+
+
 def main():
     assert ref_import.available(), "needs /root/reference"
     GOLD.mkdir(parents=True, exist_ok=True)
@@ -220,6 +254,8 @@ def main():
     only = sys.argv[1:]
     if not only or "ops" in only:
         run_ops()
+    if not only or "smooth" in only:
+        run_smooth()
     for v, kw in VARIANTS.items():
         if not only or v in only:
             run_variant(v, kw)

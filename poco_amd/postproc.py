@@ -26,8 +26,9 @@ def prepare_uncert(var, kinematic: bool = True) -> np.ndarray:
     return kinematic_uncert(var) if kinematic else var
 
 
-def global_uncert(var: np.ndarray, backbone: str, thr: float = 0.40) -> np.ndarray:
-    """get_global_uncert (poco_utils.py:50-60) followed by the clip of tester.py:245."""
+def global_uncert(var: np.ndarray, backbone: str, thr: float = 0.40, clip: bool = True) -> np.ndarray:
+    """get_global_uncert (poco_utils.py:50-60); folder mode clips it to [0, 0.99] (tester.py:245), video mode
+    (tester.py:418-419) does not."""
     var = var.copy()
     if "cliff" in backbone:
         var[var[:, 0] > 2 * thr] = 1.0
@@ -35,7 +36,7 @@ def global_uncert(var: np.ndarray, backbone: str, thr: float = 0.40) -> np.ndarr
     else:
         var[var[:, 0] > thr] = 1.0
         g = var.mean(-1)
-    return np.clip(g, 0, 0.99)
+    return np.clip(g, 0, 0.99) if clip else g
 
 
 def convert_crop_cam_to_orig_img(cam, bbox, img_width, img_height):

@@ -111,6 +111,80 @@ class POCOTester:
             results.append({k: np.concatenate([p[k] for p in parts], 0) for k in parts[0]})
         return results
 
+    @torch.no_grad()
+    def run_on_video(self, tracking_results: dict, frames, orig_width: int, orig_height: int, bbox_scale: float = 1.0):
+        """Per-track results like pocolib/core/tester.py:362-479.
+
+        tracking_results: {person_id: {'bbox': [T,4] (cx,cy,w,h), 'frames': [T] frame indices}} - what
+        multi_person_tracker hands to the reference (tester.py:113-151).  frames: sequence or callable
+        frame index -> uint8 [H,W,3] RGB.
+
+        The reference walks person by person and re-reads every frame for every person
+        (dataset/inference.py:72-135).  Here the stream is frame-major: a frame is decoded and uploaded once,
+        all people visible in it are cropped on the GPU, crops of consecutive frames are packed into full
+        batches of `batch_size`, and the regressed rows are scattered back to the tracks."""
+        get = frames if callable(frames) else (lambda i: frames[i])
+        bs = self.model.max_batch
+        # (frame, person, slot in that person's track), frame-major
+        items = sorted((int(f), pid, k) for pid, tr in tracking_results.items() for k, f in enumerate(tr["frames"]))
+        keys = ("pred_cam", "smpl_vertices", "pred_pose", "pred_shape", "smpl_joints3d", "smpl_joints2d", "var_pose")
+        store = {pid: {k: [None] * len(tr["frames"]) for k in keys} for pid, tr in tracking_results.items()}
+        pend_batches, pend_meta = [], []
+
+        def flush():
+            if not pend_meta:
+                return
+            batch = {k: torch.cat([b[k] for b in pend_batches], 0) for k in pend_batches[0]}
+            out = self.model(batch, want_segm=False)
+            host = {k: out[k].cpu().numpy() for k in keys}
+            for row, (pid, slot) in enumerate(pend_meta):
+                for k in keys:
+                    store[pid][k][slot] = host[k][row]
+            pend_batches.clear()
+            pend_meta.clear()
+
+        i = 0
+        while i < len(items):
+            f = items[i][0]
+            j = i
+            while j < len(items) and items[j][0] == f:
+                j += 1
+            fr = torch.from_numpy(np.ascontiguousarray(get(f))).to(self.device, non_blocking=True)
+            group = items[i:j]
+            while group:                     # a frame with more people than fit goes out in pieces
+                room = bs - len(pend_meta)
+                part, group = group[:room], group[room:]
+                dets = np.stack([np.asarray(tracking_results[pid]["bbox"][slot], np.float32) for _, pid, slot in part])
+                pend_batches.append(self.make_batch(fr, dets, bbox_scale))
+                pend_meta.extend((pid, slot) for _, pid, slot in part)
+                if len(pend_meta) == bs:
+                    flush()
+            i = j
+        flush()
+
+        results = {}
+        for pid, tr in tracking_results.items():
+            st = {k: np.stack(v) for k, v in store[pid].items()}
+            bboxes = np.asarray(tr["bbox"], np.float32).reshape(-1, 4)
+            pose, betas = st["pred_pose"], st["pred_shape"]
+            verts, j3d = st["smpl_vertices"], st["smpl_joints3d"]
+            if getattr(self.args, "smooth", False):               # tester.py:442-447
+                from .smooth import smooth_pose
+                verts, pose, j3d = smooth_pose(self.model, pose, betas, getattr(self.args, "min_cutoff", 0.004),
+                                               getattr(self.args, "beta", 1.5))
+            var = postproc.prepare_uncert(torch.from_numpy(st["var_pose"]), True)       # tester.py:416-419
+            results[pid] = {
+                "pred_cam": st["pred_cam"],
+                "orig_cam": postproc.convert_crop_cam_to_orig_img(st["pred_cam"], bboxes, orig_width, orig_height),
+                "verts": verts, "pose": pose, "betas": betas, "joints2d": None,
+                "smpl_joints3d": j3d,
+                "smpl_joints2d": postproc.convert_crop_coords_to_orig_img(bboxes, st["smpl_joints2d"],
+                                                                          self.model_cfg.DATASET.IMG_RES),
+                "var": var, "var_global": postproc.global_uncert(var, self.backbone, clip=False),
+                "bboxes": bboxes, "frame_ids": np.asarray(tr["frames"]),
+            }
+        return results
+
     def run_on_image_folder(self, image_folder: str, detections: Optional[dict], output_path: str, bbox_scale=1.0):
         from PIL import Image
         names = sorted(x for x in os.listdir(image_folder) if x.lower().endswith(IMG_EXT))
@@ -135,6 +209,43 @@ class POCOTester:
                 np.savez_compressed(os.path.join(output_path, os.path.splitext(n)[0] + "_poco.npz"), **r)
         return {"images": len(names), "crops": n_crops, "seconds": dt, "fps": len(names) / max(dt, 1e-9),
                 "crops_per_s": n_crops / max(dt, 1e-9)}
+
+
+def _run_on_video_folder(self, frame_folder: str, tracking_path: Optional[str], output_path: str, bbox_scale=1.0):
+    """demo.py --mode video on a folder of extracted frames (demo.py:60-160): per-track results written as
+    <output>/poco_results.npz (the reference joblib-dumps the same dict, demo.py:147-150)."""
+    from PIL import Image
+    names = sorted(x for x in os.listdir(frame_folder) if x.lower().endswith(IMG_EXT))
+    if not names:
+        raise FileNotFoundError(f"no frames in {frame_folder}")
+    first = np.asarray(Image.open(os.path.join(frame_folder, names[0])).convert("RGB"))
+    H, W = first.shape[:2]
+    if tracking_path:
+        with open(tracking_path) as f:
+            tracking = {k: {"bbox": np.asarray(v["bbox"], np.float32), "frames": np.asarray(v["frames"], np.int64)}
+                        for k, v in json.load(f).items()}
+    else:
+        s = float(min(H, W))
+        tracking = {"0": {"bbox": np.tile([[W / 2.0, H / 2.0, s, s]], (len(names), 1)).astype(np.float32),
+                          "frames": np.arange(len(names))}}
+    skip = max(int(getattr(self.args, "skip_frame", 1)), 1)
+    if skip > 1:
+        tracking = {k: {"bbox": v["bbox"][::skip], "frames": v["frames"][::skip]} for k, v in tracking.items()}
+    load = lambda i: np.asarray(Image.open(os.path.join(frame_folder, names[i])).convert("RGB"))   # noqa: E731
+    t0 = time.time()
+    results = self.run_on_video(tracking, load, W, H, bbox_scale)
+    torch.cuda.synchronize()
+    dt = time.time() - t0
+    os.makedirs(output_path, exist_ok=True)
+    flat = {f"{pid}/{k}": v for pid, r in results.items() for k, v in r.items() if v is not None}
+    np.savez_compressed(os.path.join(output_path, "poco_results.npz"), **flat)
+    n_crops = sum(len(v["frames"]) for v in tracking.values())
+    n_frames = len({int(f) for v in tracking.values() for f in v["frames"]})
+    return {"images": n_frames, "crops": n_crops, "tracks": len(tracking), "seconds": dt,
+            "fps": n_frames / max(dt, 1e-9), "crops_per_s": n_crops / max(dt, 1e-9)}
+
+
+POCOTester.run_on_video_folder = _run_on_video_folder
 
 
 def load_detections(path: Optional[str]) -> Optional[dict]:

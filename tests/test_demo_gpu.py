@@ -68,3 +68,78 @@ def test_demo_folder_end_to_end(tmp_path, cuda):
         assert np.abs(res["verts"] - ref["smpl_vertices"].numpy()).max() < 1e-3
         assert res["var_global"].shape == (len(d),) and res["var_global"].max() <= 0.99
         assert res["smpl_joints2d"].shape == (len(d), 49, 3)
+
+
+def _tester(tmp_path, variant="resnet50-cliff", cfg="configs/demo_poco_cliff_resnet50.yaml", extra=()):
+    import demo
+    from poco_amd.tester import POCOTester
+    w = util.synth_weights(variant)
+    ckpt = tmp_path / "poco_synth.pt"
+    torch.save({"state_dict": {"model." + k: torch.from_numpy(v) for k, v in w.items()}}, ckpt)
+    np.savez(tmp_path / "smpl.npz", **synth.synth_smpl(7))
+    args = demo.parse_args(["--cfg", cfg, "--ckpt", str(ckpt), "--mode", "video", "--vid_file", str(tmp_path),
+                            "--output_folder", str(tmp_path / "out"), "--batch_size", "5",
+                            "--smpl", str(tmp_path / "smpl.npz"), "--no_render", *extra])
+    return POCOTester(args), args
+
+
+def test_video_mode_tracks_match_frame_mode(tmp_path, cuda):
+    """run_on_video (frame-major packing across frames/people, ragged last batch, a person entering late) returns,
+    per track, exactly what the per-frame path regresses for the same boxes (tester.py:362-479 vs :153-245)."""
+    from poco_amd import postproc
+    t, _ = _tester(tmp_path)
+    r = np.random.default_rng(5)
+    frames = [r.integers(0, 256, (240, 320, 3), dtype=np.uint8) for _ in range(6)]
+    tracks = {
+        "a": {"bbox": np.array([[160 + 3 * i, 120, 150, 150] for i in range(6)], np.float32), "frames": np.arange(6)},
+        "b": {"bbox": np.array([[80, 100 + 2 * i, 90, 120] for i in range(4)], np.float32), "frames": np.arange(2, 6)},
+        "c": {"bbox": np.array([[250, 60, 70, 70]], np.float32), "frames": np.array([3])},
+    }
+    res = t.run_on_video(tracks, frames, 320, 240)
+    assert set(res) == {"a", "b", "c"}
+    for pid, tr in tracks.items():
+        per_frame = t.run_on_frames([frames[f] for f in tr["frames"]], [tr["bbox"][k:k + 1] for k in range(len(tr["frames"]))])
+        pose = np.concatenate([p["pose"] for p in per_frame])
+        verts = np.concatenate([p["verts"] for p in per_frame])
+        # different batch compositions -> different tile configurations: equal to rounding, not bitwise
+        assert np.abs(res[pid]["pose"] - pose).max() < 1e-5
+        assert np.abs(res[pid]["verts"] - verts).max() < 1e-5
+        assert res[pid]["verts"].shape == (len(tr["frames"]), 6890, 3)
+        assert res[pid]["smpl_joints2d"].shape == (len(tr["frames"]), 49, 2)
+        assert np.array_equal(res[pid]["frame_ids"], tr["frames"]) and res[pid]["joints2d"] is None
+        assert np.allclose(res[pid]["orig_cam"], postproc.convert_crop_cam_to_orig_img(res[pid]["pred_cam"], tr["bbox"], 320, 240))
+        assert res[pid]["var"].shape == (len(tr["frames"]), 24) and res[pid]["var_global"].shape == (len(tr["frames"]),)
+
+
+def test_video_mode_smoothing(tmp_path, cuda):
+    """--smooth: filtered pose = the pinned one-euro restatement; verts/joints = LBS of the filtered pose with each
+    frame's betas (smooth_pose.py:43-67), checked against the float64 oracle."""
+    from oracle import smooth_np
+    t, _ = _tester(tmp_path, extra=("--smooth",))
+    r = np.random.default_rng(6)
+    frames = [r.integers(0, 256, (200, 300, 3), dtype=np.uint8) for _ in range(7)]
+    tracks = {"p": {"bbox": np.array([[150 + 4 * i, 100, 120, 140] for i in range(7)], np.float32), "frames": np.arange(7)}}
+    t.args.smooth = False
+    raw = t.run_on_video(tracks, frames, 300, 200)["p"]
+    t.args.smooth = True
+    sm = t.run_on_video(tracks, frames, 300, 200)["p"]
+    v64, pose_hat, j64 = smooth_np.smooth_pose(raw["pose"], raw["betas"], synth.synth_smpl(7), 0.004, 1.5)
+    assert np.abs(sm["pose"] - pose_hat).max() < 1e-6
+    assert np.array_equal(sm["pose"][0], raw["pose"][0]) and np.abs(sm["pose"][3] - raw["pose"][3]).max() > 1e-4
+    assert np.abs(sm["verts"] - v64).max() < 1e-4 and np.abs(sm["smpl_joints3d"] - j64).max() < 1e-4
+
+
+def test_demo_video_cli(tmp_path, cuda):
+    from PIL import Image
+    import demo
+    fr = tmp_path / "frames"
+    fr.mkdir()
+    r = np.random.default_rng(1)
+    for i in range(3):
+        Image.fromarray(r.integers(0, 256, (120, 160, 3), dtype=np.uint8)).save(fr / f"{i:06d}.png")
+    t, args = _tester(tmp_path)
+    args.vid_file = str(fr)
+    stats = t.run_on_video_folder(str(fr), None, str(tmp_path / "out"))
+    assert stats["images"] == 3 and stats["crops"] == 3 and stats["tracks"] == 1
+    z = np.load(tmp_path / "out" / "poco_results.npz")
+    assert z["0/verts"].shape == (3, 6890, 3) and z["0/var_global"].shape == (3,)
