@@ -143,3 +143,30 @@ def test_demo_video_cli(tmp_path, cuda):
     assert stats["images"] == 3 and stats["crops"] == 3 and stats["tracks"] == 1
     z = np.load(tmp_path / "out" / "poco_results.npz")
     assert z["0/verts"].shape == (3, 6890, 3) and z["0/var_global"].shape == (3,)
+
+
+def test_crop_stream_matches_batch_path(tmp_path, cuda):
+    """poco_amd.stream.CropStream (pinned frame ring, GPU crops into the resident batch, graph replay, packed
+    253-float record) == POCOTester.make_batch + model(...) on the same frames / boxes."""
+    from poco_amd.stream import CropStream, REC
+    t, _ = _tester(tmp_path)
+    r = np.random.default_rng(9)
+    frames = [r.integers(0, 256, (180, 240, 3), dtype=np.uint8) for _ in range(3)]
+    boxes = [np.array([[120, 90, 100, 100], [60, 70, 50, 80]], np.float32), np.array([[200, 50, 70, 60]], np.float32),
+             np.array([[100, 100, 150, 120], [30, 40, 40, 40]], np.float32)]
+    cs = CropStream(t.model, (180, 240), batch=5, ring=4)
+    for rep in range(2):                       # second pass re-uses ring slots and the captured graph
+        groups = [(cs.upload(f), b) for f, b in zip(frames, boxes)]
+        rec, n = cs.run(groups, rep & 1)
+        torch.cuda.synchronize()
+        assert n == 5 and rec.shape == (5, REC)
+        rec = rec.numpy().copy()
+        row = 0
+        for f, b in zip(frames, boxes):
+            out = t.model(t.make_batch(torch.from_numpy(f).to(cuda), b), want_segm=False)
+            k = len(b)
+            assert np.abs(rec[row:row + k, :216] - out["pred_pose"].reshape(k, 216).cpu().numpy()).max() < 1e-5
+            assert np.abs(rec[row:row + k, 216:226] - out["pred_shape"].cpu().numpy()).max() < 1e-5
+            assert np.abs(rec[row:row + k, 226:229] - out["pred_cam"].cpu().numpy()).max() < 1e-5
+            assert np.abs(rec[row:row + k, 229:253] - out["var_pose"].cpu().numpy()).max() < 1e-5
+            row += k
