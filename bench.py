@@ -106,6 +106,9 @@ def main():
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--lanes", type=int, default=4, help="HIP streams for independent branches (1 = single stream)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay of the forward")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend (nccl = RCCL; gloo only to exercise the multi-rank path on a "
+                         "box with fewer GPUs than ranks: ranks then share devices round-robin)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -113,13 +116,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != max(1, args.gpus) and world > 1:
         raise SystemExit(f"WORLD_SIZE={world} but --gpus {args.gpus}")
-    device = torch.device(f"cuda:{local_rank}")
+    ndev = torch.cuda.device_count()
+    if args.backend == "nccl" and world > 1 and local_rank >= ndev:
+        raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but only {ndev} GPUs visible")
+    device = torch.device(f"cuda:{local_rank % max(ndev, 1)}")
     torch.cuda.set_device(device)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     from poco_amd import synth
     B = args.batch
@@ -137,7 +146,13 @@ def main():
         else:
             model.graph_forward(batch, out)
         if world > 1 and not args.no_gather:
-            dist.all_gather_into_tensor(gathered, pdist.pack_records(out))
+            rec = pdist.pack_records(out)
+            if args.backend == "nccl":
+                dist.all_gather_into_tensor(gathered, rec)          # RCCL over xGMI, device buffers
+            else:                                                   # gloo smoke path: staged through the host
+                parts = [torch.empty(B, pdist.REC) for _ in range(world)]
+                dist.all_gather(parts, rec.cpu())
+                gathered.copy_(torch.cat(parts, 0))
 
     for _ in range(args.warmup):
         step()
@@ -157,11 +172,31 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        t = torch.tensor([elapsed], device=device if args.backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     step_ms = [ev[i].elapsed_time(ev[i + 1]) for i in range(args.steps)]
     ev_ms = float(np.mean(step_ms))
+
+    dominant = None
+    if rank == 0 and world == 1:
+        # per-kernel view (HIP events around every op, launched back to back on ONE stream so kernels do not
+        # overlap): group the conv ops by the kernel symbol they launch, pick the symbol with the most time
+        from collections import defaultdict
+        model.set_num_lanes(1)
+        prof = model.profile_ops(batch, iters=5)
+        model.set_num_lanes(args.lanes)
+        agg = defaultdict(lambda: [0, 0.0, 0.0])
+        for i, (nm, fl, ty, ms) in enumerate(prof):
+            d = model.conv_desc(i)
+            if d is None:
+                continue
+            a = agg[model.kernel_symbol(d, model.conv_cfg(i, B))]
+            a[0] += 1; a[1] += ms; a[2] += fl * B
+        sym, (n, ms, fl) = max(agg.items(), key=lambda kv: kv[1][1])
+        dominant = {"kernel": sym, "launches_per_step": n, "avg_us": round(ms / n * 1e3, 2),
+                    "share_of_kernel_time": round(ms / sum(p[3] for p in prof), 3),
+                    "gflop_per_launch": round(fl / n / 1e9, 3), "tflops": round(fl / (ms * 1e-3) / 1e12, 2)}
 
     if rank == 0:
         value = world * B * args.steps / elapsed
@@ -175,13 +210,18 @@ def main():
             "config": {"workload": f"{args.variant} forward (backbone+head+SMPL-LBS+confidence MLP), "
                                    f"{B} crops/GPU of 224x224, fp32 MFMA", "variant": args.variant,
                        "crops_per_gpu": B, "global_batch": world * B,
-                       "parallelism": f"dp{world} (crop sharding" + (", RCCL all-gather of 254-float SMPL records)" if world > 1 and not args.no_gather else ")")},
+                       "parallelism": f"dp{world} (crop sharding" + (f", {'RCCL' if args.backend == 'nccl' else 'gloo (smoke path)'} all-gather of 254-float SMPL records)"
+                                                                          if world > 1 and not args.no_gather else ")")},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": pmc_traffic(args.variant, B),
-                         "note": f"algorithmic {flops_per_crop/1e9:.3f} GFLOP/crop x {B} crops per forward / mean HIP-event "
-                                 f"forward time {ev_ms:.3f} ms on the launch stream; conv_mfma_kernel launches are >97% of it "
-                                 "(profiles/)"},
+                         "note": f"whole forward: algorithmic {flops_per_crop/1e9:.3f} GFLOP/crop x {B} crops / mean "
+                                 f"HIP-event forward time {ev_ms:.3f} ms on the launch stream (MFMA conv kernels are >96% "
+                                 "of the kernel time, profiles/); `dominant` = the kernel symbol with the most time, "
+                                 "algorithmic flops of its launches / their HIP-event time on one stream"},
         }
+        if dominant is not None:
+            dominant["frac"] = round(dominant["tflops"] / PEAK_F32_MFMA_TFLOPS, 4)
+            line["roofline"]["dominant"] = dominant
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.variant)
         print(json.dumps(line), flush=True)

@@ -100,6 +100,9 @@ size_t poco_workspace_bytes(poco_handle_t h);
 int poco_uncert_feat_dim(poco_handle_t h);
 int poco_set_conv_cfg(poco_handle_t h, int op_index, int B, const int* cfg7);
 int poco_get_conv_desc(poco_handle_t h, int op_index, int* desc8);
+/* the tile configuration (7 ints, csrc/common.h) conv op `op_index` runs with at batch size B: the value set by
+ * poco_set_conv_cfg or, without one, the built-in heuristic's choice. */
+int poco_get_conv_cfg(poco_handle_t h, int op_index, int B, int* cfg7);
 
 /* SMPL linear blend skinning with the engine's loaded body model: replaces
  * smplx.SMPL.forward(pose2rot=False) as wrapped by pocolib/models/head/smpl_head.py:22-34.

@@ -1264,6 +1264,28 @@ extern "C" int poco_set_conv_cfg(poco_handle_t h, int op_index, int B, const int
   return POCO_OK;
 }
 
+extern "C" int poco_get_conv_cfg(poco_handle_t h, int op_index, int B, int* cfg7) {
+  Engine* e = H(h);
+  if (!e || op_index < 0 || op_index >= (int)e->ops.size() || !cfg7 || e->ops[op_index].type != OP_CONV || B < 1) {
+    poco_set_error("poco_get_conv_cfg: bad arguments");
+    return POCO_ERR_ARG;
+  }
+  const Op& op = e->ops[op_index];
+  ConvCfg c;
+  auto it = op.cfg.find(B);
+  if (it != op.cfg.end()) c = it->second;
+  else {
+    const Act& ai = e->acts[op.in.act];
+    ConvDesc d{};
+    d.B = B; d.H = ai.H; d.W = ai.W; d.Cin = op.Cin; d.Cout = op.Cout; d.ks = op.ks; d.stride = op.stride;
+    d.in_cs = ai.C; d.out_cs = e->acts[op.out.act].C; d.act = op.actfn;
+    c = conv_default_cfg(d);
+  }
+  const int v[7] = {c.MT, c.NT, c.WM, c.WN, c.R, c.NI, c.ALG};
+  for (int k = 0; k < 7; ++k) cfg7[k] = v[k];
+  return POCO_OK;
+}
+
 extern "C" int poco_get_conv_desc(poco_handle_t h, int op_index, int* desc8) {
   Engine* e = H(h);
   if (!e || op_index < 0 || op_index >= (int)e->ops.size() || !desc8) return POCO_ERR_ARG;

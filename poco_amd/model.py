@@ -52,6 +52,7 @@ def _bind():
     L.poco_uncert_feat_dim.argtypes = [C.c_void_p]
     L.poco_set_conv_cfg.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int)]
     L.poco_get_conv_desc.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+    L.poco_get_conv_cfg.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int)]
     L.poco_set_num_lanes.argtypes = [C.c_void_p, C.c_int]
     L.poco_smpl_lbs.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 5
     L.poco_realnvp.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
@@ -300,6 +301,22 @@ class POCO:
         d = (C.c_int * 8)()
         rc = self._L.poco_get_conv_desc(self._h, op_index, d)
         return None if rc != 0 else tuple(d)
+
+    def conv_cfg(self, op_index: int, B: int):
+        """(MT,NT,WM,WN,R,NI,ALG) conv op `op_index` runs with at batch size B."""
+        self._apply_tuned(B)
+        c = (C.c_int * 7)()
+        check(self._L.poco_get_conv_cfg(self._h, op_index, B, c), "poco_get_conv_cfg")
+        return tuple(c)
+
+    @staticmethod
+    def kernel_symbol(desc, cfg) -> str:
+        """Name of the HIP kernel template instance a conv op launches (as rocprofv3 prints it)."""
+        MT, NT, WM, WN, R, NI, ALG = cfg
+        ks, st = desc[4], desc[5]
+        return {0: f"conv_mfma_kernel<{ks}, {st}, {MT}, {NT}>", 1: f"conv_dma_kernel<{ks}, {st}, {MT}, {NT}>",
+                2: f"conv_dma_persist_kernel<{ks}, {st}, {MT}, {NT}>", 3: f"conv_wino_kernel<{NT}>",
+                4: f"conv_wino2_kernel<{NT}>", 5: "linear_mfma_kernel"}[ALG]
 
     def set_conv_cfg(self, op_index: int, B: int, cfg) -> None:
         arr = (C.c_int * 7)(*(tuple(cfg) + (0,) * (7 - len(cfg))))
