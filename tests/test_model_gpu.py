@@ -161,3 +161,31 @@ def test_realnvp_op(variant, L, cuda):
     assert np.abs(fw - ref_fw).max() < 1e-3 * max(1.0, np.abs(ref_fw).max())
     back, _ = poco_ref.realnvp_backward(sd, torch.from_numpy(fw), c)
     assert np.abs(back.numpy() - x.numpy()).max() < 1e-3
+
+
+@pytest.mark.parametrize("variant,B", [("hrnet_w48_cls-cliff", 64), ("hrnet_w32-pare", 32), ("resnet50-cliff", 128)])
+def test_full_size_properties(variant, B, cuda):
+    """Size-independent properties at BASELINE.json's batch sizes (where the CPU oracle would take minutes):
+    crops are independent, so (1) permuting the batch permutes the rows BITWISE (tiles of different crops share
+    MFMA blocks but never mix), (2) duplicated crops give identical rows, (3) the returned mesh is exactly the
+    stand-alone LBS operator applied to the returned parameters, (4) confidences are sigmoids, rotations
+    orthonormal (rot6d_to_rotmat, geometry.py:247-261)."""
+    m = util.make_engine(variant, max_batch=B)
+    bnp = synth.synth_batch(B, 99)
+    for k in bnp:                                  # duplicates: crop 1 := crop 0, last := first
+        bnp[k][1] = bnp[k][0]
+        bnp[k][B - 1] = bnp[k][0]
+    batch = util.cuda_batch(bnp, cuda)
+    out = {k: v.clone() for k, v in m(batch).items() if torch.is_tensor(v)}
+    perm = torch.from_numpy(np.random.default_rng(3).permutation(B)).to(cuda)
+    outp = m({k: v[perm].contiguous() for k, v in batch.items()})
+    for k in ("pred_pose", "pred_shape", "pred_cam", "var_pose", "smpl_vertices", "smpl_joints2d", "uncert_feat"):
+        assert torch.equal(outp[k], out[k][perm]), k
+        assert torch.equal(out[k][0], out[k][1]) and torch.equal(out[k][0], out[k][B - 1]), k
+    v, j = m.smpl_lbs(out["pred_shape"], out["pred_pose"].contiguous())
+    assert torch.equal(v, out["smpl_vertices"]) and torch.equal(j, out["smpl_joints3d"])
+    R = out["pred_pose"].reshape(-1, 3, 3)
+    eye = torch.eye(3, device=cuda).expand_as(R)
+    assert float((R @ R.transpose(1, 2) - eye).abs().max()) < 1e-5 and float((torch.linalg.det(R) - 1).abs().max()) < 1e-5
+    assert float(out["var_pose"].min()) > 0.0 and float(out["var_pose"].max()) < 1.0
+    assert all(bool(torch.isfinite(t).all()) for t in out.values())
