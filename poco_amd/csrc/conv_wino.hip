@@ -669,7 +669,13 @@ int conv_wino_launch(const ConvDesc& d, const ConvCfg& cfg, hipStream_t stream) 
     p.nblocks_m = g.nblocks_m; p.nb_n = (p.nT16 + cfg.NT - 1) / cfg.NT;
     const long tiles4 = (long)p.nblocks_m * p.nb_n;
     const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(2, (160 * 1024) / std::max<size_t>(lds4, 1)));
-    dim3 grid4((unsigned)std::min<long>(tiles4, 256L * per_cu), 1);
+    // balanced persistent grid: every block walks the same number of tiles (896 tiles -> 224 blocks x 4 instead of
+    // 256 blocks doing 4 or 3), which takes the same time and leaves the spare CUs to the other lanes' kernels
+    const long cap4 = 256L * per_cu;
+    const long rounds4 = (tiles4 + cap4 - 1) / cap4;
+    long g4 = (tiles4 + rounds4 - 1) / rounds4;
+    if (g4 > 8) g4 = std::min(cap4, (g4 + 7) / 8 * 8);      // multiple of 8 for the XCD-aware walk
+    dim3 grid4((unsigned)g4, 1);
     auto fn4 = cfg.NT == 3 ? conv_wino2_kernel<3> : cfg.NT == 2 ? conv_wino2_kernel<2> : conv_wino2_kernel<1>;
     if (lds4 > 64 * 1024) {
       static thread_local bool configured4[4] = {false, false, false, false};

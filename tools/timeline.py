@@ -1,0 +1,41 @@
+"""Analyse a rocprofv3 --kernel-trace CSV of bench.py: GPU-busy fraction, concurrency, per-stream gaps."""
+import csv
+import sys
+from collections import defaultdict
+
+rows = list(csv.DictReader(open(sys.argv[1])))
+ks = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Stream_Id", r.get("Queue_Id", "0"))) for r in rows]
+ks.sort()
+# last forward = between the last two stem kernels
+stems = [i for i, k in enumerate(ks) if "stem_conv" in k[2]]
+lo, hi = stems[-2], stems[-1]
+fw = ks[lo:hi]
+t0, t1 = fw[0][0], max(k[1] for k in fw)
+print(f"forward {(t1 - t0) / 1e3:.1f} us, {len(fw)} kernels")
+ev = []
+for s, e, n, q in fw:
+    ev.append((s, 1)); ev.append((e, -1))
+ev.sort()
+busy = {0: 0, 1: 0, 2: 0, 3: 0, 4: 0}
+cur, last = 0, t0
+for t, d in ev:
+    busy[min(cur, 4)] += t - last
+    cur += d; last = t
+tot = t1 - t0
+print("concurrency histogram (fraction of wall time with k kernels resident):", {k: round(v / tot, 3) for k, v in busy.items()})
+per = defaultdict(list)
+for s, e, n, q in fw:
+    per[q].append((s, e, n))
+for q, lst in per.items():
+    lst.sort()
+    gaps = [lst[i + 1][0] - lst[i][1] for i in range(len(lst) - 1)]
+    small = [g for g in gaps if 0 <= g < 20000]
+    print(f"queue {q}: {len(lst)} kernels, busy {sum(e - s for s, e, _ in lst) / 1e3:.0f} us, "
+          f"median back-to-back gap {sorted(small)[len(small) // 2] / 1e3 if small else -1:.2f} us, sum small gaps {sum(small) / 1e3:.0f} us")
+# per-kernel-name average duration in this forward
+agg = defaultdict(lambda: [0, 0])
+for s, e, n, q in fw:
+    a = agg[n.split("(")[0][-40:]]
+    a[0] += 1; a[1] += e - s
+for n, (c, d) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:8]:
+    print(f"  {n:42s} n={c:4d} sum {d / 1e3:8.0f} us avg {d / c / 1e3:7.1f} us")
