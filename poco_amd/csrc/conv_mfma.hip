@@ -187,35 +187,82 @@ conv_mfma_kernel(const ConvKParams p) {
   const bool nvalid = nt0 < p.nT16;   // wave-uniform (grid.y may overshoot when WN does not divide)
   const int total_units = ((p.npos + 7) >> 3) << 5;   // (pos rounded to 8) * 4 quads
 
+  // Register-staged pipeline: a thread's patch units (position, channel quad) are decoded ONCE (their global
+  // offsets stay in registers), the loads of slice c+1 are issued right after the barrier and ride under the
+  // MFMAs of slice c, and land in LDS after the next barrier.  Falls back to decode-per-slice for big patches.
+  constexpr int MAXU = (MT <= 7) ? 12 : 0;
+  const bool reg_stage = MAXU > 0 && total_units <= MAXU * nthreads;     // block-uniform
+  auto unit_pos = [&](int u, int* q) {
+    const int w = u & 31;
+    *q = w >> 3;
+    return (uint32_t)(((u >> 5) << 3) + (w & 7));
+  };
+  auto unit_goff = [&](uint32_t pos, int q) -> int {       // float offset of (pos, q) in slice 0, -1 = zero padding
+    if (pos >= (uint32_t)p.npos) return -1;
+    const uint32_t sl = fdiv(pos, p.dSlab);
+    const uint32_t rem = pos - sl * p.dSlab.d;
+    const uint32_t prow = fdiv(rem, p.dPW);
+    const uint32_t pcol = rem - prow * p.dPW.d;
+    const uint32_t s = s0 + sl;
+    const uint32_t b = fdiv(s, p.dBands);
+    const uint32_t band = s - b * p.dBands.d;
+    const int iy = (int)(band * p.R) * STRIDE - PAD + (int)prow;
+    const int ix = (int)pcol - PAD;
+    if (s < (uint32_t)p.S && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
+      return (int)((size_t)(b * p.H + iy) * p.in_rs + ix * 16 + q * 4);
+    return -1;
+  };
+  int uoff[MAXU > 0 ? MAXU : 1];
+  float4 st[MAXU > 0 ? MAXU : 1];
+  if (reg_stage) {
+#pragma unroll
+    for (int k = 0; k < MAXU; ++k) {
+      const int u = tid + k * nthreads;
+      int q;
+      const uint32_t pos = unit_pos(u, &q);
+      uoff[k] = (u < total_units) ? unit_goff(pos, q) : -1;
+    }
+  }
+  auto gload = [&](int c) {                     // unconditional loads (dead units read offset 0) + select
+#pragma unroll
+    for (int k = 0; k < MAXU; ++k)
+      st[k] = *reinterpret_cast<const float4*>(p.in + (size_t)max(uoff[k], 0) + (size_t)c * p.in_ss);
+  };
+  auto lwrite = [&]() {
+#pragma unroll
+    for (int k = 0; k < MAXU; ++k) {
+      const int u = tid + k * nthreads;
+      if (u < total_units) {
+        int q;
+        const uint32_t pos = unit_pos(u, &q);
+        if (pos < (uint32_t)p.npos) patch[q * p.planeF4 + pos] = (uoff[k] >= 0) ? st[k] : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+  };
+  if (reg_stage) gload(0);
+
   const int nIter = p.nC16 * p.repeat;   // repeat > 1 only for profiling experiments
   for (int it = 0; it < nIter; ++it) {
     const int c = it % p.nC16;
     if (it > 0) __syncthreads();
     // ---- stage the 16-channel slice c of the halo patch ------------------------------------
+    if (reg_stage) {
+      lwrite();
+    } else {
 #pragma unroll 4
-    for (int u = tid; u < total_units; u += nthreads) {
-      const int w = u & 31;
-      const int q = w >> 3;
-      const uint32_t pos = (uint32_t)(((u >> 5) << 3) + (w & 7));
-      if (pos < (uint32_t)p.npos) {
-        const uint32_t sl = fdiv(pos, p.dSlab);
-        const uint32_t rem = pos - sl * p.dSlab.d;
-        const uint32_t prow = fdiv(rem, p.dPW);
-        const uint32_t pcol = rem - prow * p.dPW.d;
-        const uint32_t s = s0 + sl;
-        const uint32_t b = fdiv(s, p.dBands);
-        const uint32_t band = s - b * p.dBands.d;
-        const int iy = (int)(band * p.R) * STRIDE - PAD + (int)prow;
-        const int ix = (int)pcol - PAD;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (s < (uint32_t)p.S && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) {
-          const size_t off = (size_t)(b * p.H + iy) * p.in_rs + (size_t)c * p.in_ss + ix * 16 + q * 4;
-          v = *reinterpret_cast<const float4*>(p.in + off);
+      for (int u = tid; u < total_units; u += nthreads) {
+        int q;
+        const uint32_t pos = unit_pos(u, &q);
+        if (pos < (uint32_t)p.npos) {
+          const int off = unit_goff(pos, q);
+          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (off >= 0) v = *reinterpret_cast<const float4*>(p.in + (size_t)off + (size_t)c * p.in_ss);
+          patch[q * p.planeF4 + pos] = v;
         }
-        patch[q * p.planeF4 + pos] = v;
       }
     }
     __syncthreads();
+    if (reg_stage && it + 1 < nIter) gload((it + 1) % p.nC16);   // in flight during this slice's MFMAs
 
     if (nvalid) {
       const float4* wc = p.wfrag + ((size_t)c * p.nT16 + nt0) * 64 + lane;
