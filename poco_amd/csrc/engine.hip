@@ -371,10 +371,16 @@ struct Builder {
 
   // HighResolutionModule.forward, hrnet.py:248-266.  last_into: write branch-0 output into a wider
   // concat buffer (POCO-PARE's 480-channel feature map) instead of a fresh tensor.
-  std::vector<int> hr_module(const std::string& p, std::vector<int> xs, const std::vector<int>& ch, Ref out0 = Ref()) {
+  // keep_open: the module is followed by another module of the same stage -> its fuse sums and the next module's
+  // branch chains form ONE parallel region (lane i = sum_i, then the 8 convs of branch i): one join less per
+  // module, and a lane's sum overlaps the other lanes' first convs.
+  bool region_open = false;
+  std::vector<int> hr_module(const std::string& p, std::vector<int> xs, const std::vector<int>& ch, Ref out0 = Ref(),
+                             bool keep_open = false) {
     const int nb = (int)xs.size();
     // phase 1: the branches are independent chains of 8 convs -> one lane (HIP stream) each
-    begin_parallel(1);
+    if (!region_open) begin_parallel(1);
+    region_open = false;
     static const std::string lmap = [] { const char* v = getenv("POCO_BRANCH_LANES"); return std::string(v ? v : "0123"); }();
     for (int i = 0; i < nb; ++i) {
       lane(i < (int)lmap.size() ? lmap[i] - '0' : i);
@@ -438,7 +444,8 @@ struct Builder {
       if (i == 0 && out0.act >= 0) { outs[i] = out0.act; fuse_sum(p + ".fuse" + std::to_string(i), terms[i], ch[i], out0, 1); }
       else { outs[i] = new_act(a.C, a.H, a.W); fuse_sum(p + ".fuse" + std::to_string(i), terms[i], ch[i], R(outs[i]), 1); }
     }
-    end_parallel();
+    if (keep_open && !((seq_mask >> 7) & 1)) region_open = true;
+    else end_parallel();
     return outs;
   }
 
@@ -474,7 +481,8 @@ struct Builder {
       end_parallel();
       for (int m = 0; m < nmod[s]; ++m) {
         const bool last = (s == 2 && m == nmod[s] - 1);
-        xs = hr_module(p + "stage" + std::to_string(s + 2) + "." + std::to_string(m), xs, ch, last ? final_out0 : Ref());
+        xs = hr_module(p + "stage" + std::to_string(s + 2) + "." + std::to_string(m), xs, ch, last ? final_out0 : Ref(),
+                       m + 1 < nmod[s]);
       }
       ys = xs;
       prev_ch = ch;
