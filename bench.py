@@ -106,6 +106,9 @@ def main():
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--lanes", type=int, default=4, help="HIP streams for independent branches (1 = single stream)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay of the forward")
+    ap.add_argument("--no-dominant", action="store_true",
+                    help="skip the per-op HIP-event pass behind roofline.dominant (use under rocprofv3 so that the "
+                         "kernel statistics contain only the warm-up + timed forwards)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend (nccl = RCCL; gloo only to exercise the multi-rank path on a "
                          "box with fewer GPUs than ranks: ranks then share devices round-robin)")
@@ -179,7 +182,7 @@ def main():
     ev_ms = float(np.mean(step_ms))
 
     dominant = None
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not args.no_dominant:
         # per-kernel view (HIP events around every op, launched back to back on ONE stream so kernels do not
         # overlap): group the conv ops by the kernel symbol they launch, pick the symbol with the most time
         from collections import defaultdict

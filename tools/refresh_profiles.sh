@@ -13,7 +13,7 @@ python $R/bench.py --steps 30 --warmup 5 --variant hrnet_w32-pare --batch 32 2>/
 python $R/bench.py --steps 30 --warmup 5 --no-graph --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/${TAG}_bench_hrnet_w48_cls-cliff_nograph.json
 for L in 1 4; do
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ks_l$L -o bench -- \
-    python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-graph --lanes $L > $OUT/ks_l$L.log 2>&1
+    python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-dominant --no-graph --lanes $L > $OUT/ks_l$L.log 2>&1
   cp $OUT/ks_l$L/*/*kernel_stats.csv $OUT/${TAG}_bench_w48cliff_b64_lanes${L}_kernel_stats.csv 2>/dev/null || \
     cp $OUT/ks_l$L/*kernel_stats.csv $OUT/${TAG}_bench_w48cliff_b64_lanes${L}_kernel_stats.csv
   rm -rf $OUT/ks_l$L
