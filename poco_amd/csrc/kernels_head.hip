@@ -21,7 +21,7 @@ attn_pool_partial_kernel(const float* __restrict__ heat, int heat_cs, const floa
   };
   __shared__ float red[256 / 64][NPART];
   __shared__ float mloc[NPART];
-  __shared__ float wt[PTILE][NPART];
+  __shared__ __attribute__((aligned(16))) float wt[PTILE][NPART];
   const int b = blockIdx.x, s = blockIdx.y, tid = threadIdx.x;
   const int per = (HW + nsplit - 1) / nsplit;
   const int p0 = s * per, p1 = min(HW, p0 + per);
@@ -46,48 +46,71 @@ attn_pool_partial_kernel(const float* __restrict__ heat, int heat_cs, const floa
   if (tid < NPART) mloc[tid] = fmaxf(fmaxf(red[0][tid], red[1][tid]), fmaxf(red[2][tid], red[3][tid]));
   __syncthreads();
   // ---- weighted accumulation ----
-  const int groups = 256 / C;            // pixel lanes per channel (C = 64 -> 4, C = 128 -> 2)
-  const int c = tid % C, pg = tid / C;
-  float acc[NPART];
+  // L16 features: a wave reads 4 neighbouring pixels x one 16-channel slice = 256 contiguous bytes per step.
+  // thread = (channel-in-slice tid&15, pixel lane (tid>>4)&3, wave = slice cb, cb+4 for C = 128)
+  const int chl = tid & 15, pl = (tid >> 4) & 3, wv = tid >> 6;
+  const int nkb = (C / 16 + 3) / 4;        // slices per wave (1 for C = 64, 2 for C = 128)
+  float acc[2][NPART];
 #pragma unroll
-  for (int j = 0; j < NPART; ++j) acc[j] = 0.f;
+  for (int k = 0; k < 2; ++k)
+#pragma unroll
+    for (int j = 0; j < NPART; ++j) acc[k][j] = 0.f;
   float lsum = 0.f;                      // threads < 24 accumulate the softmax denominators
   for (int t0 = p0; t0 < p1; t0 += PTILE) {
     const int np = min(PTILE, p1 - t0);
-    for (int i = tid; i < PTILE * NPART; i += 256) {
-      const int pp = i / NPART, j = i - pp * NPART;
-      wt[pp][j] = (pp < np) ? __expf(heat[at(b, t0 + pp, 1 + j, heat_cs)] - mloc[j]) : 0.f;
+    float hv[PTILE * NPART / 256];
+#pragma unroll
+    for (int u = 0; u < PTILE * NPART / 256; ++u) {          // all 6 loads in flight
+      const int i = tid + u * 256, pp = i / NPART, j = i - pp * NPART;
+      hv[u] = heat[at(b, t0 + min(pp, np - 1), 1 + j, heat_cs)];
+    }
+#pragma unroll
+    for (int u = 0; u < PTILE * NPART / 256; ++u) {
+      const int i = tid + u * 256, pp = i / NPART, j = i - pp * NPART;
+      wt[pp][j] = (pp < np) ? __expf(hv[u] - mloc[j]) : 0.f;
     }
     __syncthreads();
     if (tid < NPART)
       for (int pp = 0; pp < np; ++pp) lsum += wt[pp][tid];
-    if (pg < groups)
-      for (int pp = pg; pp < np; pp += groups) {
-        const float f = feat[at(b, t0 + pp, c, C)];
 #pragma unroll
-        for (int j = 0; j < NPART; ++j) acc[j] = fmaf(wt[pp][j], f, acc[j]);
-      }
+    for (int k = 0; k < 2; ++k) {
+      const int cb = wv + k * 4;
+      if (k < nkb && cb * 16 < C)
+        for (int pp0 = pl; pp0 < np; pp0 += 16) {
+          // 4 feature loads in flight per thread (the loop is latency-bound: ~1 wave per SIMD); rows >= np of wt are 0
+          float f[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) f[u] = feat[at(b, t0 + min(pp0 + 4 * u, np - 1), cb * 16 + chl, C)];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const float4* w4 = reinterpret_cast<const float4*>(&wt[min(pp0 + 4 * u, PTILE - 1)][0]);   // broadcast b128 reads
+            const float m = (pp0 + 4 * u < np) ? f[u] : 0.f;
+#pragma unroll
+            for (int j4 = 0; j4 < NPART / 4; ++j4) {
+              const float4 w = w4[j4];
+              acc[k][j4 * 4] = fmaf(w.x, m, acc[k][j4 * 4]); acc[k][j4 * 4 + 1] = fmaf(w.y, m, acc[k][j4 * 4 + 1]);
+              acc[k][j4 * 4 + 2] = fmaf(w.z, m, acc[k][j4 * 4 + 2]); acc[k][j4 * 4 + 3] = fmaf(w.w, m, acc[k][j4 * 4 + 3]);
+            }
+          }
+        }
+    }
     __syncthreads();
   }
-  // reduce the pixel lanes of each channel through LDS (re-using wt as [groups][C][24] is too big
-  // for C=128 -> do it in two halves of 12 parts)
   float* sc = scratch + ((size_t)b * nsplit + s) * (2 * NPART + (size_t)C * NPART);
   if (tid < NPART) { sc[tid] = mloc[tid]; sc[NPART + tid] = lsum; }
   float* accout = sc + 2 * NPART;
-  float* lds = &wt[0][0];                // PTILE*NPART = 1536 floats
-  for (int half = 0; half < 2; ++half) {
-    for (int gsel = 1; gsel < groups; ++gsel) {
-      __syncthreads();
-      if (pg == gsel)
-        for (int j = 0; j < 12; ++j) lds[c * 12 + j] = acc[half * 12 + j];
-      __syncthreads();
-      if (pg == 0)
-        for (int j = 0; j < 12; ++j) acc[half * 12 + j] += lds[c * 12 + j];
+  // the 4 pixel lanes of a channel sit 16 lanes apart in the same wave
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int cb = wv + k * 4;
+#pragma unroll
+    for (int j = 0; j < NPART; ++j) {
+      float v = acc[k][j];
+      v += __shfl_xor(v, 16);
+      v += __shfl_xor(v, 32);
+      if (pl == 0 && k < nkb && cb * 16 < C) accout[(cb * 16 + chl) * NPART + j] = v;
     }
   }
-  if (pg == 0)
-#pragma unroll
-    for (int j = 0; j < NPART; ++j) accout[c * NPART + j] = acc[j];
 }
 
 // Stage 2: combine splits.  thread = (b, c, j)
@@ -160,7 +183,7 @@ __global__ void nhwc_to_nchw_kernel(const float* __restrict__ in, int cs, float*
 }
 
 inline int nblk(long n, int t) { return (int)((n + t - 1) / t); }
-constexpr int ATTN_NSPLIT = 7;
+constexpr int ATTN_NSPLIT = 14;
 
 }  // namespace
 
