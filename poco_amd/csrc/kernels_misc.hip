@@ -54,6 +54,68 @@ stem_conv_kernel(const float* __restrict__ img, const float* __restrict__ w, con
     o[i] = make_float4(fmaxf(acc[i].x, 0.f), fmaxf(acc[i].y, 0.f), fmaxf(acc[i].z, 0.f), fmaxf(acc[i].w, 0.f));
 }
 
+// Register-tiled variant: a thread owns 4 horizontally adjacent output pixels x 16 channels, so one broadcast
+// weight read (float4 from LDS) feeds 4 pixels and one image row segment (6 + KS floats) feeds all KS taps:
+// 16 FMAs per LDS read instead of 4 (the 1-pixel kernel above is LDS-issue-bound).  Needs Wo % 4 == 0.
+template <int KS>
+__global__ void __launch_bounds__(256)
+stem_conv4_kernel(const float* __restrict__ img, const float* __restrict__ w, const float* __restrict__ shift,
+                  float* __restrict__ out, int B, int H, int W, int Ho, int Wo) {
+  constexpr int K = KS * KS * 3;
+  constexpr int PAD = (KS - 1) / 2;
+  constexpr int NV = 6 + KS;               // input columns under 4 stride-2 outputs
+  __shared__ float4 ws[K * 16];
+  for (int i = threadIdx.x; i < K * 16; i += 256) ws[i] = reinterpret_cast<const float4*>(w)[i];
+  __syncthreads();
+  const int g = threadIdx.x & 3;
+  const int Wq = Wo >> 2;
+  const long quad = (long)blockIdx.x * 64 + (threadIdx.x >> 2);
+  if (quad >= (long)B * Ho * Wq) return;
+  const int xo0 = (int)(quad % Wq) * 4;
+  const int yo = (int)((quad / Wq) % Ho);
+  const int b = (int)(quad / ((long)Wq * Ho));
+  float4 acc[4][4];
+#pragma unroll
+  for (int px = 0; px < 4; ++px)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[px][i] = reinterpret_cast<const float4*>(shift)[g * 4 + i];
+  const float* ib = img + (size_t)b * 3 * H * W;
+  const int ix0 = xo0 * 2 - PAD;
+#pragma unroll 1
+  for (int c = 0; c < 3; ++c) {
+#pragma unroll 1
+    for (int r = 0; r < KS; ++r) {
+      const int iy = yo * 2 - PAD + r;
+      if ((unsigned)iy >= (unsigned)H) continue;
+      const float* row = ib + ((size_t)c * H + iy) * W;
+      float v[NV];
+#pragma unroll
+      for (int j = 0; j < NV; ++j) v[j] = ((unsigned)(ix0 + j) < (unsigned)W) ? row[ix0 + j] : 0.f;
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        const float4* wk = ws + ((r * KS + s) * 3 + c) * 16 + g * 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float4 wv = wk[i];
+#pragma unroll
+          for (int px = 0; px < 4; ++px) {
+            const float x = v[2 * px + s];
+            acc[px][i].x = fmaf(x, wv.x, acc[px][i].x); acc[px][i].y = fmaf(x, wv.y, acc[px][i].y);
+            acc[px][i].z = fmaf(x, wv.z, acc[px][i].z); acc[px][i].w = fmaf(x, wv.w, acc[px][i].w);
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int px = 0; px < 4; ++px) {
+    float4* o = reinterpret_cast<float4*>(out) + L16_F4((size_t)b * Ho + yo, xo0 + px, g * 4, Wo, 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      o[i] = make_float4(fmaxf(acc[px][i].x, 0.f), fmaxf(acc[px][i].y, 0.f), fmaxf(acc[px][i].z, 0.f), fmaxf(acc[px][i].w, 0.f));
+  }
+}
+
 __global__ void maxpool_kernel(const float4* __restrict__ in, float4* __restrict__ out, int B, int H, int W,
                                int Ho, int Wo, int C4) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -169,7 +231,13 @@ void launch_stem_conv(const float* img, const float* w, const float* shift, floa
   const int pad = (ks - 1) / 2;
   const int Ho = (H + 2 * pad - ks) / 2 + 1, Wo = (W + 2 * pad - ks) / 2 + 1;
   const long npix = (long)B * Ho * Wo;
-  if (ks == 3)
+  if (Wo % 4 == 0) {            // 4 pixels per thread
+    const long nquad = npix / 4;
+    if (ks == 3)
+      hipLaunchKernelGGL(stem_conv4_kernel<3>, dim3(nblk(nquad, 64)), dim3(256), 0, s, img, w, shift, out, B, H, W, Ho, Wo);
+    else
+      hipLaunchKernelGGL(stem_conv4_kernel<7>, dim3(nblk(nquad, 64)), dim3(256), 0, s, img, w, shift, out, B, H, W, Ho, Wo);
+  } else if (ks == 3)
     hipLaunchKernelGGL(stem_conv_kernel<3>, dim3(nblk(npix, 64)), dim3(256), 0, s, img, w, shift, out, B, H, W, Ho, Wo);
   else
     hipLaunchKernelGGL(stem_conv_kernel<7>, dim3(nblk(npix, 64)), dim3(256), 0, s, img, w, shift, out, B, H, W, Ho, Wo);
