@@ -640,12 +640,20 @@ bool build_graph(Engine& e, bool declare) {
   } else if (e.backbone == "hrnet_w48_cls") {
     std::vector<int> ys = b.hrnet_trunk(bp, 48);
     const int hc[4] = {32, 64, 128, 256};
-    int y = b.bottleneck(bp + "incre_modules.0.0", ys[0], 48, hc[0], 1, true);
+    // the four incre_modules (one Bottleneck per resolution, hrnet_cls.py:306-321) are independent and small
+    // (20-50 us kernels): one lane each, then the sequential downsample chain
+    int inc[4];
+    b.begin_parallel(8);
+    for (int i = 0; i < 4; ++i) {
+      b.lane(i);
+      inc[i] = b.bottleneck(bp + "incre_modules." + std::to_string(i) + ".0", ys[i], 48 << i, hc[i], 1, true);
+    }
+    b.end_parallel();
+    int y = inc[0];
     for (int i = 0; i < 3; ++i) {
-      int inc = b.bottleneck(bp + "incre_modules." + std::to_string(i + 1) + ".0", ys[i + 1], 48 << (i + 1), hc[i + 1], 1, true);
       const std::string q = bp + "downsamp_modules." + std::to_string(i);
       // hrnet_cls.py:475-477:  incre(y_{i+1}) + ReLU(BN(conv_s2(y)))   -> residual added after the ReLU
-      y = b.conv_bn(q + ".0", q + ".1", y, hc[i] * 4, hc[i + 1] * 4, 3, 2, 1, inc, true, 1);
+      y = b.conv_bn(q + ".0", q + ".1", y, hc[i] * 4, hc[i + 1] * 4, 3, 2, 1, inc[i + 1], true, 1);
     }
     y = b.conv_bn(bp + "final_layer.0", bp + "final_layer.1", y, 1024, 2048, 1, 1, 1, -1, true);
     Op ap; ap.type = OP_AVGPOOL; ap.name = bp + "avgpool"; ap.in = Builder::R(y); ap.out = Builder::R(xc, 0);

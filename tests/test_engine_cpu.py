@@ -58,3 +58,32 @@ def test_forward_before_finalize_is_an_error():
     from poco_amd.model import _Inputs, _Outputs
     rc = m._L.poco_forward(m._h, 1, C.byref(_Inputs()), C.byref(_Outputs()), None)
     assert rc != 0 and b"finalize" in m._L.poco_last_error()
+
+
+@pytest.mark.parametrize("variant", list(VARIANTS))
+def test_tuned_table_entries_are_valid_configurations(variant):
+    """poco_amd/tuned/gfx950.json against the library's own validation (no GPU needed: geometry + LDS budget):
+    every entry measured for a batch size must be accepted for that batch size, and the nearest-batch fallback
+    must leave every conv op with a configuration the library accepts (or the heuristic) at untuned batch sizes."""
+    from poco_amd import tune
+    table = tune.load_table()
+    assert len(table) > 100
+    m = POCO(backbone=variant, num_flow_layers=VARIANTS[variant], max_batch=1)      # declarations only
+    convs = [i for i, _ in enumerate(m.ops()) if m.conv_desc(i) is not None]
+    for B in (64, 32):
+        hit = 0
+        for i in convs:
+            cfg = table.get(tune.shape_key(B, *m.conv_desc(i)[:6]))
+            if cfg:
+                m.set_conv_cfg(i, B, cfg)            # raises PocoHipError if the entry does not fit the op
+                hit += 1
+        if (variant, B) in (("hrnet_w48_cls-cliff", 64), ("hrnet_w48_cls-cliff", 32), ("hrnet_w32-pare", 32),
+                            ("resnet50-cliff", 64)):
+            assert hit == len(convs), (variant, B, hit, len(convs))   # bench batch sizes are fully tuned
+    for B in (1, 5, 48, 128):
+        n = tune.apply_table(m, B, table)
+        assert 0 < n <= len(convs)
+        for i in convs:
+            cfg = m._L.poco_get_conv_cfg       # the active configuration is always retrievable
+            c = (C.c_int * 7)()
+            assert cfg(m._h, i, B, c) == 0 and c[6] in (0, 1, 2, 3, 4, 5)
