@@ -391,17 +391,18 @@ conv_wino2_kernel(const WinoParams p) {
   auto issue_u = [&](int c, int it, int nt0) {
     // item i = (position xi, n-tile j) lives at ((xi*nC16 + c)*nT16 + nt) KiB of the packed buffer: a wave-uniform
     // base for the slice + a 32-bit per-item offset stepped incrementally (scalar ALU only, one v_add per DMA)
-    unsigned ub = lds_base + (unsigned)(2 * rawF4 + (it & 1) * p.ubufF4) * 16u + (unsigned)dw * 1024u;
+    const unsigned ub0 = lds_base + (unsigned)(2 * rawF4 + (it & 1) * p.ubufF4) * 16u;
     const char* sb = reinterpret_cast<const char*>(p.ufrag) + (size_t)((unsigned)c * (unsigned)p.nT16) * 1024u;
     const unsigned xstride = (unsigned)(p.nC16 * p.nT16) * 1024u;
-    const int dxi = dn / NT, dj = dn - dxi * NT;
-    int xi = dw / NT, j = dw - xi * NT;
+    // every block reads the SAME fragments of slice c from L2: rotate the issue order by the block index so that
+    // the CUs of an XCD do not all queue on one L2 channel at the same moment (dbg & 128 = plain order)
+    const int rot = (p.dbg & 128) ? 0 : (int)((blockIdx.x >> 3) * 5u) % nuitems;
     for (int i = dw; i < nuitems; i += dn) {
+      int ii = i + rot;
+      if (ii >= nuitems) ii -= nuitems;
+      const int xi = ii / NT, j = ii - xi * NT;
       const unsigned off = (unsigned)xi * xstride + (unsigned)min(nt0 + j, p.nT16 - 1) * 1024u;
-      lds_dma16_sv(sb, off + (unsigned)lane * 16u, (unsigned)__builtin_amdgcn_readfirstlane((int)ub));
-      ub += (unsigned)dn * 1024u;
-      xi += dxi; j += dj;
-      if (j >= NT) { j -= NT; ++xi; }
+      lds_dma16_sv(sb, off + (unsigned)lane * 16u, (unsigned)__builtin_amdgcn_readfirstlane((int)(ub0 + (unsigned)ii * 1024u)));
     }
   };
 
