@@ -189,3 +189,20 @@ def test_full_size_properties(variant, B, cuda):
     assert float((R @ R.transpose(1, 2) - eye).abs().max()) < 1e-5 and float((torch.linalg.det(R) - 1).abs().max()) < 1e-5
     assert float(out["var_pose"].min()) > 0.0 and float(out["var_pose"].max()) < 1.0
     assert all(bool(torch.isfinite(t).all()) for t in out.values())
+
+
+def test_repeatability_bitwise(cuda):
+    """Race screen (short form of tools/stress.py): repeated forwards on the same inputs are bitwise identical in
+    eager 4-lane, eager 1-lane and graph-replay mode (LDS-DMA / barrier / lane-join races would show up as rare
+    differing tiles)."""
+    m = util.make_engine("hrnet_w48_cls-cliff", max_batch=16)
+    batch = util.cuda_batch(synth.synth_batch(16, 5), cuda)
+    keys = ("pred_pose", "pred_shape", "pred_cam", "var_pose", "smpl_vertices", "uncert_feat")
+    ref = {k: v.clone() for k, v in m(batch).items() if k in keys}
+    out = m._alloc_outputs(16, False)
+    for mode in ("eager4", "eager1", "graph"):
+        m.set_num_lanes(1 if mode == "eager1" else 4)
+        for _ in range(15):
+            o = m.graph_forward(batch, out) if mode == "graph" else m(batch)
+            for k in keys:
+                assert torch.equal(o[k], ref[k]), (mode, k)
