@@ -96,10 +96,8 @@ struct Engine {
   size_t ws_floats = 0;
   std::vector<void*> dev_allocs;
   int num_lanes = 4;      // 1 = run everything on the caller's stream
-  int num_splits = 1;     // >1: the batch is cut into sub-batches that run the whole program on own streams
-  int b0 = 0;             // first crop of the sub-batch currently being enqueued
-  hipStream_t split_stream[4][4] = {};   // [split][lane]; [0][0] is the caller's stream
-  hipEvent_t ev_sfork = nullptr, ev_sjoin[4] = {}, ev_lfork[4] = {}, ev_ljoin[4][4] = {};
+  hipStream_t lane_stream[4] = {};   // side lanes 1..3 (lane 0 is the caller's stream)
+  hipEvent_t ev_fork = nullptr, ev_join[4] = {};
   // SMPL / flow device models
   SmplDev smpl{};
   int a_A = -1, a_j24 = -1, a_verts = -1, a_j49 = -1, a_attn_scratch = -1, a_camt = -1, a_fullt = -1, a_j2d = -1;
@@ -110,15 +108,11 @@ struct Engine {
   std::string err;
 
   ~Engine() {
-    for (int sp = 0; sp < 4; ++sp) {
-      for (int k = 0; k < 4; ++k) {
-        if ((sp > 0 || k > 0) && split_stream[sp][k]) (void)hipStreamDestroy(split_stream[sp][k]);
-        if (ev_ljoin[sp][k]) (void)hipEventDestroy(ev_ljoin[sp][k]);
-      }
-      if (ev_sjoin[sp]) (void)hipEventDestroy(ev_sjoin[sp]);
-      if (ev_lfork[sp]) (void)hipEventDestroy(ev_lfork[sp]);
+    for (int k = 1; k < 4; ++k) {
+      if (lane_stream[k]) (void)hipStreamDestroy(lane_stream[k]);
+      if (ev_join[k]) (void)hipEventDestroy(ev_join[k]);
     }
-    if (ev_sfork) (void)hipEventDestroy(ev_sfork);
+    if (ev_fork) (void)hipEventDestroy(ev_fork);
     for (void* p : dev_allocs) (void)hipFree(p);
     if (ws) (void)hipFree(ws);
   }
@@ -938,13 +932,12 @@ float* ext_out(const IO& io, int slot) {
   }
 }
 
-// e.b0 = first crop of the sub-batch being enqueued (batch-split execution)
 // activations are L16 (common.h): a channel offset inside a wider buffer is a slice-row offset
 inline float* aptr(Engine& e, const Ref& r) {
   const Act& a = e.acts[r.act];
-  return e.ws + a.off + (size_t)e.b0 * a.per_crop() + l16_chan_off(r.co, a.W);
+  return e.ws + a.off + l16_chan_off(r.co, a.W);
 }
-inline float* sptr(Engine& e, int act) { const Act& a = e.acts[act]; return e.ws + a.off + (size_t)e.b0 * a.per_crop(); }
+inline float* sptr(Engine& e, int act) { const Act& a = e.acts[act]; return e.ws + a.off; }
 inline int astride(Engine& e, const Ref& r) { return e.acts[r.act].C; }   // valid for vector acts (H=W=1)
 
 int run_op(Engine& e, Op& op, int B, const IO& io, hipStream_t s) {
@@ -1141,14 +1134,10 @@ extern "C" int poco_finalize(poco_handle_t h) {
   plan_workspace(*e);
   POCO_HIP_CHECK(hipMalloc(&e->ws, e->ws_floats * sizeof(float)));
   POCO_HIP_CHECK(hipMemset(e->ws, 0, e->ws_floats * sizeof(float)));
-  POCO_HIP_CHECK(hipEventCreateWithFlags(&e->ev_sfork, hipEventDisableTiming));
-  for (int sp = 0; sp < 4; ++sp) {
-    POCO_HIP_CHECK(hipEventCreateWithFlags(&e->ev_sjoin[sp], hipEventDisableTiming));
-    POCO_HIP_CHECK(hipEventCreateWithFlags(&e->ev_lfork[sp], hipEventDisableTiming));
-    for (int k = 0; k < 4; ++k) {
-      if (sp > 0 || k > 0) POCO_HIP_CHECK(hipStreamCreateWithFlags(&e->split_stream[sp][k], hipStreamNonBlocking));
-      POCO_HIP_CHECK(hipEventCreateWithFlags(&e->ev_ljoin[sp][k], hipEventDisableTiming));
-    }
+  POCO_HIP_CHECK(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
+  for (int k = 1; k < 4; ++k) {
+    POCO_HIP_CHECK(hipStreamCreateWithFlags(&e->lane_stream[k], hipStreamNonBlocking));
+    POCO_HIP_CHECK(hipEventCreateWithFlags(&e->ev_join[k], hipEventDisableTiming));
   }
   POCO_HIP_CHECK(hipDeviceSynchronize());
   e->params.clear();   // host copies no longer needed
@@ -1156,10 +1145,11 @@ extern "C" int poco_finalize(poco_handle_t h) {
   return POCO_OK;
 }
 
-// Enqueue the whole program for crops [b0, b0+B) on (main, side lanes).
-static int enqueue_program(Engine* e, int B, int b0, const IO& io, hipStream_t main, hipStream_t* side,
-                           hipEvent_t fork_ev, hipEvent_t* join_ev) {
-  e->b0 = b0;
+// Enqueue the whole program on the caller's stream (lane 0) and the side lanes.
+static int enqueue_program(Engine* e, int B, const IO& io, hipStream_t main) {
+  hipStream_t* side = e->lane_stream;
+  hipEvent_t fork_ev = e->ev_fork;
+  hipEvent_t* join_ev = e->ev_join;
   const int nops = (int)e->ops.size();
   for (int i = 0; i < nops;) {
     int j = i;
@@ -1176,7 +1166,7 @@ static int enqueue_program(Engine* e, int B, int b0, const IO& io, hipStream_t m
       Op& op = e->ops[k];
       hipStream_t s = (fork && op.lane > 0) ? side[op.lane] : main;
       int rc = run_op(*e, op, B, io, s);
-      if (rc != POCO_OK) { e->b0 = 0; return rc; }
+      if (rc != POCO_OK) return rc;
     }
     if (fork) {
       // join: the main stream continues only after every side lane of this phase is done
@@ -1188,7 +1178,6 @@ static int enqueue_program(Engine* e, int B, int b0, const IO& io, hipStream_t m
     }
     i = j;
   }
-  e->b0 = 0;
   return POCO_OK;
 }
 
@@ -1199,8 +1188,7 @@ extern "C" int poco_forward(poco_handle_t h, int B, const poco_inputs_t* in, con
   if (B < 1 || B > e->max_batch) { poco_set_error("poco_forward: batch " + std::to_string(B) + " outside 1.." + std::to_string(e->max_batch)); return POCO_ERR_ARG; }
   hipStream_t caller = (hipStream_t)stream;
   IO io{in, out};
-  e->split_stream[0][0] = caller;
-  int rc = enqueue_program(e, B, 0, io, caller, e->split_stream[0], e->ev_lfork[0], e->ev_ljoin[0]);
+  int rc = enqueue_program(e, B, io, caller);
   if (rc != POCO_OK) return rc;
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) { poco_set_error(std::string("poco_forward: ") + hipGetErrorString(err)); return POCO_ERR_HIP; }
