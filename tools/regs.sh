@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: poco_amd/regs.sh poco_amd/csrc/file.hip  -> terse per-kernel register/scratch summary
+# usage: tools/regs.sh poco_amd/csrc/file.hip  -> terse per-kernel register/scratch summary
 hipcc -O3 -std=c++17 --offload-arch=gfx950 -Rpass-analysis=kernel-resource-usage -c "$1" -o /tmp/regs_tmp.o 2>&1 | python3 -c "
 import sys,re
 rows=[];cur=None
