@@ -90,13 +90,15 @@ __device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4
 // Shared output stage of both Winograd kernels: v[n][k] (k = r'*2 + q', a 2x2 pixel block per lane, 4
 // channels each) + shift (+ residual) (activation) -> NHWC.  Residual loads are batched and unconditional
 // (dead pixels read pixel 0) and nothing is loaded between stores - see conv_store_tile in conv_mfma.hip.
-template <int NT, bool HAS_RES>
+// ROWSEL: -1 = all four pixels of the lane's 2x2 block, 0 / 1 = only its upper / lower pixel row (k = 2*ROWSEL + {0,1})
+template <int NT, bool HAS_RES, int ROWSEL = -1>
 __device__ __forceinline__ void wino_store_impl(const WinoParams& p, f32x4 (&v)[NT][4], int nt0, int g, int ob, int oy,
                                                 int ox) {
+  constexpr int K0 = ROWSEL < 0 ? 0 : 2 * ROWSEL, K1 = ROWSEL < 0 ? 4 : 2 * ROWSEL + 2;
   int orow[4], ocol[4];      // image row (b*H + y) and 16*x of the lane's 2x2 output pixels
   bool ok[4];
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
+  for (int k = K0; k < K1; ++k) {
     const int yy = oy + (k >> 1), xx = ox + (k & 1);
     ok[k] = (ob >= 0) && yy < p.H && xx < p.W;
     orow[k] = ok[k] ? ob * p.H + yy : 0;
@@ -110,7 +112,7 @@ __device__ __forceinline__ void wino_store_impl(const WinoParams& p, f32x4 (&v)[
 #pragma unroll
     for (int n = 0; n < NT; ++n)
 #pragma unroll
-      for (int k = 0; k < 4; ++k)
+      for (int k = K0; k < K1; ++k)
         rr[n][k] = *reinterpret_cast<const float4*>(p.res + (size_t)orow[k] * p.res_rs + ocol[k] + min(nt0 + n, p.nT16 - 1) * p.out_ss + g * 4);
   }
 #pragma unroll
@@ -118,7 +120,7 @@ __device__ __forceinline__ void wino_store_impl(const WinoParams& p, f32x4 (&v)[
     const bool nok = nt0 + n < p.nT16;
     const int co = (nt0 + n) * 16 + g * 4;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = K0; k < K1; ++k) {
       f32x4 v4 = v[n][k];
       v4[0] += sh[n].x; v4[1] += sh[n].y; v4[2] += sh[n].z; v4[3] += sh[n].w;
       float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -136,10 +138,10 @@ __device__ __forceinline__ void wino_store_impl(const WinoParams& p, f32x4 (&v)[
     }
   }
 }
-template <int NT>
+template <int NT, int ROWSEL = -1>
 __device__ __forceinline__ void wino_store(const WinoParams& p, f32x4 (&v)[NT][4], int nt0, int g, int ob, int oy, int ox) {
-  if (p.res != nullptr) wino_store_impl<NT, true>(p, v, nt0, g, ob, oy, ox);
-  else wino_store_impl<NT, false>(p, v, nt0, g, ob, oy, ox);
+  if (p.res != nullptr) wino_store_impl<NT, true, ROWSEL>(p, v, nt0, g, ob, oy, ox);
+  else wino_store_impl<NT, false, ROWSEL>(p, v, nt0, g, ob, oy, ox);
 }
 
 // NT = 1: up to 12 waves per block (VGPR cap 170), NT = 2: up to 8 waves (cap 256)
@@ -423,6 +425,7 @@ conv_wino2_kernel(const WinoParams p) {
   if (t >= tend) return;
   int goff[WINO_MAXG], goffN[WINO_MAXG];
   int it0 = 0;
+  bool first_tile = true;
   if (dma_wave) {
     decode_goff(t, goff);
     const int nt0 = (t / p.nblocks_m) * NT;
@@ -460,7 +463,10 @@ conv_wino2_kernel(const WinoParams p) {
 #pragma unroll
       for (int n = 0; n < NT; ++n) acc[i][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    if (dma_wave) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // the first fetches of a tile are waited for by their issuer: here for the block's first tile, inside the
+    // previous tile's output stage otherwise (before that wave's stores, so that no wait ever covers a store)
+    if (dma_wave && first_tile) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    first_tile = false;
     __syncthreads();                   // raw(0), U(0) (and raw(1)) of this tile have landed
 
     // The K loop is instantiated once per half (wave-uniform) so that its body is ONE basic block: hipcc
@@ -491,7 +497,11 @@ conv_wino2_kernel(const WinoParams p) {
         const int it = it0 + c;
         // raw(c+1) and U(c) landed; everybody is done with slice c-1 (for c == 0: with the window read of
         // slice 0 above, whose buffer the raw(2) DMA below overwrites)
-        if constexpr (HALF == 1 || (WINO_EXP & 64)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr (HALF == 1 || (WINO_EXP & 64)) {
+          // slice 0 has nothing to wait for (its data landed before the tile's first barrier); the wait of slice 1
+          // also retires this wave's output stores of the previous tile, long since written
+          if (c > 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
 #if !(WINO_EXP & 8)
         __syncthreads();
 #endif
@@ -567,24 +577,40 @@ conv_wino2_kernel(const WinoParams p) {
       issue_u(0, itn, (tn / p.nblocks_m) * NT);
       if (p.nC16 > 1) issue_raw(1, itn + 1, goffN);
     }
-    float4* xch = smem + 2 * rawF4 + (itl & 1) * p.ubufF4;   // the last slice's U buffer: [wm][n][4][lane]
-    if (half == 1) {
+    // Output stage, split between the halves: the lower half finishes the upper pixel row of every 2x2 block
+    // (k = 0,1), the upper half the lower row (k = 2,3); each hands the partial sums of the OTHER row to its
+    // partner through LDS (the last slice's U buffer is dead): [wave][n][2][lane].
+    float4* xch = smem + 2 * rawF4 + (itl & 1) * p.ubufF4;
+    {
+      const int ks = half == 0 ? 2 : 0;                 // the row this half gives away
 #pragma unroll
       for (int n = 0; n < NT; ++n)
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
-          xch[((wm * NT + n) * 4 + k) * 64 + lane] = make_float4(y[n][k][0], y[n][k][1], y[n][k][2], y[n][k][3]);
+        for (int k = 0; k < 2; ++k) {
+          const f32x4 v = (half == 0) ? y[n][2 + k] : y[n][k];
+          xch[((wave * NT + n) * 2 + k) * 64 + lane] = make_float4(v[0], v[1], v[2], v[3]);
+        }
+      (void)ks;
     }
     __syncthreads();
-    if (half == 0 && !(p.dbg & 1)) {
+    if (!(p.dbg & 1)) {
+      const int pw = half == 0 ? wave + p.WM : wave - p.WM;    // partner: same tile group, other half
 #pragma unroll
       for (int n = 0; n < NT; ++n)
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const float4 o = xch[((wm * NT + n) * 4 + k) * 64 + lane];
-          y[n][k][0] += o.x; y[n][k][1] += o.y; y[n][k][2] += o.z; y[n][k][3] += o.w;
+        for (int k = 0; k < 2; ++k) {
+          const float4 o = xch[((pw * NT + n) * 2 + k) * 64 + lane];
+          f32x4& d = (half == 0) ? y[n][k] : y[n][2 + k];
+          d[0] += o.x; d[1] += o.y; d[2] += o.z; d[3] += o.w;
         }
-      wino_store<NT>(p, y, nt0, g, ob, oy, ox);
+      if (half == 0) wino_store<NT, 0>(p, y, nt0, g, ob, oy, ox);
+      else {
+        // the DMA issuer: retire the next tile's first fetches (and this stage's residual loads) BEFORE storing
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        wino_store<NT, 1>(p, y, nt0, g, ob, oy, ox);
+      }
+    } else if (half == 1) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     if (has_next) {
 #pragma unroll
