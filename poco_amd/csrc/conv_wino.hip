@@ -570,9 +570,9 @@ conv_wino2_kernel(const WinoParams p) {
     }
     const int itl = it0 + p.nC16 - 1;  // last slice of this tile
     const int itn = itl + 1;           // first slice of the next tile
+    if (has_next && dma_wave) decode_goff(tn, goffN);   // address math of the next tile's patch: off the critical path
     __syncthreads();                   // every wave is done with the raw and U buffers of this tile
     if (has_next && dma_wave) {
-      decode_goff(tn, goffN);
       issue_raw(0, itn, goffN);
       issue_u(0, itn, (tn / p.nblocks_m) * NT);
       if (p.nC16 > 1) issue_raw(1, itn + 1, goffN);
