@@ -1,0 +1,56 @@
+/* Plain-C client of include/poco_hip.h: proves the boundary needs nothing but a C compiler and dlopen.
+ * No GPU: it only uses the host-side part of the ABI (declarations of a variant, strict loading errors).
+ * usage: abi_check <path to libpoco_hip.so>;  prints "ok <n tensors>" */
+#include <dlfcn.h>
+#include <stdio.h>
+#include <string.h>
+#include "poco_hip.h"
+
+typedef const char* (*last_error_fn)(void);
+typedef int (*create_fn)(const char*, int, int, poco_handle_t*);
+typedef void (*destroy_fn)(poco_handle_t);
+typedef int (*num_tensors_fn)(poco_handle_t);
+typedef int (*tensor_info_fn)(poco_handle_t, int, char*, size_t, int64_t*, int*, int*);
+typedef int (*load_tensor_fn)(poco_handle_t, const char*, const float*, const int64_t*, int);
+typedef int (*forward_fn)(poco_handle_t, int, const poco_inputs_t*, const poco_outputs_t*, void*);
+
+int main(int argc, char** argv) {
+  if (argc < 2) return 2;
+  void* so = dlopen(argv[1], RTLD_NOW | RTLD_LOCAL);
+  if (!so) { fprintf(stderr, "dlopen: %s\n", dlerror()); return 3; }
+  last_error_fn last_error = (last_error_fn)dlsym(so, "poco_last_error");
+  create_fn create = (create_fn)dlsym(so, "poco_create");
+  destroy_fn destroy = (destroy_fn)dlsym(so, "poco_destroy");
+  num_tensors_fn num_tensors = (num_tensors_fn)dlsym(so, "poco_num_tensors");
+  tensor_info_fn tensor_info = (tensor_info_fn)dlsym(so, "poco_tensor_info");
+  load_tensor_fn load_tensor = (load_tensor_fn)dlsym(so, "poco_load_tensor");
+  forward_fn forward = (forward_fn)dlsym(so, "poco_forward");
+  if (!last_error || !create || !destroy || !num_tensors || !tensor_info || !load_tensor || !forward) return 4;
+
+  poco_handle_t h = 0;
+  if (create("no_such-variant", 4, 1, &h) == 0) return 5;              /* unknown variant is an error ... */
+  if (strlen(last_error()) == 0) return 6;                             /* ... with a message */
+  if (create("resnet50-cliff", 4, 1, &h) != 0) { fprintf(stderr, "%s\n", last_error()); return 7; }
+  int n = num_tensors(h);
+  if (n < 100) return 8;
+  int found = 0;
+  for (int i = 0; i < n; ++i) {
+    char name[256]; int64_t shape[8]; int rank = 0, required = 0;
+    if (tensor_info(h, i, name, sizeof name, shape, &rank, &required) != 0) return 9;
+    if (strcmp(name, "backbone.conv1.weight") == 0) {
+      found = 1;
+      if (rank != 4 || shape[0] != 64 || shape[1] != 3 || shape[2] != 7 || shape[3] != 7 || !required) return 10;
+    }
+  }
+  if (!found) return 11;
+  float w[4] = {0};
+  int64_t bad_shape[1] = {4};
+  if (load_tensor(h, "backbone.conv1.weight", w, bad_shape, 1) == 0) return 12;     /* strict shapes */
+  if (load_tensor(h, "backbone.nope", w, bad_shape, 1) == 0) return 13;             /* strict names */
+  poco_inputs_t in; poco_outputs_t out;
+  memset(&in, 0, sizeof in); memset(&out, 0, sizeof out);
+  if (forward(h, 1, &in, &out, 0) == 0) return 14;                                  /* not finalized */
+  destroy(h);
+  printf("ok %d\n", n);
+  return 0;
+}

@@ -87,3 +87,25 @@ def test_tuned_table_entries_are_valid_configurations(variant):
             cfg = m._L.poco_get_conv_cfg       # the active configuration is always retrievable
             c = (C.c_int * 7)()
             assert cfg(m._h, i, B, c) == 0 and c[6] in (0, 1, 2, 3, 4, 5)
+
+
+def test_c_abi_from_plain_c(tmp_path):
+    """include/poco_hip.h is C (not C++): compile tests/c_abi/abi_check.c with gcc -std=c99 -Wall -Werror and let it
+    drive the host-side part of the ABI through dlopen (declarations, strict loading, error strings)."""
+    import os
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("gcc not available")
+    root = Path(__file__).resolve().parent.parent
+    exe = tmp_path / "abi_check"
+    subprocess.run([gcc, "-std=c99", "-Wall", "-Wextra", "-Werror", "-I", str(root / "include"),
+                    str(root / "tests" / "c_abi" / "abi_check.c"), "-o", str(exe), "-ldl"], check=True)
+    # header alone must also pass a strict C syntax check
+    subprocess.run([gcc, "-std=c99", "-Wall", "-Werror", "-fsyntax-only", "-x", "c", str(root / "include" / "poco_hip.h")],
+                   check=True)
+    env = dict(os.environ)
+    env["LD_LIBRARY_PATH"] = "/opt/rocm/lib:" + env.get("LD_LIBRARY_PATH", "")
+    r = subprocess.run([str(exe), str(_lib.LIB_PATH)], capture_output=True, text=True, env=env)
+    assert r.returncode == 0 and r.stdout.startswith("ok "), (r.returncode, r.stdout, r.stderr)
