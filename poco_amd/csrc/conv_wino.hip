@@ -326,8 +326,8 @@ conv_wino_kernel(const WinoParams p) {
 //   * the raw patch is double-buffered: while the MFMAs of slice c issue, the same wave reads the
 //     window of slice c+1 from the other buffer and transforms it (VALU beside MFMA); one barrier per
 //     slice, no barrier-separated read/transform/MFMA phases;
-//   * the two halves of a tile meet once, at the end: the upper half hands its partial 2x2 outputs to
-//     its partner through LDS (the U buffers are dead by then), the lower half adds and stores.
+//   * the two halves of a tile meet once, at the end: each hands the partial sums of one pixel row of the 2x2
+//     output blocks to its partner through LDS (the U buffers are dead by then) and finishes the other row.
 // ------------------------------------------------------------------------------------------------
 #ifndef WINO_EXP
 #define WINO_EXP 0     // timing experiments only (tools/build_exp.sh); non-zero values compute garbage
@@ -342,8 +342,9 @@ conv_wino2_kernel(const WinoParams p) {
   const int nwaves = blockDim.x >> 6;
   const int wm = wave % p.WM;
   const int half = wave / p.WM;          // 0: positions (r, 0..1); 1: positions (r, 2..3)
-  const int dw = (WINO_EXP & 64) ? wave : wm;                 // DMA issue: this wave's index / count among the issuers
-  const int dn = (WINO_EXP & 64) ? (int)(blockDim.x >> 6) : p.WM;
+  // every wave issues 1/8 of a slice's LDS-DMA pieces (WINO_EXP & 64: only the upper position half issues)
+  const int dw = (WINO_EXP & 64) ? wm : wave;                 // this wave's index / count among the issuers
+  const int dn = (WINO_EXP & 64) ? p.WM : (int)(blockDim.x >> 6);
   const int idx = lane & 15;
   const int g = lane >> 4;
   const int ntiles = p.nblocks_m * p.nb_n;
@@ -408,10 +409,10 @@ conv_wino2_kernel(const WinoParams p) {
     }
   };
 
-  // Only the upper-half waves touch the DMA queue (issue + s_waitcnt vmcnt); the lower-half waves own the
-  // epilogue stores and never wait on vmcnt inside the loop, so a tile's output drains to HBM in the
-  // background while the next tile's MFMAs run (on gfx9 stores and loads share the one VM counter).
-  const bool dma_wave = (WINO_EXP & 64) ? true : (half == 1);
+  // Every wave issues its share of the LDS-DMA and waits for it itself (s_waitcnt vmcnt(0) before the barrier that
+  // publishes the data).  On gfx9 stores and loads share the one VM counter, so the waits are placed where no
+  // store of the wave can still be in flight for long: before its output stores, and at the top of slices c > 0.
+  const bool dma_wave = (WINO_EXP & 64) ? (half == 1) : true;
   // XCD-aware walk: workgroup b runs on XCD b % 8 (round-robin dispatch), so XCD x owns the contiguous tile
   // range [x*per, (x+1)*per) and its gridDim/8 blocks stride through it: neighbouring row bands (shared halo
   // rows) and the same tiles of consecutive layers meet in one L2 instead of eight.  dbg & 64 = plain walk.
@@ -497,7 +498,7 @@ conv_wino2_kernel(const WinoParams p) {
         const int it = it0 + c;
         // raw(c+1) and U(c) landed; everybody is done with slice c-1 (for c == 0: with the window read of
         // slice 0 above, whose buffer the raw(2) DMA below overwrites)
-        if constexpr (HALF == 1 || (WINO_EXP & 64)) {
+        if constexpr (HALF == 1 || !(WINO_EXP & 64)) {
           // slice 0 has nothing to wait for (its data landed before the tile's first barrier); the wait of slice 1
           // also retires this wave's output stores of the previous tile, long since written
           if (c > 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -506,7 +507,7 @@ conv_wino2_kernel(const WinoParams p) {
         __syncthreads();
 #endif
 #if !(WINO_EXP & 4)
-        if constexpr (HALF == 1 || (WINO_EXP & 64)) {
+        if constexpr (HALF == 1 || !(WINO_EXP & 64)) {
 #if !(WINO_EXP & 16)
           if (c + 1 < p.nC16) issue_u(c + 1, it + 1, nt0);
 #endif
@@ -603,13 +604,11 @@ conv_wino2_kernel(const WinoParams p) {
           f32x4& d = (half == 0) ? y[n][k] : y[n][2 + k];
           d[0] += o.x; d[1] += o.y; d[2] += o.z; d[3] += o.w;
         }
+      // a DMA issuer retires the next tile's first fetches BEFORE storing (no later wait then covers a store)
+      if (dma_wave) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       if (half == 0) wino_store<NT, 0>(p, y, nt0, g, ob, oy, ox);
-      else {
-        // the DMA issuer: retire the next tile's first fetches (and this stage's residual loads) BEFORE storing
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        wino_store<NT, 1>(p, y, nt0, g, ob, oy, ox);
-      }
-    } else if (half == 1) {
+      else wino_store<NT, 1>(p, y, nt0, g, ob, oy, ox);
+    } else if (dma_wave) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     if (has_next) {
