@@ -506,16 +506,21 @@ conv_wino2_kernel(const WinoParams p) {
 #if !(WINO_EXP & 8)
         __syncthreads();
 #endif
+        // the two waves of a SIMD (lower / upper half of one tile group) issue their DMA share at different points of
+        // the slice - the lower half here, the upper half after its first two transform rows - so that one of them
+        // always feeds the MFMA pipe while the other sits in the (slow) DMA issue
+        auto issue_slice = [&]() {
 #if !(WINO_EXP & 4)
-        if constexpr (HALF == 1 || !(WINO_EXP & 64)) {
 #if !(WINO_EXP & 16)
           if (c + 1 < p.nC16) issue_u(c + 1, it + 1, nt0);
 #endif
 #if !(WINO_EXP & 32)
           if (c + 2 < p.nC16) issue_raw(c + 2, it + 2, goff);
 #endif
-        }
 #endif
+        };
+        constexpr bool LATE_ISSUE = (HALF == 1) && !(WINO_EXP & 64) && !(WINO_EXP & 8192);
+        if constexpr ((HALF == 1 || !(WINO_EXP & 64)) && !LATE_ISSUE) issue_slice();
         float4 vnext[8];
 #if WINO_EXP & 1
 #pragma unroll
@@ -526,6 +531,7 @@ conv_wino2_kernel(const WinoParams p) {
         const float4* ul = smem + 2 * rawF4 + (it & 1) * p.ubufF4 + (2 * HALF * NT) * 64 + lane;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
+          if constexpr (LATE_ISSUE) { if (r == 2) issue_slice(); }
           float4 u0[NT], u1[NT];
 #pragma unroll
           for (int n = 0; n < NT; ++n) {
