@@ -519,7 +519,12 @@ conv_wino2_kernel(const WinoParams p) {
 #endif
 #endif
         };
-        constexpr bool LATE_ISSUE = (HALF == 1) && !(WINO_EXP & 64) && !(WINO_EXP & 8192);
+#ifndef WINO_ISSUE_LO
+#define WINO_ISSUE_LO (-1)     // transform row before which the lower / upper half issues its DMA share (-1 = slice top)
+#define WINO_ISSUE_HI 2
+#endif
+        constexpr int ISSUE_AT = (WINO_EXP & 8192) ? -1 : (HALF == 0 ? WINO_ISSUE_LO : WINO_ISSUE_HI);
+        constexpr bool LATE_ISSUE = ISSUE_AT >= 0 && !(WINO_EXP & 64);
         if constexpr ((HALF == 1 || !(WINO_EXP & 64)) && !LATE_ISSUE) issue_slice();
         float4 vnext[8];
 #if WINO_EXP & 1
@@ -531,7 +536,7 @@ conv_wino2_kernel(const WinoParams p) {
         const float4* ul = smem + 2 * rawF4 + (it & 1) * p.ubufF4 + (2 * HALF * NT) * 64 + lane;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          if constexpr (LATE_ISSUE) { if (r == 2) issue_slice(); }
+          if constexpr (LATE_ISSUE) { if (r == ISSUE_AT) issue_slice(); }
           float4 u0[NT], u1[NT];
 #pragma unroll
           for (int n = 0; n < NT; ++n) {
