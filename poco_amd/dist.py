@@ -54,3 +54,43 @@ def all_gather_records(rec: torch.Tensor, n_total: int, group=None) -> torch.Ten
     dist.all_gather_into_tensor(buf, send.contiguous(), group=group)
     parts: List[torch.Tensor] = [buf[r * nmax: r * nmax + (hi - lo)] for r, (lo, hi) in enumerate(sizes)]
     return torch.cat(parts, 0)
+
+
+# ---- video mode: tracks are the unit of sharding (tester.py:368) ------------------------------
+def shard_tracks(tracking_results: dict, rank: int, world: int) -> dict:
+    """Greedy longest-first assignment of whole tracks to ranks (a track's frames stay together so that temporal
+    smoothing needs no exchange); deterministic for a given dict, balanced to within the longest track."""
+    order = sorted(tracking_results, key=lambda k: (-len(tracking_results[k]["frames"]), str(k)))
+    load = [0] * world
+    mine = {}
+    for k in order:
+        r = min(range(world), key=lambda i: (load[i], i))
+        load[r] += len(tracking_results[k]["frames"])
+        if r == rank:
+            mine[k] = tracking_results[k]
+    return mine
+
+
+def gather_track_records(local: Dict[str, torch.Tensor], group=None) -> Dict[str, torch.Tensor]:
+    """All ranks end up with every track's [T, 254] records.  `local`: {person_id: [T,254] tensor} of this rank.
+    One all-gather of the concatenated rows (padded to the largest rank) + one object gather of the (id, T) index."""
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    ids = sorted(local, key=str)
+    index = [(k, int(local[k].shape[0])) for k in ids]
+    all_index: List[list] = [None] * world
+    dist.all_gather_object(all_index, index, group=group)
+    rows = torch.cat([local[k] for k in ids], 0) if ids else torch.zeros(0, REC)
+    nmax = max(1, max(sum(t for _, t in idx) for idx in all_index))
+    dev = rows.device
+    send = torch.zeros(nmax, REC, device=dev, dtype=torch.float32)
+    send[: rows.shape[0]] = rows
+    buf = torch.empty(world * nmax, REC, device=dev, dtype=torch.float32)
+    dist.all_gather_into_tensor(buf, send, group=group)
+    out = {}
+    for r, idx in enumerate(all_index):
+        off = r * nmax
+        for k, t in idx:
+            out[k] = buf[off: off + t].clone()
+            off += t
+    return out

@@ -65,3 +65,45 @@ def test_unpack_roundtrip():
     d = pdist.unpack_records(pdist.pack_records(o))
     for k in ("pred_pose", "pred_shape", "pred_cam", "var_pose"):
         assert torch.equal(d[k], o[k])
+
+
+def test_shard_tracks_partition_and_balance():
+    tracks = {f"p{i}": {"frames": list(range(n)), "bbox": [[0, 0, 1, 1]] * n} for i, n in enumerate([50, 3, 17, 17, 40, 1, 9, 28])}
+    for world in (1, 2, 3, 8):
+        parts = [pdist.shard_tracks(tracks, r, world) for r in range(world)]
+        keys = [k for p in parts for k in p]
+        assert sorted(keys) == sorted(tracks)                       # every track on exactly one rank
+        loads = [sum(len(v["frames"]) for v in p.values()) for p in parts]
+        assert max(loads) - min(loads) <= 50                        # balanced to within the longest track
+        assert parts == [pdist.shard_tracks(tracks, r, world) for r in range(world)]   # deterministic
+
+
+def _track_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    tracks = {f"p{i}": {"frames": list(range(n))} for i, n in enumerate([5, 2, 7, 1])}
+    mine = pdist.shard_tracks(tracks, rank, world)
+    rec = lambda k, t: torch.full((t, pdist.REC), float(int(k[1:]) + 1)) + torch.arange(t).view(t, 1)   # noqa: E731
+    local = {k: rec(k, len(v["frames"])) for k, v in mine.items()}
+    full = pdist.gather_track_records(local)
+    ok = set(full) == set(tracks) and all(torch.equal(full[k], rec(k, len(v["frames"]))) for k, v in tracks.items())
+    q.put((rank, ok))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_track_gather_gloo():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_track_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok in res), res
