@@ -176,6 +176,20 @@ conv_mfma_kernel(const ConvKParams p) {
   };
   if (reg_stage) gload(0);
 
+  // weight fragments of the tap that runs next, fetched one tap ahead (L2-resident, 1 KiB per n-tile per wave);
+  // the last tap of a slice fetches tap 0 of the next slice, so no slice starts on an exposed L2 round trip
+  const size_t wtap = (size_t)p.nC16 * p.nT16 * 64;   // stride between taps
+  const size_t wslice = (size_t)p.nT16 * 64;          // stride between 16-channel slices
+  const float4* wbase = p.wfrag + (size_t)nt0 * 64 + lane;
+  int wnoff[NT];
+#pragma unroll
+  for (int n = 0; n < NT; ++n) wnoff[n] = (nt0 + n < p.nT16) ? n * 64 : 0;
+  float4 wv[NT];
+  if (nvalid) {
+#pragma unroll
+    for (int n = 0; n < NT; ++n) wv[n] = wbase[wnoff[n]];
+  }
+
   const int nIter = p.nC16 * p.repeat;   // repeat > 1 only for profiling experiments
   for (int it = 0; it < nIter; ++it) {
     const int c = it % p.nC16;
@@ -200,22 +214,18 @@ conv_mfma_kernel(const ConvKParams p) {
     if (reg_stage && it + 1 < nIter) gload((it + 1) % p.nC16);   // in flight during this slice's MFMAs
 
     if (nvalid) {
-      const float4* wc = p.wfrag + ((size_t)c * p.nT16 + nt0) * 64 + lane;
-      const size_t wtap = (size_t)p.nC16 * p.nT16 * 64;   // stride between taps
+      const float4* wc = wbase + (size_t)c * wslice;
+      const float4* wcn = wbase + (size_t)((it + 1 < nIter) ? (it + 1) % p.nC16 : c) * wslice;
       const float4* pl = patch + g * p.planeF4;
-      float4 wv[NT];
-#pragma unroll
-      for (int n = 0; n < NT; ++n) wv[n] = wc[(nt0 + n < p.nT16) ? n * 64 : 0];
       int tr = 0, ts = 0;
 #pragma unroll 1
       for (int tap = 0; tap < KS * KS; ++tap) {
         const int toff = tr * p.PW + ts;
         if (++ts == KS) { ts = 0; ++tr; }
-        // prefetch the next tap's weight fragments (L2-resident, 1 KiB per n-tile per wave)
         float4 wnx[NT];
-        const int tnext = (tap + 1 < KS * KS) ? tap + 1 : tap;
+        const float4* wnp = (tap + 1 < KS * KS) ? wc + (size_t)(tap + 1) * wtap : wcn;
 #pragma unroll
-        for (int n = 0; n < NT; ++n) wnx[n] = wc[tnext * wtap + ((nt0 + n < p.nT16) ? n * 64 : 0)];
+        for (int n = 0; n < NT; ++n) wnx[n] = wnp[wnoff[n]];
 #pragma unroll
         for (int m0 = 0; m0 < MT; m0 += 2) {
           const float4 a0 = pl[base[m0] + toff];

@@ -329,6 +329,16 @@ conv_wino_kernel(const WinoParams p) {
 //   * the two halves of a tile meet once, at the end: each hands the partial sums of one pixel row of the 2x2
 //     output blocks to its partner through LDS (the U buffers are dead by then) and finishes the other row.
 // ------------------------------------------------------------------------------------------------
+#ifdef WINO_TRACE
+// timing probe (tools/wino_trace.py; build: hipcc ... -DWINO_TRACE=1, see the tool's docstring): every wave sums the
+// shader clocks it spends in the phases of the persistent loop; [block][wave][8] written once at kernel end.
+__device__ unsigned long long g_wino_trace[512 * 8 * 8];
+#define TR_NOW() ((unsigned long long)__builtin_readcyclecounter())
+#define TR_ADD(k, t0, t1) tr[k] += (t1) - (t0)
+#else
+#define TR_NOW() 0ull
+#define TR_ADD(k, t0, t1) (void)0
+#endif
 #ifndef WINO_EXP
 #define WINO_EXP 0     // timing experiments only (tools/build_exp.sh); non-zero values compute garbage
 #endif
@@ -427,6 +437,11 @@ conv_wino2_kernel(const WinoParams p) {
   int goff[WINO_MAXG], goffN[WINO_MAXG];
   int it0 = 0;
   bool first_tile = true;
+#ifdef WINO_TRACE
+  unsigned long long tr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const unsigned long long tr_start = TR_NOW();
+  const unsigned long long tr_rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
   if (dma_wave) {
     decode_goff(t, goff);
     const int nt0 = (t / p.nblocks_m) * NT;
@@ -466,9 +481,12 @@ conv_wino2_kernel(const WinoParams p) {
 
     // the first fetches of a tile are waited for by their issuer: here for the block's first tile, inside the
     // previous tile's output stage otherwise (before that wave's stores, so that no wait ever covers a store)
+    [[maybe_unused]] const unsigned long long tA = TR_NOW();
     if (dma_wave && first_tile) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     first_tile = false;
     __syncthreads();                   // raw(0), U(0) (and raw(1)) of this tile have landed
+    [[maybe_unused]] unsigned long long tB = TR_NOW();
+    TR_ADD(0, tA, tB);                 // 0: first-slice wait + tile-start barrier
 
     // The K loop is instantiated once per half (wave-uniform) so that its body is ONE basic block: hipcc
     // can then interleave the window reads + transform of slice c+1 with the MFMAs of slice c.
@@ -501,11 +519,21 @@ conv_wino2_kernel(const WinoParams p) {
         if constexpr (HALF == 1 || !(WINO_EXP & 64)) {
           // slice 0 has nothing to wait for (its data landed before the tile's first barrier); the wait of slice 1
           // also retires this wave's output stores of the previous tile, long since written
+          [[maybe_unused]] const unsigned long long t0 = TR_NOW();
+          TR_ADD(1, tB, t0);           // 1: slice body (window reads, transform, MFMAs, DMA issue)
           if (c > 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          [[maybe_unused]] const unsigned long long t1 = TR_NOW();
+          TR_ADD(2, t0, t1);           // 2: waiting for this wave's own DMA
+          tB = t1;
         }
 #if !(WINO_EXP & 8)
         __syncthreads();
 #endif
+        {
+          [[maybe_unused]] const unsigned long long t2 = TR_NOW();
+          TR_ADD(3, tB, t2);           // 3: slice barrier
+          tB = t2;
+        }
         // the two waves of a SIMD (lower / upper half of one tile group) issue their DMA share at different points of
         // the slice - the lower half here, the upper half after its first two transform rows - so that one of them
         // always feeds the MFMA pipe while the other sits in the (slow) DMA issue
@@ -580,6 +608,8 @@ conv_wino2_kernel(const WinoParams p) {
         else           { y[n][r * 2] = sA[r];         y[n][r * 2 + 1] = -sA[r] - sB[r]; }
       }
     }
+    [[maybe_unused]] const unsigned long long tC = TR_NOW();
+    TR_ADD(1, tB, tC);                 // the last slice's body + partial inverse transform
     const int itl = it0 + p.nC16 - 1;  // last slice of this tile
     const int itn = itl + 1;           // first slice of the next tile
     if (has_next && dma_wave) decode_goff(tn, goffN);   // address math of the next tile's patch: off the critical path
@@ -627,8 +657,24 @@ conv_wino2_kernel(const WinoParams p) {
       for (int k = 0; k < WINO_MAXG; ++k) goff[k] = goffN[k];
     }
     it0 = itn;
+    [[maybe_unused]] const unsigned long long tD = TR_NOW();
+    TR_ADD(4, tC, tD);                 // 4: end-of-tile stage (barriers, exchange, next tile's first issue, stores)
   }
+#ifdef WINO_TRACE
+  tr[5] = TR_NOW() - tr_start;         // 5: whole kernel
+  tr[6] = tr_start;
+  tr[7] = __builtin_amdgcn_s_memrealtime() - tr_rt0;   // 100 MHz reference clock over the same interval
+  if (lane == 0 && blockIdx.x < 512) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) g_wino_trace[((size_t)blockIdx.x * 8 + wave) * 8 + k] = tr[k];
+  }
+#endif
 }
+#ifdef WINO_TRACE
+extern "C" int poco_debug_wino_trace(unsigned long long* host, size_t n) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_wino_trace), n * sizeof(unsigned long long));
+}
+#endif
 
 struct WGeo {
   int TX, nbands, S, PR, PW, npos, planeF4, nblocks_m;
