@@ -40,6 +40,8 @@ struct ConvCfg {
                // 2: ALG 1 persistent over tiles; 3: Winograd F(2x2,3x3) (MT ignored, NT in {1,2}, R even);
                // 4: Winograd, half-position waves + pipelined transform (WN = 2 halves, WM <= 4, NT <= 3)
                // 5: small-M linear (H = W = 1, ks = 1): K split over WM waves per 16 outputs (linear_mfma.hip)
+               // 6: 1x1 conv (stride 1|2) as a register-direct GEMM, no LDS / barriers (gemm1x1.hip):
+               //    (MT,NT) in {(2,4),(4,2),(4,4),(7,2),(7,4),(8,2)}, R = operand prefetch depth (2|3), NI = 1
 };
 constexpr int CONV_CFG_INTS = 7;   // ints per configuration in the C ABI / tuning table
 inline ConvCfg conv_cfg_from(const int* c) { return ConvCfg{c[0], c[1], c[2], c[3], c[4], c[5], c[6]}; }
@@ -82,6 +84,10 @@ size_t conv_lds_bytes(const ConvDesc& d, const ConvCfg& cfg);
 // ---- small-M linear layers (linear_mfma.hip), ALG 5 -------------------------------------------------
 bool linear_cfg_valid(const ConvDesc& d, const ConvCfg& cfg);
 int linear_launch(const ConvDesc& d, const ConvCfg& cfg, hipStream_t stream);
+
+// ---- 1x1 convs as a register-direct GEMM (gemm1x1.hip), ALG 6 ---------------------------------------
+bool gemm1x1_cfg_valid(const ConvDesc& d, const ConvCfg& cfg);
+int gemm1x1_launch(const ConvDesc& d, const ConvCfg& cfg, hipStream_t stream);
 
 // ---- Winograd F(2x2,3x3) variant (conv_wino.hip) --------------------------------------------------
 #include <vector>

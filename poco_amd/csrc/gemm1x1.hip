@@ -1,0 +1,212 @@
+// 1x1 convolutions (stride 1 or 2) as a register-direct GEMM — ALG 6.
+//
+// The Bottleneck 1x1 convs of ResNet-50 / HRNet layer1 / the cls head (resnet.py:101-121, hrnet.py:79-99,
+// hrnet_cls.py:306-353) are plain GEMMs D[co][pix] = sum_k W[co][k] X[k][pix].  A 1x1 conv has no halo: in the
+// L16 layout the 16-channel slice of 16 neighbouring pixels is ONE contiguous KiB, i.e. exactly the MFMA B operand
+// of a wave (lane (idx, g) holds x[pixel idx][16c + 4g .. +3]), so it can be loaded global -> VGPR with one
+// coalesced dwordx4 per sub-tile and needs no LDS staging at all.  The LDS-DMA kernels pay one block barrier per
+// 16-channel slice, which for a 1x1 conv is only MT*NT*4 MFMAs of work; here there is no LDS and no barrier:
+// every wave free-runs over K with its operands of the next D-1 slices in flight in registers, and the waves of a
+// block that share pixels (same wm) or weights (same wn) meet in the vector L1.
+//
+// Operand roles as in the other kernels: packed weight fragments (conv_pack_weights, ks = 1) = A operand, pixels =
+// B operand, so a lane ends up with 4 consecutive output channels of one pixel -> 16-B stores.
+#include "conv_mfma_types.h"
+
+namespace {
+
+struct G1Params {
+  const float* in;       // slice offsets folded into the pointers
+  const float* res;
+  float* out;
+  const float4* wfrag;   // [Cin/16][Cout16/16][64] float4
+  const float* bias;
+  int P;                 // output pixels B*Ho*Wo
+  int H, W, Ho, Wo, stride;
+  int nC16, nT16, WM, WN;
+  int in_rs, in_ss, res_rs, out_rs, out_ss;
+  int act, res_after_act, relu_from;
+  FastDiv dWo, dHo;
+};
+
+template <int MT, int NT, int D, bool HAS_RES>
+__global__ void __launch_bounds__(512)
+gemm1x1_kernel(const G1Params p) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave % p.WM, wn = wave / p.WM;
+  const int idx = lane & 15, g = lane >> 4;
+  const int mt0 = (blockIdx.x * p.WM + wm) * MT;        // first 16-pixel sub-tile of this wave
+  const int nt0 = (blockIdx.y * p.WN + wn) * NT;        // first 16-channel tile of this wave
+  if (nt0 >= p.nT16 || mt0 * 16 >= p.P) return;         // wave-uniform; there are no barriers in this kernel
+
+  int boff[MT];      // float offset of this lane's pixel (slice 0, channel quad g) in the input
+  int orow[MT];      // output image row (b*Ho + y) or -1
+  int ox16[MT];      // 16 * x
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    const int pix = (mt0 + m) * 16 + idx;
+    const uint32_t pc = (uint32_t)min(pix, p.P - 1);    // dead lanes re-read the last pixel
+    const uint32_t row = fdiv(pc, p.dWo);
+    const uint32_t x = pc - row * p.Wo;
+    uint32_t irow = row, ix = x;
+    if (p.stride == 2) {
+      const uint32_t b = fdiv(row, p.dHo);
+      irow = b * p.H + (row - b * p.Ho) * 2;
+      ix = x * 2;
+    }
+    boff[m] = (int)(irow * (uint32_t)p.in_rs + ix * 16u) + 4 * g;
+    orow[m] = pix < p.P ? (int)row : -1;
+    ox16[m] = (int)x * 16;
+  }
+  const float4* wl = p.wfrag + (size_t)nt0 * 64 + lane;
+  const int wslice = p.nT16 * 64;                        // float4 per K slice
+  int woff[NT];
+#pragma unroll
+  for (int n = 0; n < NT; ++n) woff[n] = (nt0 + n < p.nT16) ? n * 64 : 0;
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  float4 a[D][NT], b[D][MT];
+  auto load = [&](int s, int c) {                        // unconditional (c is clamped by the caller)
+#pragma unroll
+    for (int n = 0; n < NT; ++n) a[s][n] = wl[(size_t)c * wslice + woff[n]];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) b[s][m] = *reinterpret_cast<const float4*>(p.in + boff[m] + (size_t)c * p.in_ss);
+  };
+  auto mma = [&](int s) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        const float wj = (j == 0) ? a[s][n].x : (j == 1) ? a[s][n].y : (j == 2) ? a[s][n].z : a[s][n].w;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          const float bj = (j == 0) ? b[s][m].x : (j == 1) ? b[s][m].y : (j == 2) ? b[s][m].z : b[s][m].w;
+          acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wj, bj, acc[m][n], 0, 0, 0);
+        }
+      }
+  };
+  const int last = p.nC16 - 1;
+#pragma unroll
+  for (int s = 0; s < D - 1; ++s) load(s, min(s, last));
+  const int nfull = p.nC16 / D * D;
+  for (int c0 = 0; c0 < nfull; c0 += D) {
+#pragma unroll
+    for (int u = 0; u < D; ++u) {                        // slice c0 + u lives in stage u (c0 is a multiple of D)
+      load((u + D - 1) % D, min(c0 + u + D - 1, last));
+      mma(u);
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < D - 1; ++u) {                      // tail: nC16 % D slices, already (being) loaded
+    if (nfull + u < p.nC16) mma(u);
+  }
+
+  // ---- epilogue: shift (+ residual) (activation) -> L16 channel slice --------------------------------------
+  int ob[MT], rb[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    ob[m] = orow[m] >= 0 ? orow[m] * p.out_rs + ox16[m] + g * 4 : -1;
+    rb[m] = max(orow[m], 0) * p.res_rs + ox16[m] + g * 4;
+  }
+  float4 sh[NT];
+#pragma unroll
+  for (int n = 0; n < NT; ++n) sh[n] = *reinterpret_cast<const float4*>(p.bias + min(nt0 + n, p.nT16 - 1) * 16 + g * 4);
+  // residual loads are unconditional and never under a branch (hipcc then counts them: a load under a branch makes it
+  // fall back to s_waitcnt vmcnt(0) before every store)
+  auto load_res = [&](int n, float4* r) {
+    const int co = min(nt0 + n, p.nT16 - 1) * p.out_ss;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) r[m] = *reinterpret_cast<const float4*>(p.res + rb[m] + co);
+  };
+  float4 rcur[MT], rnext[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) rcur[m] = rnext[m] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if constexpr (HAS_RES) load_res(0, rcur);
+#pragma unroll
+  for (int n = 0; n < NT; ++n) {
+    if constexpr (HAS_RES) { if (n + 1 < NT) load_res(n + 1, rnext); }   // the next group's residuals are in flight during the stores
+    const int co = (nt0 + n) * 16 + g * 4;
+    const bool nok = nt0 + n < p.nT16;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      f32x4 v = acc[m][n];
+      v[0] += sh[n].x; v[1] += sh[n].y; v[2] += sh[n].z; v[3] += sh[n].w;
+      const float4 r = rcur[m];
+      if (!p.res_after_act) { v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w; }
+      if (p.act == 1 || (p.act == 3 && co >= p.relu_from)) {
+        v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+      } else if (p.act == 2) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = 1.f / (1.f + __expf(-v[e]));
+      }
+      if (p.res_after_act) { v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w; }
+      if (nok && ob[m] >= 0)
+        *reinterpret_cast<float4*>(p.out + ob[m] + (nt0 + n) * p.out_ss) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+#pragma unroll
+    for (int m = 0; m < MT; ++m) rcur[m] = rnext[m];
+  }
+}
+
+template <int MT, int NT>
+int launch_d(int D, const G1Params& p, dim3 grid, int nthreads, hipStream_t stream) {
+  const bool r = p.res != nullptr;
+  if (D == 2 && r) hipLaunchKernelGGL((gemm1x1_kernel<MT, NT, 2, true>), grid, dim3(nthreads), 0, stream, p);
+  else if (D == 2) hipLaunchKernelGGL((gemm1x1_kernel<MT, NT, 2, false>), grid, dim3(nthreads), 0, stream, p);
+  else if (r) hipLaunchKernelGGL((gemm1x1_kernel<MT, NT, 3, true>), grid, dim3(nthreads), 0, stream, p);
+  else hipLaunchKernelGGL((gemm1x1_kernel<MT, NT, 3, false>), grid, dim3(nthreads), 0, stream, p);
+  POCO_HIP_CHECK(hipGetLastError());
+  return POCO_OK;
+}
+
+bool tile_ok(int MT, int NT) {
+  return (MT == 2 && NT == 4) || (MT == 4 && (NT == 2 || NT == 4)) || (MT == 7 && (NT == 2 || NT == 4)) || (MT == 8 && NT == 2);
+}
+
+}  // namespace
+
+// cfg: {MT, NT, WM, WN, R = prefetch depth D (2|3), NI = 1, ALG = 6}
+bool gemm1x1_cfg_valid(const ConvDesc& d, const ConvCfg& cfg) {
+  const long P = (long)d.B * ((d.H - 1) / d.stride + 1) * ((d.W - 1) / d.stride + 1);
+  return d.ks == 1 && (d.stride == 1 || d.stride == 2) && d.Cin % 16 == 0 && d.Cout % 16 == 0 && tile_ok(cfg.MT, cfg.NT) &&
+         cfg.WM >= 1 && cfg.WN >= 1 && cfg.WM * cfg.WN <= 8 && (cfg.R == 2 || cfg.R == 3) && cfg.NI == 1 && P < (1L << 27) &&
+         (long)d.B * d.H * d.in_cs * d.W < (1L << 31) && P * std::max(d.out_cs, d.res_cs) < (1L << 31);
+}
+
+int gemm1x1_launch(const ConvDesc& d, const ConvCfg& cfg, hipStream_t stream) {
+  if (!gemm1x1_cfg_valid(d, cfg)) {
+    poco_set_error("gemm1x1: ALG 6 needs ks = 1, stride 1|2, (MT,NT) in {(2,4),(4,2),(4,4),(7,2),(7,4),(8,2)}, WM*WN <= 8, R (depth) 2|3, NI = 1");
+    return POCO_ERR_ARG;
+  }
+  if ((d.in_cs | d.in_co | d.out_cs | d.out_co | d.res_cs | d.res_co) & 3) {
+    poco_set_error("conv: channel strides/offsets must be multiples of 4");
+    return POCO_ERR_ARG;
+  }
+  G1Params p{};
+  p.H = d.H; p.W = d.W; p.stride = d.stride;
+  p.Ho = (d.H - 1) / d.stride + 1; p.Wo = (d.W - 1) / d.stride + 1;
+  p.in = d.in + l16_chan_off(d.in_co, d.W);
+  p.res = d.res ? d.res + l16_chan_off(d.res_co, p.Wo) : nullptr;
+  p.out = d.out + l16_chan_off(d.out_co, p.Wo);
+  p.wfrag = reinterpret_cast<const float4*>(d.wfrag); p.bias = d.bias;
+  p.P = d.B * p.Ho * p.Wo;
+  p.nC16 = d.Cin / 16; p.nT16 = d.Cout / 16; p.WM = cfg.WM; p.WN = cfg.WN;
+  p.in_rs = d.in_cs * d.W; p.in_ss = d.W * 16;
+  p.res_rs = d.res_cs * p.Wo; p.out_rs = d.out_cs * p.Wo; p.out_ss = p.Wo * 16;
+  p.act = d.act; p.res_after_act = d.res_after_act; p.relu_from = d.relu_from;
+  p.dWo = make_fastdiv(p.Wo); p.dHo = make_fastdiv(p.Ho);
+  const int mtiles = (p.P + 15) / 16;
+  const dim3 grid((mtiles + cfg.WM * cfg.MT - 1) / (cfg.WM * cfg.MT), (p.nT16 + cfg.WN * cfg.NT - 1) / (cfg.WN * cfg.NT));
+  const int nthreads = cfg.WM * cfg.WN * 64;
+#define G1_CASE(mt, nt) if (cfg.MT == mt && cfg.NT == nt) return launch_d<mt, nt>(cfg.R, p, grid, nthreads, stream);
+  G1_CASE(2, 4) G1_CASE(4, 2) G1_CASE(4, 4) G1_CASE(7, 2) G1_CASE(7, 4) G1_CASE(8, 2)
+#undef G1_CASE
+  poco_set_error("gemm1x1: unsupported tile");
+  return POCO_ERR_ARG;
+}

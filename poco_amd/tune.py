@@ -41,6 +41,13 @@ def candidates(B, H, W, Cin, Cout, ks, stride, lds_cap=150 * 1024) -> List[Tuple
         return [(1, 1, wm, 1, 1, 1, 5) for wm in (1, 2, 4, 8, 16)] + [(4, 1, 1, 1, 1, min(B, 64), 1)]
     if ks == 1 and stride == 1:          # split-K GEMM straight from global memory (small planes / few pixels)
         out.update((1, 1, wm, 1, 1, 1, 5) for wm in (1, 2, 4, 8))
+    if ks == 1:                          # register-direct GEMM, no LDS (ALG 6); R = operand prefetch depth
+        for (MT, NT), (WM, WN), D in itertools.product(((2, 4), (4, 2), (4, 4), (7, 2), (7, 4), (8, 2)),
+                                                       ((1, 1), (1, 2), (2, 1), (1, 4), (2, 2), (4, 1), (1, 8), (2, 4), (4, 2), (8, 1)),
+                                                       (2, 3)):
+            if WN > 1 and (WN - 1) * NT >= nT:       # a whole wave column beyond Cout
+                continue
+            out.add((MT, NT, WM, WN, D, 1, 6))
     for MT, NT, WM, WN in itertools.product((4, 7, 13), (1, 2, 3, 4), (1, 2, 4, 8), (1, 2, 3, 4, 6, 8)):
         if WM * WN > 8 or (MT == 13 and NT > (2 if ks == 3 else 3)) or nT % NT:
             continue
@@ -122,7 +129,7 @@ def tune_shape(L, B, H, W, Cin, Cout, ks, stride, iters=8):
     return cands2[best_i], float(ms2[best_i]), float(base), len(cands)
 
 
-def tune_model(model, B: int, verbose=True, skip=()) -> Dict[str, dict]:
+def tune_model(model, B: int, verbose=True, skip=(), only_ks=0) -> Dict[str, dict]:
     from ._lib import lib
     L = lib()
     L.poco_tune_conv.argtypes = [C.c_int] * 7 + [C.POINTER(C.c_int), C.c_int, C.c_int, C.POINTER(C.c_float), C.c_void_p]
@@ -137,7 +144,7 @@ def tune_model(model, B: int, verbose=True, skip=()) -> Dict[str, dict]:
     t0 = time.time()
     for (H, W, Cin, Cout, ks, stride), idxs in sorted(shapes.items(), key=lambda kv: -len(kv[1])):
         key = shape_key(B, H, W, Cin, Cout, ks, stride)
-        if key in skip:
+        if key in skip or (only_ks and (ks != only_ks or H * W == 1)):
             continue
         cfg, ms, base, n = tune_shape(L, B, H, W, Cin, Cout, ks, stride)
         fl = 2.0 * B * ((H + 2 * ((ks - 1) // 2) - ks) // stride + 1) ** 2 * Cout * Cin * ks * ks if H == W else 0
@@ -267,6 +274,7 @@ def main():
     ap.add_argument("--batch", type=int, nargs="+", default=[64])
     ap.add_argument("--only-missing", action="store_true", help="keep existing table entries, tune new shapes only")
     ap.add_argument("--out", default=str(TABLE), help="where to write the merged table")
+    ap.add_argument("--ks", type=int, default=0, help="re-tune only the spatial convs of this kernel size (1 or 3)")
     ap.add_argument("--in-context", action="store_true",
                     help="second pass: re-pick the configuration of the most expensive shapes inside the whole forward")
     args = ap.parse_args()
@@ -278,7 +286,7 @@ def main():
         if args.in_context:
             full.update({k: v for k, v in tune_in_context(args.variant, B).items() if v["cfg"][0] > 0})
             continue
-        full.update({k: v for k, v in tune_model(m, B, skip=set(full) if args.only_missing else ()).items()
+        full.update({k: v for k, v in tune_model(m, B, skip=set(full) if args.only_missing else (), only_ks=args.ks).items()
                      if v["cfg"][0] > 0})
     out = Path(args.out)
     out.parent.mkdir(exist_ok=True, parents=True)

@@ -180,3 +180,50 @@ def test_conv1x1_split_k(case, wm, cuda):
     out = ops.conv2d_nhwc(torch.from_numpy(x).to(cuda), w, scale, shift, 1, torch.from_numpy(res).to(cuda), True,
                           cfg=(1, 1, wm, 1, 1, 1, 5)).cpu().numpy()
     assert np.abs(out - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max())
+
+
+GEMM1X1 = [
+    # B, H, W, Cin, Cout, stride, res
+    (2, 56, 56, 64, 256, 1, True),      # Bottleneck expand + residual (resnet.py:101-121)
+    (2, 56, 56, 256, 64, 1, False),     # Bottleneck reduce
+    (3, 14, 14, 1024, 256, 1, False),
+    (3, 14, 14, 256, 1024, 1, True),
+    (5, 7, 7, 2048, 512, 1, False),     # 49-pixel planes: sub-tiles straddle images
+    (2, 56, 56, 256, 512, 2, False),    # downsample.0 (1x1 stride 2)
+    (3, 14, 14, 1024, 2048, 2, False),
+    (1, 13, 9, 32, 48, 1, True),        # ragged plane, Cout not a multiple of NT*16
+    (2, 15, 11, 48, 16, 2, True),       # odd plane, stride 2
+    (1, 1, 1, 16, 16, 1, False),        # one pixel
+    (2, 28, 28, 80, 144, 1, True),      # K = 5 slices: exercises the depth-2 and depth-3 tails
+]
+GEMM1X1_CFG = [(2, 4, 2, 2, 2, 1, 6), (4, 2, 4, 2, 3, 1, 6), (4, 4, 1, 4, 2, 1, 6), (4, 4, 2, 2, 3, 1, 6), (7, 2, 2, 4, 3, 1, 6),
+               (7, 4, 1, 2, 2, 1, 6), (7, 4, 2, 2, 3, 1, 6), (8, 2, 8, 1, 2, 1, 6), (8, 2, 1, 1, 3, 1, 6)]
+
+
+@pytest.mark.parametrize("cfg", GEMM1X1_CFG, ids=lambda c: "-".join(map(str, c)))
+@pytest.mark.parametrize("case", GEMM1X1, ids=lambda c: "x".join(map(str, c)))
+def test_conv1x1_register_gemm(case, cfg, cuda):
+    """ALG 6: 1x1 convs (stride 1|2) as a register-direct GEMM without LDS (csrc/gemm1x1.hip); Bottleneck 1x1 convs of
+    resnet.py:101-121 / hrnet.py:79-99 incl. the stride-2 downsample path."""
+    from poco_amd import ops
+    B, H, W, Cin, Cout, stride, has_res = case
+    rng = np.random.default_rng(B * 977 + Cin + Cout)
+    x = rng.standard_normal((B, H, W, Cin)).astype(np.float32)
+    w = (rng.standard_normal((Cout, Cin, 1, 1)) / np.sqrt(Cin)).astype(np.float32)
+    scale = rng.uniform(0.5, 1.5, Cout).astype(np.float32)
+    shift = rng.uniform(-0.5, 0.5, Cout).astype(np.float32)
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    res = rng.standard_normal((B, Ho, Wo, Cout)).astype(np.float32) if has_res else None
+    ref = _ref(x, w, scale, shift, stride, res, True)
+    out = ops.conv2d_nhwc(torch.from_numpy(x).to(cuda), w, scale, shift, stride,
+                          None if res is None else torch.from_numpy(res).to(cuda), True, cfg=cfg).cpu().numpy()
+    assert out.shape == ref.shape
+    assert np.abs(out - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max())
+
+
+def test_conv1x1_register_gemm_rejects_3x3(cuda):
+    from poco_amd import ops
+    x = torch.zeros(1, 8, 8, 16, device=cuda)
+    w = np.zeros((16, 16, 3, 3), np.float32)
+    with pytest.raises(RuntimeError):
+        ops.conv2d_nhwc(x, w, cfg=(4, 2, 2, 2, 2, 1, 6))
