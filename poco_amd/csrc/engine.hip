@@ -176,6 +176,8 @@ struct Builder {
   // POCO_SEQ_PHASES (bit mask, experiments): run the tagged kind of parallel region on one lane
   int seq_mask = [] { const char* v = getenv("POCO_SEQ_PHASES"); return v ? atoi(v) : 0; }();
   bool region_seq = false;
+  // POCO_NO_KCAT=1 (experiments): keep the projection shortcut of layer1.0 a separate conv + residual
+  bool kcat = [] { const char* v = getenv("POCO_NO_KCAT"); return !(v && atoi(v)); }();
   void begin_parallel(int kind = 0) { ++cur_phase; cur_lane = 0; in_parallel = true; region_seq = (seq_mask >> kind) & 1; }
   void end_parallel() { in_parallel = false; }
   void lane(int k) { cur_lane = region_seq ? 0 : k % 4; }
@@ -276,7 +278,38 @@ struct Builder {
     int y = conv_bn(p + ".conv1", p + ".bn1", x, C, C, 3, 1, 1);
     return conv_bn(p + ".conv2", p + ".bn2", y, C, C, 3, 1, 1, x);
   }
-  int bottleneck(const std::string& p, int x, int Cin, int planes, int stride, bool down) {   // :79-99
+  // `cat` >= 0 (stride-1 block with a projection shortcut): x lives in channels [planes, planes + Cin) of the act `cat`.
+  // conv2 then writes its output into channels [0, planes) of the same act and
+  //     bn3(conv3(t)) + bn_d(conv_d(x))  =  [s3*W3 | sd*Wd] . [t ; x] + (b3 + bd)
+  // runs as ONE 1x1 conv over the planes + Cin channels: the 4*planes-wide tensor is written once instead of written
+  // by the shortcut conv, re-read as a residual and written again (at 56x56 that is 2 x 205 MB per 64 crops).
+  int bottleneck(const std::string& p, int x, int Cin, int planes, int stride, bool down, int cat = -1) {   // :79-99
+    if (cat >= 0) {
+      const int Cout = planes * 4;
+      const int t1 = conv(p + ".conv1", p + ".conv1", p + ".bn1", R(cat, planes), Cin, planes, 1, 1, 1, false);
+      conv(p + ".conv2", p + ".conv2", p + ".bn2", R(t1), planes, planes, 3, 1, 1, false, Ref(), 0, R(cat, 0));
+      const HostParam* w3 = P(p + ".conv3.weight", {Cout, planes, 1, 1});
+      const HostParam* wd = P(p + ".downsample.0.weight", {Cout, Cin, 1, 1});
+      std::vector<float> s3, b3, sd, bd;
+      bn_fold(p + ".bn3", nullptr, Cout, s3, b3);
+      bn_fold(p + ".downsample.1", nullptr, Cout, sd, bd);
+      HostParam wm, bm;
+      const bool have = !declare && w3 && wd;
+      if (have) {
+        const int K = planes + Cin;
+        wm.shape = {Cout, K, 1, 1};
+        wm.data.resize((size_t)Cout * K);
+        bm.shape = {Cout};
+        bm.data.resize(Cout);
+        for (int o = 0; o < Cout; ++o) {
+          for (int k = 0; k < planes; ++k) wm.data[(size_t)o * K + k] = (float)((double)s3[o] * w3->data[(size_t)o * planes + k]);
+          for (int k = 0; k < Cin; ++k) wm.data[(size_t)o * K + planes + k] = (float)((double)sd[o] * wd->data[(size_t)o * Cin + k]);
+          bm.data[o] = (float)((double)b3[o] + (double)bd[o]);
+        }
+      }
+      return conv(p + ".conv3+downsample", "", "", R(cat, 0), planes + Cin, Cout, 1, 1, 1, true, Ref(), 0, Ref(), nullptr, 0,
+                  false, true, have ? &wm : nullptr, have ? &bm : nullptr);
+    }
     int y = conv_bn(p + ".conv1", p + ".bn1", x, Cin, planes, 1, 1, 1);
     y = conv_bn(p + ".conv2", p + ".bn2", y, planes, planes, 3, stride, 1);
     int r = x;
@@ -446,8 +479,10 @@ struct Builder {
   // stem + layer1 + transitions + stages 2-4 (hrnet.py:466-497 / hrnet_cls.py:438-469)
   std::vector<int> hrnet_trunk(const std::string& p, int w, Ref final_out0 = Ref()) {
     int x = stem(p, 3, 224);
-    x = conv_bn(p + "conv2", p + "bn2", x, 64, 64, 3, 2, 1);
-    for (int k = 0; k < 4; ++k) x = bottleneck(p + "layer1." + std::to_string(k), x, k == 0 ? 64 : 256, 64, 1, k == 0);
+    const int cat = kcat ? new_act(128, 56, 56) : -1;      // [layer1.0 conv2 output | stem output], see bottleneck()
+    x = conv_bn(p + "conv2", p + "bn2", x, 64, 64, 3, 2, 1, -1, false, 0, kcat ? R(cat, 64) : Ref());
+    for (int k = 0; k < 4; ++k)
+      x = bottleneck(p + "layer1." + std::to_string(k), x, k == 0 ? 64 : 256, 64, 1, k == 0, k == 0 ? cat : -1);
     std::vector<int> ys = {x};
     std::vector<int> prev_ch = {256};
     const int nmod[3] = {1, 4, 3};
@@ -658,8 +693,10 @@ bool build_graph(Engine& e, bool declare) {
     int x = b.stem(bp, 7, 224);
     const Act a = e.acts[x];
     Op mp; mp.type = OP_MAXPOOL; mp.name = bp + "maxpool"; mp.in = Builder::R(x);
-    int p = b.new_act(64, (a.H + 2 - 3) / 2 + 1, (a.W + 2 - 3) / 2 + 1);
-    mp.out = Builder::R(p);
+    const int Hp = (a.H + 2 - 3) / 2 + 1, Wp = (a.W + 2 - 3) / 2 + 1;
+    const int cat = b.kcat ? b.new_act(128, Hp, Wp) : -1;   // [layer1.0 conv2 output | max-pool output]
+    int p = b.kcat ? cat : b.new_act(64, Hp, Wp);
+    mp.out = b.kcat ? Builder::R(cat, 64) : Builder::R(p);
     b.push(std::move(mp));
     x = p;
     const int nblk[4] = {3, 4, 6, 3};
@@ -668,7 +705,8 @@ bool build_graph(Engine& e, bool declare) {
       const int planes = 64 << li;
       for (int k = 0; k < nblk[li]; ++k) {
         const int stride = (k == 0 && li > 0) ? 2 : 1;
-        x = b.bottleneck(bp + "layer" + std::to_string(li + 1) + "." + std::to_string(k), x, cin, planes, stride, k == 0);
+        x = b.bottleneck(bp + "layer" + std::to_string(li + 1) + "." + std::to_string(k), x, cin, planes, stride, k == 0,
+                         (li == 0 && k == 0) ? cat : -1);
         cin = planes * 4;
       }
     }
@@ -964,7 +1002,7 @@ int run_op(Engine& e, Op& op, int B, const IO& io, hipStream_t s) {
     }
     case OP_MAXPOOL: {
       const Act& a = e.acts[op.in.act];
-      launch_maxpool3x3s2(aptr(e, op.in), aptr(e, op.out), B, a.H, a.W, a.C, s);
+      launch_maxpool3x3s2(aptr(e, op.in), aptr(e, op.out), B, a.H, a.W, a.C, e.acts[op.out.act].C, s);
       return POCO_OK;
     }
     case OP_BILINEAR: {

@@ -12,7 +12,7 @@
 void launch_stem_conv(const float* img_nchw, const float* w, const float* shift, float* out_nhwc, int B,
                       int H, int W, int ks, hipStream_t s);
 // 3x3 stride-2 pad-1 max pool, NHWC (resnet.py:206).
-void launch_maxpool3x3s2(const float* in, float* out, int B, int H, int W, int C, hipStream_t s);
+void launch_maxpool3x3s2(const float* in, float* out, int B, int H, int W, int C, int out_cs, hipStream_t s);
 // x2 bilinear upsample, align_corners=True, NHWC (hrnet.py:440).
 void launch_bilinear_up2x(const float* in, float* out, int B, int H, int W, int C, hipStream_t s);
 // out = ReLU( sum_k addend_k[b, y >> shift_k, x >> shift_k, :] )  (HRNet fuse, hrnet.py:257-264).

@@ -117,7 +117,7 @@ stem_conv4_kernel(const float* __restrict__ img, const float* __restrict__ w, co
 }
 
 __global__ void maxpool_kernel(const float4* __restrict__ in, float4* __restrict__ out, int B, int H, int W,
-                               int Ho, int Wo, int C4) {
+                               int Ho, int Wo, int C4, int outC16) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const long n = (long)B * Ho * Wo * C4;
   if (i >= n) return;
@@ -141,7 +141,7 @@ __global__ void maxpool_kernel(const float4* __restrict__ in, float4* __restrict
       m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
     }
   }
-  out[i] = m;
+  out[L16_F4((size_t)b * Ho + yo, xo, c, Wo, outC16)] = m;     // outC16 > C16: a channel slice of a wider buffer
 }
 
 // torch F.interpolate(scale_factor=2, mode='bilinear', align_corners=True) semantics
@@ -243,11 +243,11 @@ void launch_stem_conv(const float* img, const float* w, const float* shift, floa
     hipLaunchKernelGGL(stem_conv_kernel<7>, dim3(nblk(npix, 64)), dim3(256), 0, s, img, w, shift, out, B, H, W, Ho, Wo);
 }
 
-void launch_maxpool3x3s2(const float* in, float* out, int B, int H, int W, int C, hipStream_t s) {
+void launch_maxpool3x3s2(const float* in, float* out, int B, int H, int W, int C, int out_cs, hipStream_t s) {
   const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
   const long n = (long)B * Ho * Wo * (C / 4);
   hipLaunchKernelGGL(maxpool_kernel, dim3(nblk(n, 256)), dim3(256), 0, s, (const float4*)in, (float4*)out, B, H, W,
-                     Ho, Wo, C / 4);
+                     Ho, Wo, C / 4, out_cs / 16);
 }
 
 void launch_bilinear_up2x(const float* in, float* out, int B, int H, int W, int C, hipStream_t s) {
