@@ -83,6 +83,23 @@ def test_lanes_equivalent(variant, cuda):
                 assert torch.equal(v, b[k]), (lanes, k)
 
 
+@pytest.mark.parametrize("variant", ["hrnet_w48_cls-cliff", "resnet50-cliff"])
+def test_kconcat_shortcut_matches_separate_convs(variant, cuda, monkeypatch):
+    """layer1.0: bn3(conv3(t)) + bn_d(conv_d(x)) as ONE 1x1 conv over [t ; x] (engine.hip bottleneck(), cat mode) against
+    the two-launch form of the reference (hrnet.py:79-99 / resnet.py:101-121); only the summation order differs."""
+    batch = util.cuda_batch(synth.synth_batch(5, 31), cuda)
+    merged = util.make_engine(variant, max_batch=5)
+    monkeypatch.setenv("POCO_NO_KCAT", "1")
+    separate = util.make_engine(variant, max_batch=5)
+    monkeypatch.delenv("POCO_NO_KCAT")
+    names = lambda m: [n for n, _, _ in m.ops()]
+    assert any(n.endswith("layer1.0.conv3+downsample") for n in names(merged))
+    assert any(n.endswith("layer1.0.downsample.0") for n in names(separate)) and len(names(separate)) == len(names(merged)) + 1
+    a, b = merged(batch), separate(batch)
+    for k in ("pred_pose", "pred_shape", "pred_cam", "var_pose", "smpl_vertices"):
+        assert (a[k] - b[k]).abs().max().item() < 2e-5, k
+
+
 @pytest.mark.parametrize("variant,B", [("hrnet_w48_cls-cliff", 64), ("hrnet_w32-pare", 32), ("resnet50-cliff", 64)])
 def test_bench_batch_with_tuned_table(variant, B, cuda):
     """The batch sizes bench.py runs use the measured tile table (Winograd / LDS-DMA / persistent variants,
