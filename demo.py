@@ -36,10 +36,11 @@ def parse_args(argv=None):
     p.add_argument("--min_cutoff", type=float, default=0.004)
     p.add_argument("--beta", type=float, default=1.5)
     p.add_argument("--tracking", type=str, default=None,
-                   help="video mode: json {person_id: {'bbox': [[cx,cy,w,h],...], 'frames': [idx,...]}} "
-                        "(multi_person_tracker output); default = one centred track over all frames")
+                   help="video mode: json or the reference's tracking_results_<method>.pkl {person_id: {'bbox': [[cx,cy,w,h],...], "
+                        "'frames': [idx,...]}} (multi_person_tracker output); default = one centred track over all frames")
     p.add_argument("--skip_frame", type=int, default=1)
-    p.add_argument("--detections", type=str, default=None, help="json: {image name: [[cx,cy,w,h],...]}")
+    p.add_argument("--detections", type=str, default=None,
+                   help="json {image name: [[cx,cy,w,h],...]} or the reference's detection_results.pkl (per-image list)")
     p.add_argument("--smpl", type=str, default="data/smpl/SMPL_NEUTRAL.npz",
                    help="SMPL body model as .npz (tools/convert_smpl.py converts the licensed .pkl)")
     return p.parse_args(argv)

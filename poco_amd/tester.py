@@ -185,15 +185,20 @@ class POCOTester:
             }
         return results
 
-    def run_on_image_folder(self, image_folder: str, detections: Optional[dict], output_path: str, bbox_scale=1.0):
+    def run_on_image_folder(self, image_folder: str, detections, output_path: str, bbox_scale=1.0):
         from PIL import Image
         names = sorted(x for x in os.listdir(image_folder) if x.lower().endswith(IMG_EXT))
         frames, dets = [], []
         for n in names:
             img = np.asarray(Image.open(os.path.join(image_folder, n)).convert("RGB"))
             frames.append(img)
-            if detections and n in detections:
-                dets.append(np.asarray(detections[n], dtype=np.float32))
+            d = None
+            if isinstance(detections, dict):
+                d = detections.get(n)
+            elif detections is not None and len(frames) - 1 < len(detections):     # reference cache: indexed by image position
+                d = detections[len(frames) - 1]
+            if d is not None and len(d) > 0:
+                dets.append(np.asarray(d, dtype=np.float32).reshape(-1, 4))
             else:                       # no detector in scope: one centred square box over the image
                 H, W = img.shape[:2]
                 s = float(min(H, W))
@@ -221,9 +226,7 @@ def _run_on_video_folder(self, frame_folder: str, tracking_path: Optional[str], 
     first = np.asarray(Image.open(os.path.join(frame_folder, names[0])).convert("RGB"))
     H, W = first.shape[:2]
     if tracking_path:
-        with open(tracking_path) as f:
-            tracking = {k: {"bbox": np.asarray(v["bbox"], np.float32), "frames": np.asarray(v["frames"], np.int64)}
-                        for k, v in json.load(f).items()}
+        tracking = load_tracking(tracking_path)
     else:
         s = float(min(H, W))
         tracking = {"0": {"bbox": np.tile([[W / 2.0, H / 2.0, s, s]], (len(names), 1)).astype(np.float32),
@@ -248,8 +251,36 @@ def _run_on_video_folder(self, frame_folder: str, tracking_path: Optional[str], 
 POCOTester.run_on_video_folder = _run_on_video_folder
 
 
-def load_detections(path: Optional[str]) -> Optional[dict]:
-    if not path:
-        return None
+def _load_any(path: str):
+    """json, or the joblib/pickle caches the reference writes next to its outputs (demo.py:125-131,163-169)."""
+    if path.lower().endswith((".pkl", ".pickle", ".joblib")):
+        try:
+            import joblib
+            return joblib.load(path)
+        except ImportError:
+            import pickle
+            with open(path, "rb") as f:
+                return pickle.load(f)
     with open(path) as f:
         return json.load(f)
+
+
+def load_detections(path: Optional[str]):
+    """{image name: [[cx,cy,w,h],...]} (json) or the reference's `detection_results.pkl`: a sequence indexed by the
+    position of the image in the sorted folder listing (tester.py:153-169).  None = no detector output."""
+    return _load_any(path) if path else None
+
+
+def load_tracking(path: Optional[str]) -> Optional[dict]:
+    """{person_id: {'bbox': [T,4] (cx,cy,w,h), 'frames': [T]}} from json or the reference's
+    `tracking_results_<method>.pkl` (demo.py:125-131); tracks shorter than MIN_NUM_FRAMES = 25 frames are dropped as in
+    tester.py:133-136."""
+    if not path:
+        return None
+    raw = _load_any(path)
+    out = {}
+    for k, v in raw.items():
+        frames = np.asarray(v["frames"], np.int64).reshape(-1)
+        if path.lower().endswith(".json") or frames.shape[0] >= 25:
+            out[str(k)] = {"bbox": np.asarray(v["bbox"], np.float32).reshape(-1, 4), "frames": frames}
+    return out

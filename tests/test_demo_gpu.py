@@ -68,6 +68,16 @@ def test_demo_folder_end_to_end(tmp_path, cuda):
         assert np.abs(res["verts"] - ref["smpl_vertices"].numpy()).max() < 1e-3
         assert res["var_global"].shape == (len(d),) and res["var_global"].max() <= 0.99
         assert res["smpl_joints2d"].shape == (len(d), 49, 3)
+    # the reference's detector cache (joblib list indexed by image position, demo.py:163-169) gives the same results
+    import joblib
+    joblib.dump([np.asarray(dets[n], np.float32) for n in sorted(frames)], tmp_path / "detection_results.pkl")
+    args.detections = str(tmp_path / "detection_results.pkl")
+    args.output_folder = str(tmp_path / "out_pkl")
+    demo.main(args)
+    for n in frames:
+        a = dict(np.load(tmp_path / "out" / "imgs_" / (n[:-4] + "_poco.npz")))
+        b = dict(np.load(tmp_path / "out_pkl" / "imgs_" / (n[:-4] + "_poco.npz")))
+        assert all(np.array_equal(a[k], b[k]) for k in a)
 
 
 def _tester(tmp_path, variant="resnet50-cliff", cfg="configs/demo_poco_cliff_resnet50.yaml", extra=()):
