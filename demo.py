@@ -39,6 +39,7 @@ def parse_args(argv=None):
                    help="video mode: json or the reference's tracking_results_<method>.pkl {person_id: {'bbox': [[cx,cy,w,h],...], "
                         "'frames': [idx,...]}} (multi_person_tracker output); default = one centred track over all frames")
     p.add_argument("--skip_frame", type=int, default=1)
+    p.add_argument("--save_obj", action="store_true", help="save results as .obj files (meshes/<image|person>/<idx>.obj)")
     p.add_argument("--detections", type=str, default=None,
                    help="json {image name: [[cx,cy,w,h],...]} or the reference's detection_results.pkl (per-image list)")
     p.add_argument("--smpl", type=str, default="data/smpl/SMPL_NEUTRAL.npz",

@@ -56,3 +56,15 @@ def convert_crop_coords_to_orig_img(bbox, keypoints, crop_size):
     kp[:, :, 0] = (cx - h / 2)[..., None] + kp[:, :, 0]
     kp[:, :, 1] = (cy - h / 2)[..., None] + kp[:, :, 1]
     return kp
+
+
+def write_obj(path, verts, faces=None):
+    """Wavefront .obj of one mesh (the reference's --save_obj, tester.py:300-303,532-535: `meshes/<image or person>/
+    <idx>.obj`).  verts [V,3] float, faces [F,3] 0-based vertex ids or None (vertex cloud)."""
+    import os
+    os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
+    v = np.asarray(verts, np.float64).reshape(-1, 3)
+    with open(path, "w") as f:
+        f.write("".join("v %.6f %.6f %.6f\n" % (a, b, c) for a, b, c in v))
+        if faces is not None:
+            f.write("".join("f %d %d %d\n" % (a + 1, b + 1, c + 1) for a, b, c in np.asarray(faces, np.int64).reshape(-1, 3)))

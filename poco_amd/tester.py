@@ -62,6 +62,16 @@ class POCOTester:
         kw = model_kwargs(self.model_cfg)
         self.model = POCO(**kw, pretrained=args.ckpt, inf_model=getattr(args, "inf_model", "best"),
                           max_batch=max(int(args.batch_size), 1), smpl=args.smpl, device="cuda:0").finalize()
+        self.faces = None                       # triangle list for --save_obj, if the body-model file carries one
+        if isinstance(args.smpl, str) and os.path.isfile(args.smpl):
+            with np.load(args.smpl) as z:
+                if "faces" in z.files:
+                    self.faces = np.asarray(z["faces"], np.int64)
+
+    def _save_meshes(self, folder: str, verts: np.ndarray, names):
+        from .postproc import write_obj
+        for v, n in zip(verts, names):
+            write_obj(os.path.join(folder, n + ".obj"), v, self.faces)
 
     # ---- one batch of detections of one frame ---------------------------------------------------
     def make_batch(self, frame_u8: torch.Tensor, dets: np.ndarray, bbox_scale: float = 1.0) -> Dict[str, torch.Tensor]:
@@ -212,6 +222,9 @@ class POCOTester:
         for n, r in zip(names, results):
             if r is not None:
                 np.savez_compressed(os.path.join(output_path, os.path.splitext(n)[0] + "_poco.npz"), **r)
+                if getattr(self.args, "save_obj", False):          # tester.py:300-303
+                    self._save_meshes(os.path.join(output_path, "meshes", os.path.splitext(n)[0]), r["verts"],
+                                      [f"{i:06d}" for i in range(len(r["verts"]))])
         return {"images": len(names), "crops": n_crops, "seconds": dt, "fps": len(names) / max(dt, 1e-9),
                 "crops_per_s": n_crops / max(dt, 1e-9)}
 
@@ -242,6 +255,10 @@ def _run_on_video_folder(self, frame_folder: str, tracking_path: Optional[str], 
     os.makedirs(output_path, exist_ok=True)
     flat = {f"{pid}/{k}": v for pid, r in results.items() for k, v in r.items() if v is not None}
     np.savez_compressed(os.path.join(output_path, "poco_results.npz"), **flat)
+    if getattr(self.args, "save_obj", False):                      # tester.py:532-535
+        for pid, r in results.items():
+            sub = f"{int(pid):04d}" if str(pid).lstrip("-").isdigit() else str(pid)
+            self._save_meshes(os.path.join(output_path, "meshes", sub), r["verts"], [f"{int(f):06d}" for f in r["frame_ids"]])
     n_crops = sum(len(v["frames"]) for v in tracking.values())
     n_frames = len({int(f) for v in tracking.values() for f in v["frames"]})
     return {"images": n_frames, "crops": n_crops, "tracks": len(tracking), "seconds": dt,

@@ -78,6 +78,18 @@ def test_demo_folder_end_to_end(tmp_path, cuda):
         a = dict(np.load(tmp_path / "out" / "imgs_" / (n[:-4] + "_poco.npz")))
         b = dict(np.load(tmp_path / "out_pkl" / "imgs_" / (n[:-4] + "_poco.npz")))
         assert all(np.array_equal(a[k], b[k]) for k in a)
+    # --save_obj: meshes/<image>/<idx>.obj as tester.py:300-303 (faces come from the body-model file when it has them)
+    smpl_f = dict(smpl)
+    smpl_f["faces"] = np.stack([np.arange(0, 300), np.arange(1, 301), np.arange(2, 302)], 1).astype(np.int32)
+    np.savez(tmp_path / "smpl.npz", **smpl_f)
+    args.save_obj = True
+    args.output_folder = str(tmp_path / "out_obj")
+    demo.main(args)
+    res = dict(np.load(tmp_path / "out_obj" / "imgs_" / "im0_poco.npz"))
+    lines = (tmp_path / "out_obj" / "imgs_" / "meshes" / "im0" / "000001.obj").read_text().splitlines()
+    v = np.array([[float(t) for t in ln.split()[1:]] for ln in lines if ln.startswith("v ")])
+    assert v.shape == (6890, 3) and np.abs(v - res["verts"][1]).max() < 1e-5
+    assert sum(ln.startswith("f ") for ln in lines) == 300 and lines[6890] == "f 1 2 3"
 
 
 def _tester(tmp_path, variant="resnet50-cliff", cfg="configs/demo_poco_cliff_resnet50.yaml", extra=()):
