@@ -37,7 +37,7 @@ struct ParamDecl {
 
 enum OpType {
   OP_STEM, OP_CONV, OP_MAXPOOL, OP_BILINEAR, OP_FUSE, OP_AVGPOOL, OP_ATTN, OP_LC2D, OP_ROT6D, OP_COPY,
-  OP_BCAST, OP_SMPL, OP_CAMERA, OP_NCHW_OUT
+  OP_BCAST, OP_SMPL, OP_CAMERA, OP_NCHW_OUT, OP_CHAIN
 };
 
 // external buffer slots (inputs / outputs of poco_forward)
@@ -72,6 +72,8 @@ struct Op {
   float* wdev = nullptr;
   float* bdev = nullptr;
   float* wdev_wino = nullptr;   // 3x3 stride-1 convs: Winograd-transformed weights (ALG 3)
+  float* wdev2 = nullptr;       // OP_CHAIN: the second 1x1 conv (next block's conv1)
+  float* bdev2 = nullptr;
   // fuse
   Ref fsrc[4];        // terms may be channel slices of wider (merged-conv) buffers
   int fshift[4] = {0, 0, 0, 0};
@@ -178,6 +180,8 @@ struct Builder {
   bool region_seq = false;
   // POCO_NO_KCAT=1 (experiments): keep the projection shortcut of layer1.0 a separate conv + residual
   bool kcat = [] { const char* v = getenv("POCO_NO_KCAT"); return !(v && atoi(v)); }();
+  // POCO_NO_CHAIN=1 (experiments): conv3 of a layer1 block and conv1 of the next one as two launches
+  bool chain = [] { const char* v = getenv("POCO_NO_CHAIN"); return !(v && atoi(v)); }();
   void begin_parallel(int kind = 0) { ++cur_phase; cur_lane = 0; in_parallel = true; region_seq = (seq_mask >> kind) & 1; }
   void end_parallel() { in_parallel = false; }
   void lane(int k) { cur_lane = region_seq ? 0 : k % 4; }
@@ -315,6 +319,50 @@ struct Builder {
     int r = x;
     if (down) r = conv_bn(p + ".downsample.0", p + ".downsample.1", x, Cin, planes * 4, 1, stride, 0);
     return conv_bn(p + ".conv3", p + ".bn3", y, planes, planes * 4, 1, 1, 1, r);
+  }
+
+  // conv3 + residual + ReLU of block `pa` chained with conv1 + ReLU of block `pb` (planes = 64; csrc/bneck_chain.hip):
+  // t [.,64] , x [.,256]  ->  y [.,256] (returned) and u [.,64] (*u_out)
+  int chain_op(const std::string& pa, const std::string& pb, int t, int x, int* u_out) {
+    const Act at = e.acts[t];
+    const HostParam* w3 = P(pa + ".conv3.weight", {256, 64, 1, 1});
+    const HostParam* w1 = P(pb + ".conv1.weight", {64, 256, 1, 1});
+    std::vector<float> s3, b3, s1, b1;
+    bn_fold(pa + ".bn3", nullptr, 256, s3, b3);
+    bn_fold(pb + ".bn1", nullptr, 64, s1, b1);
+    Op op;
+    op.type = OP_CHAIN; op.name = pa + ".conv3+" + pb.substr(pb.rfind('.') + 1) + ".conv1";
+    op.in = R(t); op.res = R(x);
+    const int y = new_act(256, at.H, at.W), u = new_act(64, at.H, at.W);
+    op.out = R(y); op.out2 = R(u);
+    op.flops = 2.0 * at.H * at.W * (64.0 * 256 + 256.0 * 64);
+    if (!declare && w3 && w1) {
+      std::vector<float> p3(conv_packed_weight_floats(64, 256, 1)), p1(conv_packed_weight_floats(256, 64, 1));
+      conv_pack_weights(w3->data.data(), s3.data(), 256, 64, 1, 256, p3.data());
+      conv_pack_weights(w1->data.data(), s1.data(), 64, 256, 1, 64, p1.data());
+      op.wdev = upload(p3); op.bdev = upload(b3);
+      op.wdev2 = upload(p1); op.bdev2 = upload(b1);
+    }
+    push(std::move(op));
+    *u_out = u;
+    return y;
+  }
+
+  // layer1 of HRNet / ResNet-50: `nblk` Bottlenecks with planes = 64 at stride 1, the first with a projection shortcut
+  int layer1(const std::string& lp, int x, int cat, int nblk) {
+    x = bottleneck(lp + "0", x, 64, 64, 1, true, cat);
+    if (!chain) {
+      for (int k = 1; k < nblk; ++k) x = bottleneck(lp + std::to_string(k), x, 256, 64, 1, false);
+      return x;
+    }
+    int u = conv_bn(lp + "1.conv1", lp + "1.bn1", x, 256, 64, 1, 1, 1);
+    for (int k = 1; k < nblk; ++k) {
+      const std::string q = lp + std::to_string(k);
+      const int t = conv_bn(q + ".conv2", q + ".bn2", u, 64, 64, 3, 1, 1);
+      if (k + 1 < nblk) x = chain_op(q, lp + std::to_string(k + 1), t, x, &u);
+      else x = conv_bn(q + ".conv3", q + ".bn3", t, 64, 256, 1, 1, 1, x);
+    }
+    return x;
   }
 
   int stem(const std::string& p, int ks, int H) {                   // conv1+bn1+relu from the NCHW image
@@ -481,8 +529,7 @@ struct Builder {
     int x = stem(p, 3, 224);
     const int cat = kcat ? new_act(128, 56, 56) : -1;      // [layer1.0 conv2 output | stem output], see bottleneck()
     x = conv_bn(p + "conv2", p + "bn2", x, 64, 64, 3, 2, 1, -1, false, 0, kcat ? R(cat, 64) : Ref());
-    for (int k = 0; k < 4; ++k)
-      x = bottleneck(p + "layer1." + std::to_string(k), x, k == 0 ? 64 : 256, 64, 1, k == 0, k == 0 ? cat : -1);
+    x = layer1(p + "layer1.", x, cat, 4);
     std::vector<int> ys = {x};
     std::vector<int> prev_ch = {256};
     const int nmod[3] = {1, 4, 3};
@@ -701,12 +748,13 @@ bool build_graph(Engine& e, bool declare) {
     x = p;
     const int nblk[4] = {3, 4, 6, 3};
     int cin = 64;
-    for (int li = 0; li < 4; ++li) {
+    x = b.layer1(bp + "layer1.", x, cat, nblk[0]);
+    cin = 256;
+    for (int li = 1; li < 4; ++li) {
       const int planes = 64 << li;
       for (int k = 0; k < nblk[li]; ++k) {
         const int stride = (k == 0 && li > 0) ? 2 : 1;
-        x = b.bottleneck(bp + "layer" + std::to_string(li + 1) + "." + std::to_string(k), x, cin, planes, stride, k == 0,
-                         (li == 0 && k == 0) ? cat : -1);
+        x = b.bottleneck(bp + "layer" + std::to_string(li + 1) + "." + std::to_string(k), x, cin, planes, stride, k == 0);
         cin = planes * 4;
       }
     }
@@ -1043,6 +1091,11 @@ int run_op(Engine& e, Op& op, int B, const IO& io, hipStream_t s) {
       float* y = ext_out(io, op.out2.ext);
       launch_rot6d(aptr(e, op.in), astride(e, op.in), aptr(e, op.out), astride(e, op.out), y, 216, B, s);
       return POCO_OK;
+    }
+    case OP_CHAIN: {
+      const Act& a = e.acts[op.in.act];
+      return launch_bneck_chain(aptr(e, op.in), a.C, aptr(e, op.res), e.acts[op.res.act].C, aptr(e, op.out), e.acts[op.out.act].C,
+                                aptr(e, op.out2), e.acts[op.out2.act].C, op.wdev, op.bdev, op.wdev2, op.bdev2, B, a.H, a.W, s);
     }
     case OP_COPY: {
       const float* src; int sstride;

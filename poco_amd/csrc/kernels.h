@@ -12,6 +12,10 @@
 void launch_stem_conv(const float* img_nchw, const float* w, const float* shift, float* out_nhwc, int B,
                       int H, int W, int ks, hipStream_t s);
 // 3x3 stride-2 pad-1 max pool, NHWC (resnet.py:206).
+// conv3 + residual + ReLU of one Bottleneck chained with conv1 + ReLU of the next (bneck_chain.hip)
+int launch_bneck_chain(const float* t, int t_cs, const float* res, int res_cs, float* y, int y_cs, float* u, int u_cs,
+                       const float* w3, const float* b3, const float* w1, const float* b1, int B, int H, int W,
+                       hipStream_t s);
 void launch_maxpool3x3s2(const float* in, float* out, int B, int H, int W, int C, int out_cs, hipStream_t s);
 // x2 bilinear upsample, align_corners=True, NHWC (hrnet.py:440).
 void launch_bilinear_up2x(const float* in, float* out, int B, int H, int W, int C, hipStream_t s);

@@ -100,6 +100,24 @@ def test_kconcat_shortcut_matches_separate_convs(variant, cuda, monkeypatch):
         assert (a[k] - b[k]).abs().max().item() < 2e-5, k
 
 
+@pytest.mark.parametrize("variant", ["hrnet_w32-pare", "resnet50-cliff"])
+def test_chained_bottleneck_matches_separate_convs(variant, cuda, monkeypatch):
+    """layer1: conv3 + residual + ReLU of block k and conv1 + ReLU of block k+1 as one kernel (csrc/bneck_chain.hip: the
+    256-channel tensor stays in registers between the two GEMMs) against the two-launch form (hrnet.py:79-99 /
+    resnet.py:101-121).  Ragged batch: 7 crops = 21952 pixels = 1372 sub-tiles, not a multiple of the 2048 waves."""
+    batch = util.cuda_batch(synth.synth_batch(7, 77), cuda)
+    chained = util.make_engine(variant, max_batch=7)
+    monkeypatch.setenv("POCO_NO_CHAIN", "1")
+    separate = util.make_engine(variant, max_batch=7)
+    monkeypatch.delenv("POCO_NO_CHAIN")
+    names = lambda m: [n for n, _, _ in m.ops()]
+    nchain = sum("conv3+" in n and n.endswith(".conv1") for n in names(chained))
+    assert nchain == (2 if variant.startswith("hrnet") else 1) and len(names(separate)) == len(names(chained)) + nchain
+    a, b = chained(batch), separate(batch)
+    for k in ("pred_pose", "pred_shape", "pred_cam", "var_pose", "smpl_vertices"):
+        assert (a[k] - b[k]).abs().max().item() < 2e-5, k
+
+
 @pytest.mark.parametrize("variant,B", [("hrnet_w48_cls-cliff", 64), ("hrnet_w32-pare", 32), ("resnet50-cliff", 64)])
 def test_bench_batch_with_tuned_table(variant, B, cuda):
     """The batch sizes bench.py runs use the measured tile table (Winograd / LDS-DMA / persistent variants,
