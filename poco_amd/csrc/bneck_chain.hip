@@ -74,12 +74,19 @@ bneck_chain_kernel(const ChainParams p) {
         __builtin_amdgcn_sched_barrier(0);
       }
       const float bv[4] = {tb[c].x, tb[c].y, tb[c].z, tb[c].w};
+      // groups of 4 n-tiles, k-step outermost inside a group: consecutive MFMAs never share an accumulator
 #pragma unroll
-      for (int n = 0; n < 16; ++n) {
-        const float4 a = w3s[(c * 16 + n) * 64 + lane];
-        const float av[4] = {a.x, a.y, a.z, a.w};
+      for (int n0 = 0; n0 < 16; n0 += 4) {
+        float4 a[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], bv[j], acc[n], 0, 0, 0);
+        for (int n = 0; n < 4; ++n) a[n] = w3s[(c * 16 + n0 + n) * 64 + lane];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int n = 0; n < 4; ++n) {
+            const float aj = (j == 0) ? a[n].x : (j == 1) ? a[n].y : (j == 2) ? a[n].z : a[n].w;
+            acc[n0 + n] = __builtin_amdgcn_mfma_f32_16x16x4f32(aj, bv[j], acc[n0 + n], 0, 0, 0);
+          }
       }
     }
     // y = ReLU(acc + shift + residual): stored, and kept in place as the B operand of the second GEMM
@@ -99,13 +106,16 @@ bneck_chain_kernel(const ChainParams p) {
     for (int n = 0; n < 4; ++n) acc2[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int c = 0; c < 16; ++c) {
+      float4 a[4];
 #pragma unroll
-      for (int n = 0; n < 4; ++n) {
-        const float4 a = w1s[(c * 4 + n) * 64 + lane];
-        const float av[4] = {a.x, a.y, a.z, a.w};
+      for (int n = 0; n < 4; ++n) a[n] = w1s[(c * 4 + n) * 64 + lane];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc2[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], acc[c][j], acc2[n], 0, 0, 0);
-      }
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+          const float aj = (j == 0) ? a[n].x : (j == 1) ? a[n].y : (j == 2) ? a[n].z : a[n].w;
+          acc2[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(aj, acc[c][j], acc2[n], 0, 0, 0);
+        }
     }
     float* up = p.u + (size_t)row * p.u_rs + xo;
 #pragma unroll
