@@ -44,7 +44,7 @@ static int conv_common(const float* d_in, int B, int H, int W, int Cin, const fl
   std::vector<float> shift(Cout16, 0.f);
   if (h_shift)
     for (int i = 0; i < Cout; ++i) shift[i] = h_shift[i];
-  DevBuf dw, db, dwu;
+  DevBuf dw, db, dwu, dwu4;
   POCO_HIP_CHECK(dw.upload(packed));
   POCO_HIP_CHECK(db.upload(shift));
   ConvDesc d{};
@@ -54,6 +54,13 @@ static int conv_common(const float* d_in, int B, int H, int W, int Cin, const fl
     conv_pack_weights(wt.data(), h_scale, Cout, Cin, 4, Cout16, pu.data());
     POCO_HIP_CHECK(dwu.upload(pu));
     d.wfrag_wino = dwu.p;
+    if (cfg7 && cfg7[6] == 7) {                   // experimental F(4x4,3x3): 36-position fragments
+      std::vector<float> wt4, pu4(conv_packed_weight_floats(Cin, Cout16, 6));
+      conv_wino4_transform_weights(h_w, Cout, Cin, &wt4);
+      conv_pack_weights(wt4.data(), h_scale, Cout, Cin, 6, Cout16, pu4.data());
+      POCO_HIP_CHECK(dwu4.upload(pu4));
+      d.wfrag_wino4 = dwu4.p;
+    }
   }
   d.in = d_in; d.in_cs = Cin; d.in_co = 0;
   d.res = d_res; d.res_cs = Cout; d.res_co = 0;
@@ -126,11 +133,18 @@ extern "C" int poco_tune_conv(int B, int H, int W, int Cin, int Cout, int ks, in
   const float ws = 1.0f / sqrtf((float)(Cin * ks * ks));
   for (auto& v : hw) v = rnd() * ws;
   for (auto& v : hb) v = rnd() * 0.1f;
-  DevBuf din, dw, db, dout, dwu;
+  DevBuf din, dw, db, dout, dwu, dwu4;
   if (ks == 3 && stride == 1) {
     std::vector<float> hu((size_t)16 * Cin * Cout);
     for (auto& v : hu) v = rnd() * ws;
     POCO_HIP_CHECK(dwu.upload(hu));
+    bool any7 = false;
+    for (int i = 0; i < ncfg; ++i) any7 = any7 || cfgs6[CONV_CFG_INTS * i + 6] == 7;
+    if (any7) {
+      std::vector<float> hu4((size_t)36 * Cin * Cout);
+      for (auto& v : hu4) v = rnd() * ws;
+      POCO_HIP_CHECK(dwu4.upload(hu4));
+    }
   }
   POCO_HIP_CHECK(din.upload(hin));
   POCO_HIP_CHECK(dw.upload(hw));
@@ -138,7 +152,7 @@ extern "C" int poco_tune_conv(int B, int H, int W, int Cin, int Cout, int ks, in
   POCO_HIP_CHECK(hipMalloc(&dout.p, nout * sizeof(float)));
   ConvDesc d{};
   d.in = din.p; d.in_cs = Cin; d.out = dout.p; d.out_cs = Cout; d.wfrag = dw.p; d.bias = db.p;
-  d.wfrag_wino = dwu.p;
+  d.wfrag_wino = dwu.p; d.wfrag_wino4 = dwu4.p;
   d.B = B; d.H = H; d.W = W; d.Cin = Cin; d.Cout = Cout; d.ks = ks; d.stride = stride; d.act = 1;
   hipEvent_t e0, e1;
   POCO_HIP_CHECK(hipEventCreate(&e0));

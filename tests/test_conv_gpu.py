@@ -227,3 +227,36 @@ def test_conv1x1_register_gemm_rejects_3x3(cuda):
     w = np.zeros((16, 16, 3, 3), np.float32)
     with pytest.raises(RuntimeError):
         ops.conv2d_nhwc(x, w, cfg=(4, 2, 2, 2, 2, 1, 6))
+
+
+WINO4 = [
+    # B, H, W, Cin, Cout, res
+    (2, 56, 56, 48, 48, True),      # HRNet-W48 branch 0 BasicBlock conv
+    (3, 28, 28, 96, 96, False),
+    (2, 56, 56, 32, 32, True),      # W32
+    (5, 14, 14, 64, 48, True),      # 14 = 3.5 tiles: ragged right/bottom tiles
+    (3, 7, 7, 32, 16, False),
+    (1, 13, 9, 16, 32, True),       # ragged plane
+    (1, 1, 1, 16, 16, False),       # one pixel
+    (7, 12, 8, 160, 80, True),      # K = 10 slices; tiles not a multiple of the 16 / 32 per block
+]
+
+
+@pytest.mark.parametrize("cfg", [(1, 1, 1, 3, 1, 1, 7), (1, 2, 2, 3, 1, 1, 7), (1, 3, 1, 3, 1, 1, 7), (1, 3, 2, 3, 1, 1, 7)],
+                         ids=lambda c: "-".join(map(str, c)))
+@pytest.mark.parametrize("case", WINO4, ids=lambda c: "x".join(map(str, c)))
+def test_conv_winograd_f4x4_experimental(case, cfg, cuda):
+    """ALG 7 (experimental, not in the tuning table): Winograd F(4x4,3x3) for the 3x3 stride-1 convs of hrnet.py:42-58.
+    Tolerance 2e-4 * max|ref|: the F(4x4) transforms (constants up to 8) amplify fp32 rounding ~10x over F(2x2)."""
+    from poco_amd import ops
+    B, H, W, Cin, Cout, has_res = case
+    rng = np.random.default_rng(B * 313 + Cin + Cout)
+    x = rng.standard_normal((B, H, W, Cin)).astype(np.float32)
+    w = (rng.standard_normal((Cout, Cin, 3, 3)) / np.sqrt(9 * Cin)).astype(np.float32)
+    scale = rng.uniform(0.5, 1.5, Cout).astype(np.float32)
+    shift = rng.uniform(-0.5, 0.5, Cout).astype(np.float32)
+    res = rng.standard_normal((B, H, W, Cout)).astype(np.float32) if has_res else None
+    ref = _ref(x, w, scale, shift, 1, res, True)
+    out = ops.conv2d_nhwc(torch.from_numpy(x).to(cuda), w, scale, shift, 1,
+                          None if res is None else torch.from_numpy(res).to(cuda), True, cfg=cfg).cpu().numpy()
+    assert np.abs(out - ref).max() <= 2e-4 * max(1.0, np.abs(ref).max())
