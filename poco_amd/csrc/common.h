@@ -40,8 +40,8 @@ struct ConvCfg {
                // 2: ALG 1 persistent over tiles; 3: Winograd F(2x2,3x3) (MT ignored, NT in {1,2}, R even);
                // 4: Winograd, half-position waves + pipelined transform (WN = 2 halves, WM <= 4, NT <= 3)
                // 5: small-M linear (H = W = 1, ks = 1): K split over WM waves per 16 outputs (linear_mfma.hip)
-               // 7: Winograd F(4x4,3x3), experimental, stand-alone operator only (conv_wino4.hip): NT 1..3, WM = tile
-               //    groups per block (1|2), WN = 3
+               // 7: Winograd F(4x4,3x3), experimental, stand-alone operator only (conv_wino4.hip): NT 1..3, WM = 2 tile
+               //    groups, WN = 4 position quarters, R = output rows per slab (multiple of 4), NI slabs (<= 32 tiles)
                // 6: 1x1 conv (stride 1|2) as a register-direct GEMM, no LDS / barriers (gemm1x1.hip):
                //    (MT,NT) in {(2,4),(4,2),(4,4),(7,2),(7,4),(8,2)}, R = operand prefetch depth (2|3), NI = 1
 };
@@ -94,7 +94,8 @@ int gemm1x1_launch(const ConvDesc& d, const ConvCfg& cfg, hipStream_t stream);
 
 #include <vector>
 // ---- Winograd F(4x4,3x3), experimental (conv_wino4.hip), ALG 7 -------------------------------------------
-void conv_wino4_transform_weights(const float* w_oihw, int Cout, int Cin, std::vector<float>* out);
+size_t conv_wino4_packed_floats(int Cin, int Cout16);
+void conv_wino4_pack_weights(const float* w_oihw, const float* scale, int Cout, int Cin, int Cout16, float* dst);
 size_t conv_wino4_lds_bytes(const ConvDesc& d, const ConvCfg& cfg);
 int conv_wino4_launch(const ConvDesc& d, const ConvCfg& cfg, hipStream_t stream);
 

@@ -2,18 +2,26 @@
 //
 // 36 position GEMMs M_xi[co][tile] += U_xi[co][ci] V_xi[ci][tile] per 4x4 output tile = 2.25 MFMA-MACs per output
 // pixel and input channel instead of 4 for F(2x2,3x3) (ALG 3/4) and 9 for the direct conv: the lever beyond the MFMA
-// pipe rate for the 56x56 / 28x28 BasicBlock convs.  This first version fixes the structure and the
-// numerics; it is NOT tuned (no LDS staging of the input, single-buffered U, two barriers per 16-channel slice) and is
-// not selected by the tuning table.
+// pipe rate for the 56x56 / 28x28 BasicBlock convs.
 //
 //   V = B^T d B (6x6 window d),  M = sum_ci U .* V,  Y = A^T M A (4x4 outputs),  U = G g G^T (host, float64)
 //
-// Work split: a "tile group" is 16 tiles (the MFMA pixel dimension); three waves share a group and own two rows of
-// the 6x6 position grid each (12 positions x NT n-tiles = 36*NT accumulator VGPRs... x4).  Every wave reads the whole
-// 6x6 window of its lanes' tiles (column by column, straight from global memory in the L16 layout) but forms only its
-// two rows of B^T d, then its 12 entries of V.  After the K loop a wave reduces its rows along the columns
-// (Z = M A, 2 x 4 values), the three waves exchange Z through LDS, and wave r finishes n-tile r: Y = A^T Z, bias,
-// residual, activation, 16 pixels x 4 channels per lane.
+// Shape of this kernel
+//   * K is walked in slices of FOUR input channels = one v_mfma_f32_16x16x4_f32 per (position, n-tile): the U fragments
+//     of a slice are 36 x NT x 256 B (27 KiB at NT = 3) and the raw patch 16 B per pixel, so several slices fit in LDS
+//     at once (a 16-channel slice of F(4x4) would need 108 KiB of U alone).  Lanes carry ONE channel: the window,
+//     B^T d B and V are plain floats (12 + 9 + 6 VGPRs instead of their float4 versions).
+//   * a tile group = 16 tiles (the MFMA pixel dimension); FOUR waves share a group and own 9 of the 36 positions each
+//     (position = 6 xi + nu, wave q owns 9q .. 9q+8: 1.5 rows of the position grid), 9 x NT accumulators per wave;
+//     block = 2 groups = 8 waves.  A wave reads the 6x6 window of its lanes' tiles column by column from the LDS
+//     patch, forms the two rows of B^T d it needs and its 9 entries of V.
+//   * weights: packed as [Cin/4][9 position quads][Cout/16][64 lanes][4] - lane (co, g) holds U[4 quad + j][co][4 c4 + g]
+//     for j = 0..3, so one ds_read_b128 feeds the A operands of four positions.
+//   * after the K loop a wave reduces its (partial) rows along the columns (Z = M A, 2 x 4 values per n-tile); the four
+//     waves of a group exchange Z through LDS one n-tile at a time and wave q finishes n-tile q: Y = A^T Z, bias,
+//     residual, activation, 16 pixels x 4 channels per lane.
+// State: correct and structurally sized, NOT tuned: patch and fragments are staged with plain loads and two barriers
+// per slice (no LDS-DMA ring yet), blocks are not persistent.
 #include "conv_mfma_types.h"
 
 namespace {
@@ -22,208 +30,280 @@ struct W4Params {
   const float* in;
   const float* res;
   float* out;
-  const float4* ufrag;   // [36 positions][Cin/16][Cout16/16][64] float4 (conv_pack_weights, ks = 6)
+  const float4* ufrag;   // [Cin/4][9][Cout16/16][64] float4
   const float* bias;
-  int B, H, W, nC16, nT16;
+  int B, H, W, nC4, nT16;
   int in_rs, in_ss, res_rs, out_rs, out_ss;
-  int TX, TY, ntiles;    // tiles per row / column of an image, total tiles
-  int G;                 // tile groups per block (block = 3 * G waves)
+  int R, NI, S, nbands, TX, PR, PW, npos, tiles_per_slab;
   int act, res_after_act;
-  FastDiv dTX, dTY;
+  FastDiv dPW, dSlab, dBands, dTX, dTslab;
 };
 
-// rows of B^T (input transform) and of A^T (output transform) of F(4x4,3x3) [Lavin & Gray 2016]
+// row R of B^T applied to six values (input transform) [Lavin & Gray 2016]
 template <int R>
-__device__ __forceinline__ float4 bt_row(const float4& d0, const float4& d1, const float4& d2, const float4& d3, const float4& d4,
-                                         const float4& d5) {
-  auto c = [&](auto f) { return make_float4(f(d0.x, d1.x, d2.x, d3.x, d4.x, d5.x), f(d0.y, d1.y, d2.y, d3.y, d4.y, d5.y),
-                                            f(d0.z, d1.z, d2.z, d3.z, d4.z, d5.z), f(d0.w, d1.w, d2.w, d3.w, d4.w, d5.w)); };
-  if constexpr (R == 0) return c([](float a, float b, float cc, float d, float e, float f) { (void)b; (void)d; (void)f; return 4.f * a - 5.f * cc + e; });
-  else if constexpr (R == 1) return c([](float a, float b, float cc, float d, float e, float f) { (void)a; (void)f; return -4.f * (b + cc) + d + e; });
-  else if constexpr (R == 2) return c([](float a, float b, float cc, float d, float e, float f) { (void)a; (void)f; return 4.f * (b - cc) - d + e; });
-  else if constexpr (R == 3) return c([](float a, float b, float cc, float d, float e, float f) { (void)a; (void)f; return 2.f * (d - b) - cc + e; });
-  else if constexpr (R == 4) return c([](float a, float b, float cc, float d, float e, float f) { (void)a; (void)f; return 2.f * (b - d) - cc + e; });
-  else return c([](float a, float b, float cc, float d, float e, float f) { (void)a; (void)cc; (void)e; return 4.f * b - 5.f * d + f; });
+__device__ __forceinline__ float bt_row(float a, float b, float c, float d, float e, float f) {
+  if constexpr (R == 0) return 4.f * a - 5.f * c + e;
+  else if constexpr (R == 1) return -4.f * (b + c) + d + e;
+  else if constexpr (R == 2) return 4.f * (b - c) - d + e;
+  else if constexpr (R == 3) return 2.f * (d - b) - c + e;
+  else if constexpr (R == 4) return 2.f * (b - d) - c + e;
+  else return 4.f * b - 5.f * d + f;
 }
-__device__ __forceinline__ float4 bt_row_rt(int r, const float4* t) {     // runtime row index, fully unrolled callers
-  switch (r) {
-    case 0: return bt_row<0>(t[0], t[1], t[2], t[3], t[4], t[5]);
-    case 1: return bt_row<1>(t[0], t[1], t[2], t[3], t[4], t[5]);
-    case 2: return bt_row<2>(t[0], t[1], t[2], t[3], t[4], t[5]);
-    case 3: return bt_row<3>(t[0], t[1], t[2], t[3], t[4], t[5]);
-    case 4: return bt_row<4>(t[0], t[1], t[2], t[3], t[4], t[5]);
-    default: return bt_row<5>(t[0], t[1], t[2], t[3], t[4], t[5]);
-  }
-}
-// A^T row i applied to six values m0..m5
-__device__ __forceinline__ f32x4 at_row(int i, const f32x4& m0, const f32x4& m1, const f32x4& m2, const f32x4& m3, const f32x4& m4,
-                                        const f32x4& m5) {
-  switch (i) {
-    case 0: return m0 + m1 + m2 + m3 + m4;
-    case 1: return (m1 - m2) + 2.f * (m3 - m4);
-    case 2: return (m1 + m2) + 4.f * (m3 + m4);
-    default: return (m1 - m2) + 8.f * (m3 - m4) + m5;
-  }
+// A^T[i][k] (output transform)
+__host__ __device__ constexpr float at_c(int i, int k) {
+  constexpr float A[4][6] = {{1, 1, 1, 1, 1, 0}, {0, 1, -1, 2, -2, 0}, {0, 1, 1, 4, 4, 0}, {0, 1, -1, 8, -8, 1}};
+  return A[i][k];
 }
 
-template <int NT, int PROW>
-__device__ __forceinline__ void wino4_wave(const W4Params& p, float4* smem, int grp, int nt0, int lane, int wave, int nwaves) {
+constexpr int W4_MAXP = 2;      // patch positions staged per thread and slice (npos <= 2 * 512)
+
+template <int NT, int Q>
+__device__ __forceinline__ void wino4_wave(const W4Params& p, float4* smem, int grp, int nt0, int lane, int wave) {
+  constexpr int P0 = 9 * Q;                 // first position of this wave
+  constexpr int RA = P0 / 6;                // its two position rows: RA (from column P0 % 6 on) and RA + 1
   const int idx = lane & 15, g = lane >> 4;
-  // ---- this lane's tile ------------------------------------------------------------------------------------
-  const int tile = (blockIdx.x * p.G + grp) * 16 + idx;
-  const bool tvalid = tile < p.ntiles;
-  const uint32_t tc = (uint32_t)min(tile, p.ntiles - 1);
-  const uint32_t trow = fdiv(tc, p.dTX);                 // b * TY + ty
-  const int tx = (int)(tc - trow * (uint32_t)p.TX);
-  const uint32_t b = fdiv(trow, p.dTY);
-  const int ty = (int)(trow - b * (uint32_t)p.TY);
-  int rowoff[6], coloff[6];                              // float offsets of the window rows / columns, -1 = padding
+  const int tid = wave * 64 + lane;
+  float4* raw = smem;                                       // [npos] float4 = 4 channels of one patch position
+  float4* ul = smem + ((p.npos + 63) & ~63);                // [9][NT][64] float4
+  const float* rawf = reinterpret_cast<const float*>(raw);
+
+  // ---- this lane's tile -------------------------------------------------------------------------------------------
+  const int s0 = blockIdx.x * p.NI;
+  const uint32_t tidx = (uint32_t)(grp * 16 + idx);
+  const uint32_t sl = fdiv(tidx, p.dTslab);
+  const uint32_t rem = tidx - sl * (uint32_t)p.tiles_per_slab;
+  const uint32_t tyl = fdiv(rem, p.dTX);
+  const int tx = (int)(rem - tyl * (uint32_t)p.TX);
+  const uint32_t s = (uint32_t)s0 + sl;
+  const uint32_t b = fdiv(s, p.dBands);
+  const int band = (int)(s - b * (uint32_t)p.nbands);
+  const int oy0 = band * p.R + 4 * (int)tyl;
+  const bool tvalid = sl < (uint32_t)p.NI && s < (uint32_t)p.S && oy0 < p.H;
+  const int base = tvalid ? (int)((sl * (uint32_t)p.PR + 4 * tyl) * (uint32_t)p.PW) + 4 * tx : 0;   // window top-left in the patch
+
+  // ---- patch positions this thread stages (decoded once) ----------------------------------------------------------
+  int goff[W4_MAXP];
 #pragma unroll
-  for (int k = 0; k < 6; ++k) {
-    const int iy = 4 * ty - 1 + k, ix = 4 * tx - 1 + k;
-    rowoff[k] = (tvalid && (unsigned)iy < (unsigned)p.H) ? (int)((b * (uint32_t)p.H + (uint32_t)iy) * (uint32_t)p.in_rs) : -1;
-    coloff[k] = ((unsigned)ix < (unsigned)p.W) ? ix * 16 + 4 * g : -1;
+  for (int k = 0; k < W4_MAXP; ++k) {
+    goff[k] = -1;
+    const uint32_t pos = (uint32_t)(tid + k * 512);
+    if (pos < (uint32_t)p.npos) {
+      const uint32_t psl = fdiv(pos, p.dSlab);
+      const uint32_t prem = pos - psl * (uint32_t)(p.PR * p.PW);
+      const uint32_t prow = fdiv(prem, p.dPW);
+      const int pcol = (int)(prem - prow * (uint32_t)p.PW);
+      const uint32_t ps = (uint32_t)s0 + psl;
+      const uint32_t pb = fdiv(ps, p.dBands);
+      const int pband = (int)(ps - pb * (uint32_t)p.nbands);
+      const int iy = pband * p.R - 1 + (int)prow, ix = pcol - 1;
+      if (ps < (uint32_t)p.S && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
+        goff[k] = (int)((pb * (uint32_t)p.H + (uint32_t)iy) * (uint32_t)p.in_rs) + ix * 16;
+    }
   }
-  f32x4 acc[12][NT];
+
+  f32x4 acc[9][NT];
 #pragma unroll
-  for (int i = 0; i < 12; ++i)
+  for (int i = 0; i < 9; ++i)
 #pragma unroll
     for (int n = 0; n < NT; ++n) acc[i][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  const int nthreads = nwaves * 64;
-  const int tid = wave * 64 + lane;
-  for (int c = 0; c < p.nC16; ++c) {
-    // ---- two rows of B^T d, column by column (overlaps the U copy of the other waves) --------------------------
-    float4 t[2][6];
+  for (int c4 = 0; c4 < p.nC4; ++c4) {
+    __syncthreads();                                        // everybody is done with the previous slice
+    // ---- stage the 4-channel slice: patch (zero padded) and U fragments ------------------------------------------------
+    const size_t coff = (size_t)(c4 >> 2) * p.in_ss + (c4 & 3) * 4;
 #pragma unroll
-    for (int s = 0; s < 6; ++s) {
-      float4 d[6];
-#pragma unroll
-      for (int k = 0; k < 6; ++k) {
-        const bool ok = rowoff[k] >= 0 && coloff[s] >= 0;
-        const float4 v = *reinterpret_cast<const float4*>(p.in + (ok ? rowoff[k] + coloff[s] : 0) + (size_t)c * p.in_ss);
-        d[k] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = 0; k < W4_MAXP; ++k) {
+      const int pos = tid + k * 512;
+      if (pos < p.npos) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (goff[k] >= 0) v = *reinterpret_cast<const float4*>(p.in + goff[k] + coff);
+        raw[pos] = v;
       }
-      t[0][s] = bt_row<2 * PROW>(d[0], d[1], d[2], d[3], d[4], d[5]);
-      t[1][s] = bt_row<2 * PROW + 1>(d[0], d[1], d[2], d[3], d[4], d[5]);
     }
-    // ---- U fragments of slice c -> LDS: [36][NT][64] ----------------------------------------------------------
-    __syncthreads();                                     // everybody is done with the previous slice's fragments
-    for (int i = tid; i < 36 * NT * 64; i += nthreads) {
-      const int pos = i / (NT * 64), rem = i - pos * (NT * 64), n = rem >> 6, l = rem & 63;
-      smem[i] = p.ufrag[(((size_t)pos * p.nC16 + c) * p.nT16 + min(nt0 + n, p.nT16 - 1)) * 64 + l];
+    for (int i = tid; i < 9 * NT * 64; i += 512) {
+      const int quad = i / (NT * 64), r2 = i - quad * (NT * 64), n = r2 >> 6, l = r2 & 63;
+      ul[i] = p.ufrag[(((size_t)c4 * 9 + quad) * p.nT16 + min(nt0 + n, p.nT16 - 1)) * 64 + l];
     }
     __syncthreads();
-    // ---- V rows 2*PROW, 2*PROW+1 and their 12 position GEMMs ---------------------------------------------------
+    // ---- two rows of B^T d from the window, column by column ---------------------------------------------------------------
+    float t[2][6];
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
+    for (int sc = 0; sc < 6; ++sc) {
+      float d[6];
 #pragma unroll
-      for (int nu = 0; nu < 6; ++nu) {
-        const float4 v = bt_row_rt(nu, t[r]);            // (X B)[r][nu] = sum_s X[r][s] B^T[nu][s]
-        const float bv[4] = {v.x, v.y, v.z, v.w};
-        const int pos = (2 * PROW + r) * 6 + nu;
+      for (int k = 0; k < 6; ++k) d[k] = rawf[(base + k * p.PW + sc) * 4 + g];
+      t[0][sc] = bt_row<RA>(d[0], d[1], d[2], d[3], d[4], d[5]);
+      t[1][sc] = bt_row<RA + 1>(d[0], d[1], d[2], d[3], d[4], d[5]);
+    }
+    // ---- this wave's 9 entries of V and their position GEMMs (one MFMA each per n-tile) ------------------------------------------
+    float4 uq[4][NT];                                       // the (up to 4) position quads this wave touches
+    constexpr int QD0 = P0 / 4, NQD = (P0 + 8) / 4 - QD0 + 1;
 #pragma unroll
-        for (int n = 0; n < NT; ++n) {
-          const float4 a = smem[(pos * NT + n) * 64 + lane];
-          const float av[4] = {a.x, a.y, a.z, a.w};
+    for (int qd = 0; qd < NQD; ++qd)
 #pragma unroll
-          for (int j = 0; j < 4; ++j) acc[r * 6 + nu][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], bv[j], acc[r * 6 + nu][n], 0, 0, 0);
-        }
+      for (int n = 0; n < NT; ++n) uq[qd][n] = ul[((QD0 + qd) * NT + n) * 64 + lane];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+      const int pos = P0 + i;                               // compile-time after unrolling
+      const int xi = pos / 6, nu = pos - xi * 6;
+      const float* tr = t[xi - RA];
+      float v;
+      switch (nu) {
+        case 0: v = bt_row<0>(tr[0], tr[1], tr[2], tr[3], tr[4], tr[5]); break;
+        case 1: v = bt_row<1>(tr[0], tr[1], tr[2], tr[3], tr[4], tr[5]); break;
+        case 2: v = bt_row<2>(tr[0], tr[1], tr[2], tr[3], tr[4], tr[5]); break;
+        case 3: v = bt_row<3>(tr[0], tr[1], tr[2], tr[3], tr[4], tr[5]); break;
+        case 4: v = bt_row<4>(tr[0], tr[1], tr[2], tr[3], tr[4], tr[5]); break;
+        default: v = bt_row<5>(tr[0], tr[1], tr[2], tr[3], tr[4], tr[5]); break;
+      }
+      const int qd = pos / 4 - QD0, cj = pos & 3;
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        const float4 a4 = uq[qd][n];
+        const float a = cj == 0 ? a4.x : cj == 1 ? a4.y : cj == 2 ? a4.z : a4.w;
+        acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, v, acc[i][n], 0, 0, 0);
       }
     }
   }
-  // ---- Z = M A for this wave's two rows; exchange; wave PROW finishes n-tile PROW -----------------------------------
-  __syncthreads();                                       // U buffer is dead: reuse the LDS as [wave][n][2 rows][4 cols][64]
+
+  // ---- Z = M A (partial over this wave's columns), exchanged one n-tile at a time; wave Q finishes n-tile Q ------------------
+  float4* xch = smem;                                        // [8 waves][2 rows][4 cols][64] float4
+  const int oyb = oy0, oxb = 4 * tx;
 #pragma unroll
-  for (int n = 0; n < NT; ++n)
+  for (int n = 0; n < NT; ++n) {
+    __syncthreads();                                         // LDS free (K loop / previous round finished)
 #pragma unroll
     for (int r = 0; r < 2; ++r)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const f32x4 z = at_row(j, acc[r * 6 + 0][n], acc[r * 6 + 1][n], acc[r * 6 + 2][n], acc[r * 6 + 3][n], acc[r * 6 + 4][n],
-                               acc[r * 6 + 5][n]);
-        smem[(((wave * NT + n) * 2 + r) * 4 + j) * 64 + lane] = make_float4(z[0], z[1], z[2], z[3]);
+        f32x4 z = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+          const int pos = P0 + i, xi = pos / 6, nu = pos - xi * 6;
+          if (xi - RA == r && at_c(j, nu) != 0.f) z += at_c(j, nu) * acc[i][n];
+        }
+        xch[((wave * 2 + r) * 4 + j) * 64 + lane] = make_float4(z[0], z[1], z[2], z[3]);
       }
-  __syncthreads();
-  if (PROW >= NT || nt0 + PROW >= p.nT16) return;        // no barrier after this point
-  constexpr int n = PROW < NT ? PROW : 0;
-  f32x4 zf[6][4];
+    __syncthreads();
+    if (Q == n && nt0 + n < p.nT16) {
+      // rows of Z: 0 = q0.r0 | 1 = q0.r1 + q1.r0 | 2 = q1.r1 | 3 = q2.r0 | 4 = q2.r1 + q3.r0 | 5 = q3.r1
+      const int w0 = grp * 4;
+      auto ld = [&](int q, int r, int j) {
+        const float4 z = xch[(((w0 + q) * 2 + r) * 4 + j) * 64 + lane];
+        return (f32x4){z.x, z.y, z.z, z.w};
+      };
+      const float4 sh = *reinterpret_cast<const float4*>(p.bias + (nt0 + n) * 16 + g * 4);
 #pragma unroll
-  for (int xi = 0; xi < 6; ++xi)
+      for (int j = 0; j < 4; ++j) {
+        f32x4 zr[6];
+        zr[0] = ld(0, 0, j); zr[1] = ld(0, 1, j) + ld(1, 0, j); zr[2] = ld(1, 1, j);
+        zr[3] = ld(2, 0, j); zr[4] = ld(2, 1, j) + ld(3, 0, j); zr[5] = ld(3, 1, j);
+        const int ox = oxb + j;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const float4 z = smem[((((grp * 3 + xi / 2) * NT + n) * 2 + (xi & 1)) * 4 + j) * 64 + lane];
-      zf[xi][j] = (f32x4){z.x, z.y, z.z, z.w};
-    }
-  const float4 sh = *reinterpret_cast<const float4*>(p.bias + (nt0 + n) * 16 + g * 4);
+        for (int i = 0; i < 4; ++i) {
+          const int oy = oyb + i;
+          if (!tvalid || oy >= p.H || oy >= (band + 1) * p.R || ox >= p.W) continue;
+          f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int oy = 4 * ty + i;
+          for (int k = 0; k < 6; ++k)
+            if (at_c(i, k) != 0.f) v += at_c(i, k) * zr[k];
+          v[0] += sh.x; v[1] += sh.y; v[2] += sh.z; v[3] += sh.w;
+          const size_t orow = (size_t)b * p.H + oy;
+          float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (p.res) r = *reinterpret_cast<const float4*>(p.res + orow * p.res_rs + (size_t)(nt0 + n) * p.out_ss + ox * 16 + g * 4);
+          if (!p.res_after_act) { v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w; }
+          if (p.act == 1) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+          else if (p.act == 2) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int ox = 4 * tx + j;
-      if (!tvalid || oy >= p.H || ox >= p.W) continue;
-      f32x4 v = at_row(i, zf[0][j], zf[1][j], zf[2][j], zf[3][j], zf[4][j], zf[5][j]);
-      v[0] += sh.x; v[1] += sh.y; v[2] += sh.z; v[3] += sh.w;
-      const size_t orow = (size_t)b * p.H + oy;
-      float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (p.res) r = *reinterpret_cast<const float4*>(p.res + orow * p.res_rs + (size_t)(nt0 + n) * p.out_ss + ox * 16 + g * 4);
-      if (!p.res_after_act) { v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w; }
-      if (p.act == 1) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
-      else if (p.act == 2) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = 1.f / (1.f + __expf(-v[e]));
+            for (int e = 0; e < 4; ++e) v[e] = 1.f / (1.f + __expf(-v[e]));
+          }
+          if (p.res_after_act) { v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w; }
+          *reinterpret_cast<float4*>(p.out + orow * p.out_rs + (size_t)(nt0 + n) * p.out_ss + ox * 16 + g * 4) = make_float4(v[0], v[1], v[2], v[3]);
+        }
       }
-      if (p.res_after_act) { v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w; }
-      *reinterpret_cast<float4*>(p.out + orow * p.out_rs + (size_t)(nt0 + n) * p.out_ss + ox * 16 + g * 4) = make_float4(v[0], v[1], v[2], v[3]);
     }
   }
 }
 
 template <int NT>
-__global__ void __launch_bounds__(384)
+__global__ void __launch_bounds__(512)
 conv_wino4_kernel(const W4Params p) {
   extern __shared__ float4 smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int nwaves = blockDim.x >> 6;
-  const int grp = wave / 3, prow = wave - grp * 3;
+  const int grp = wave >> 2, q = wave & 3;
   const int nt0 = blockIdx.y * NT;
-  if (prow == 0) wino4_wave<NT, 0>(p, smem, grp, nt0, lane, wave, nwaves);
-  else if (prow == 1) wino4_wave<NT, 1>(p, smem, grp, nt0, lane, wave, nwaves);
-  else wino4_wave<NT, 2>(p, smem, grp, nt0, lane, wave, nwaves);
+  if (q == 0) wino4_wave<NT, 0>(p, smem, grp, nt0, lane, wave);
+  else if (q == 1) wino4_wave<NT, 1>(p, smem, grp, nt0, lane, wave);
+  else if (q == 2) wino4_wave<NT, 2>(p, smem, grp, nt0, lane, wave);
+  else wino4_wave<NT, 3>(p, smem, grp, nt0, lane, wave);
+}
+
+struct W4Geo { int R, NI, nbands, S, TX, PR, PW, npos, tps; };
+bool w4geo(const ConvDesc& d, const ConvCfg& cfg, W4Geo* g) {
+  if (d.ks != 3 || d.stride != 1 || cfg.NT < 1 || cfg.NT > 3 || cfg.WM != 2 || cfg.WN != 4 || d.Cin % 16 || d.Cout % 16) return false;
+  if (cfg.R < 4 || (cfg.R & 3) || cfg.NI < 1) return false;
+  g->TX = (d.W + 3) / 4;
+  const int Hc = (d.H + 3) / 4 * 4;
+  g->R = std::min(cfg.R, Hc); g->NI = cfg.NI;
+  g->nbands = (d.H + g->R - 1) / g->R;
+  if (g->NI > 1 && g->nbands > 1) return false;               // several slabs per block only for whole images
+  g->S = d.B * g->nbands;
+  g->tps = (g->R / 4) * g->TX;
+  if (g->NI * g->tps > 32) return false;                      // two groups of 16 tiles
+  g->PR = g->R + 2; g->PW = 4 * g->TX + 2;
+  g->npos = g->NI * g->PR * g->PW;
+  if (g->npos > W4_MAXP * 512) return false;
+  if ((long)d.B * d.H * d.W * std::max(std::max(d.in_cs, d.out_cs), d.res_cs) >= (1L << 31)) return false;
+  return true;
 }
 
 }  // namespace
 
-// U = G g G^T per (co, ci), float64 on the host, as a [Cout][Cin][36] "36-tap" filter for conv_pack_weights(ks = 6)
-void conv_wino4_transform_weights(const float* w_oihw, int Cout, int Cin, std::vector<float>* out) {
+// U = G g G^T per (co, ci), float64 on the host -> [36][Cout][Cin]
+static void wino4_u(const float* w_oihw, int Cout, int Cin, std::vector<double>* u) {
   static const double G[6][3] = {{1.0 / 4, 0, 0}, {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
                                  {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0, 0, 1}};
-  out->assign((size_t)Cout * Cin * 36, 0.f);
+  u->assign((size_t)36 * Cout * Cin, 0.0);
   for (size_t oc = 0; oc < (size_t)Cout * Cin; ++oc) {
     const float* gk = w_oihw + oc * 9;
     double t[6][3];
     for (int i = 0; i < 6; ++i)
       for (int j = 0; j < 3; ++j) t[i][j] = G[i][0] * gk[0 * 3 + j] + G[i][1] * gk[1 * 3 + j] + G[i][2] * gk[2 * 3 + j];
     for (int i = 0; i < 6; ++i)
-      for (int j = 0; j < 6; ++j)
-        (*out)[oc * 36 + i * 6 + j] = (float)(t[i][0] * G[j][0] + t[i][1] * G[j][1] + t[i][2] * G[j][2]);
+      for (int j = 0; j < 6; ++j) (*u)[(size_t)(i * 6 + j) * Cout * Cin + oc] = t[i][0] * G[j][0] + t[i][1] * G[j][1] + t[i][2] * G[j][2];
   }
 }
 
-// cfg: {MT = 1, NT (1..3), WM = tile groups per block (1|2), WN = 3, R = 1, NI = 1, ALG = 7}
+// packed fragments for ALG 7: [Cin/4][9 quads][Cout16/16][64 lanes][4]; lane = g*16 + co_l, value j = U[4 quad + j][co][4 c4 + g] * scale[co]
+size_t conv_wino4_packed_floats(int Cin, int Cout16) { return (size_t)36 * Cin * Cout16; }
+void conv_wino4_pack_weights(const float* w_oihw, const float* scale, int Cout, int Cin, int Cout16, float* dst) {
+  std::vector<double> u;
+  wino4_u(w_oihw, Cout, Cin, &u);
+  const int nC4 = Cin / 4, nT16 = Cout16 / 16;
+  for (int c4 = 0; c4 < nC4; ++c4)
+    for (int quad = 0; quad < 9; ++quad)
+      for (int nt = 0; nt < nT16; ++nt)
+        for (int lane = 0; lane < 64; ++lane) {
+          const int g = lane >> 4, co = nt * 16 + (lane & 15), ci = 4 * c4 + g;
+          float* o = dst + ((((size_t)c4 * 9 + quad) * nT16 + nt) * 64 + lane) * 4;
+          for (int j = 0; j < 4; ++j)
+            o[j] = co < Cout ? (float)(u[((size_t)(4 * quad + j) * Cout + co) * Cin + ci] * (scale ? (double)scale[co] : 1.0)) : 0.f;
+        }
+}
+
+// cfg: {MT = 1, NT (1..3), WM = 2 tile groups, WN = 4 position quarters, R = output rows per slab (multiple of 4), NI, ALG = 7}
 size_t conv_wino4_lds_bytes(const ConvDesc& d, const ConvCfg& cfg) {
-  if (d.ks != 3 || d.stride != 1 || cfg.NT < 1 || cfg.NT > 3 || cfg.WM < 1 || cfg.WM > 2 || cfg.WN != 3 || d.Cin % 16 || d.Cout % 16 ||
-      (long)d.B * d.H * d.W * std::max(std::max(d.in_cs, d.out_cs), d.res_cs) >= (1L << 31))
-    return 0;
-  return std::max<size_t>(36 * cfg.NT, (size_t)3 * cfg.WM * cfg.NT * 8) * 64 * sizeof(float4);
+  W4Geo g;
+  if (!w4geo(d, cfg, &g)) return 0;
+  const size_t stage = (size_t)((g.npos + 63) & ~63) + 9 * cfg.NT * 64, xch = 8 * 2 * 4 * 64;
+  return std::max(stage, xch) * sizeof(float4);
 }
 
 int conv_wino4_launch(const ConvDesc& d, const ConvCfg& cfg, hipStream_t stream) {
-  const size_t lds = conv_wino4_lds_bytes(d, cfg);
-  if (lds == 0 || !d.wfrag_wino4) {
-    poco_set_error("conv(winograd 4x4): needs ks = 3, stride 1, NT 1..3, WM 1|2, WN = 3 and the 36-position weight fragments");
+  W4Geo g;
+  if (!w4geo(d, cfg, &g) || !d.wfrag_wino4) {
+    poco_set_error("conv(winograd 4x4): needs ks = 3, stride 1, NT 1..3, WM = 2, WN = 4, R % 4 == 0, NI*(R/4)*ceil(W/4) <= 32 tiles and the ALG 7 weight fragments");
     return POCO_ERR_ARG;
   }
   if (d.act == 3) { poco_set_error("conv: the Winograd kernels have no per-channel ReLU split"); return POCO_ERR_ARG; }
@@ -232,18 +312,21 @@ int conv_wino4_launch(const ConvDesc& d, const ConvCfg& cfg, hipStream_t stream)
   p.res = d.res ? d.res + l16_chan_off(d.res_co, d.W) : nullptr;
   p.out = d.out + l16_chan_off(d.out_co, d.W);
   p.ufrag = reinterpret_cast<const float4*>(d.wfrag_wino4); p.bias = d.bias;
-  p.B = d.B; p.H = d.H; p.W = d.W; p.nC16 = d.Cin / 16; p.nT16 = d.Cout / 16;
+  p.B = d.B; p.H = d.H; p.W = d.W; p.nC4 = d.Cin / 4; p.nT16 = d.Cout / 16;
   p.in_rs = d.in_cs * d.W; p.in_ss = d.W * 16; p.res_rs = d.res_cs * d.W; p.out_rs = d.out_cs * d.W; p.out_ss = d.W * 16;
-  p.TX = (d.W + 3) / 4; p.TY = (d.H + 3) / 4; p.ntiles = d.B * p.TX * p.TY;
-  p.G = cfg.WM; p.act = d.act; p.res_after_act = d.res_after_act;
-  p.dTX = make_fastdiv(p.TX); p.dTY = make_fastdiv(p.TY);
-  const dim3 grid((p.ntiles + 16 * p.G - 1) / (16 * p.G), (p.nT16 + cfg.NT - 1) / cfg.NT);
+  p.R = g.R; p.NI = g.NI; p.S = g.S; p.nbands = g.nbands; p.TX = g.TX; p.PR = g.PR; p.PW = g.PW; p.npos = g.npos;
+  p.tiles_per_slab = g.tps;
+  p.act = d.act; p.res_after_act = d.res_after_act;
+  p.dPW = make_fastdiv(g.PW); p.dSlab = make_fastdiv(g.PR * g.PW); p.dBands = make_fastdiv(g.nbands);
+  p.dTX = make_fastdiv(g.TX); p.dTslab = make_fastdiv(g.tps);
+  const size_t lds = conv_wino4_lds_bytes(d, cfg);
+  const dim3 grid((g.S + g.NI - 1) / g.NI, (p.nT16 + cfg.NT - 1) / cfg.NT);
   auto fn = cfg.NT == 3 ? conv_wino4_kernel<3> : cfg.NT == 2 ? conv_wino4_kernel<2> : conv_wino4_kernel<1>;
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) { poco_set_error(std::string("hipFuncSetAttribute: ") + hipGetErrorString(e)); return POCO_ERR_HIP; }
   }
-  hipLaunchKernelGGL(fn, grid, dim3(3 * p.G * 64), lds, stream, p);
+  hipLaunchKernelGGL(fn, grid, dim3(512), lds, stream, p);
   POCO_HIP_CHECK(hipGetLastError());
   return POCO_OK;
 }

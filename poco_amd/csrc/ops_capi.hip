@@ -55,9 +55,8 @@ static int conv_common(const float* d_in, int B, int H, int W, int Cin, const fl
     POCO_HIP_CHECK(dwu.upload(pu));
     d.wfrag_wino = dwu.p;
     if (cfg7 && cfg7[6] == 7) {                   // experimental F(4x4,3x3): 36-position fragments
-      std::vector<float> wt4, pu4(conv_packed_weight_floats(Cin, Cout16, 6));
-      conv_wino4_transform_weights(h_w, Cout, Cin, &wt4);
-      conv_pack_weights(wt4.data(), h_scale, Cout, Cin, 6, Cout16, pu4.data());
+      std::vector<float> pu4(conv_wino4_packed_floats(Cin, Cout16));
+      conv_wino4_pack_weights(h_w, h_scale, Cout, Cin, Cout16, pu4.data());
       POCO_HIP_CHECK(dwu4.upload(pu4));
       d.wfrag_wino4 = dwu4.p;
     }

@@ -242,14 +242,22 @@ WINO4 = [
 ]
 
 
-@pytest.mark.parametrize("cfg", [(1, 1, 1, 3, 1, 1, 7), (1, 2, 2, 3, 1, 1, 7), (1, 3, 1, 3, 1, 1, 7), (1, 3, 2, 3, 1, 1, 7)],
-                         ids=lambda c: "-".join(map(str, c)))
+def _wino4_cfg(H, W, nt):
+    """(R, NI) of ALG 7 for a plane: as many 4-row tile bands as fit 32 tiles, whole images when several fit."""
+    TX, Hc = (W + 3) // 4, (H + 3) // 4 * 4
+    R = Hc if (Hc // 4) * TX <= 32 else max(4, 32 // TX * 4)
+    NI = max(1, min(32 // ((R // 4) * TX), 1024 // ((R + 2) * (4 * TX + 2)))) if R == Hc else 1
+    return (1, nt, 2, 4, R, NI, 7)
+
+
+@pytest.mark.parametrize("nt", [1, 2, 3])
 @pytest.mark.parametrize("case", WINO4, ids=lambda c: "x".join(map(str, c)))
-def test_conv_winograd_f4x4_experimental(case, cfg, cuda):
+def test_conv_winograd_f4x4_experimental(case, nt, cuda):
     """ALG 7 (experimental, not in the tuning table): Winograd F(4x4,3x3) for the 3x3 stride-1 convs of hrnet.py:42-58.
     Tolerance 2e-4 * max|ref|: the F(4x4) transforms (constants up to 8) amplify fp32 rounding ~10x over F(2x2)."""
     from poco_amd import ops
     B, H, W, Cin, Cout, has_res = case
+    cfg = _wino4_cfg(H, W, nt)
     rng = np.random.default_rng(B * 313 + Cin + Cout)
     x = rng.standard_normal((B, H, W, Cin)).astype(np.float32)
     w = (rng.standard_normal((Cout, Cin, 3, 3)) / np.sqrt(9 * Cin)).astype(np.float32)
