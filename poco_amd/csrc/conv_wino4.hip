@@ -20,8 +20,11 @@
 //   * after the K loop a wave reduces its (partial) rows along the columns (Z = M A, 2 x 4 values per n-tile); the four
 //     waves of a group exchange Z through LDS one n-tile at a time and wave q finishes n-tile q: Y = A^T Z, bias,
 //     residual, activation, 16 pixels x 4 channels per lane.
-// State: correct and structurally sized, NOT tuned: patch and fragments are staged with plain loads and two barriers
-// per slice (no LDS-DMA ring yet), blocks are not persistent.
+//   * staging: two 4-channel slices (a "pair") per barrier; patch and fragments of pair m+1 are streamed by LDS-DMA
+//     (global_load_lds_dwordx4: 64 patch positions x 16 B, or one 1 KiB fragment, per wave instruction) into the other
+//     half of a double buffer while pair m computes; every wave issues 1/8 of the pieces and waits for its own
+//     (s_waitcnt vmcnt(0)) before the barrier that publishes the pair.
+// State: correct, first pipelined version; not yet persistent, no XCD-aware walk, epilogue not overlapped.
 #include "conv_mfma_types.h"
 
 namespace {
@@ -34,7 +37,7 @@ struct W4Params {
   const float* bias;
   int B, H, W, nC4, nT16;
   int in_rs, in_ss, res_rs, out_rs, out_ss;
-  int R, NI, S, nbands, TX, PR, PW, npos, tiles_per_slab;
+  int R, NI, S, nbands, TX, PR, PW, npos, rawF4, tiles_per_slab;
   int act, res_after_act;
   FastDiv dPW, dSlab, dBands, dTX, dTslab;
 };
@@ -55,17 +58,30 @@ __host__ __device__ constexpr float at_c(int i, int k) {
   return A[i][k];
 }
 
-constexpr int W4_MAXP = 2;      // patch positions staged per thread and slice (npos <= 2 * 512)
+constexpr int W4_MAXP = 2;      // 64-position patch pieces per wave (npos <= 2 * 8 * 64)
+
+__device__ float4 g_zero_page_w4[1];   // 16 B of zeros: source of the padding lanes
+
+__device__ __forceinline__ void w4_dma16(const void* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(gsrc), "s"(lds_dst)
+      : "memory");
+}
 
 template <int NT, int Q>
 __device__ __forceinline__ void wino4_wave(const W4Params& p, float4* smem, int grp, int nt0, int lane, int wave) {
   constexpr int P0 = 9 * Q;                 // first position of this wave
   constexpr int RA = P0 / 6;                // its two position rows: RA (from column P0 % 6 on) and RA + 1
   const int idx = lane & 15, g = lane >> 4;
-  const int tid = wave * 64 + lane;
-  float4* raw = smem;                                       // [npos] float4 = 4 channels of one patch position
-  float4* ul = smem + ((p.npos + 63) & ~63);                // [9][NT][64] float4
-  const float* rawf = reinterpret_cast<const float*>(raw);
+  // LDS: [2 buffers][2 slices]{ raw: rawF4 float4 (4 channels of one patch position each) | U: [9][NT][64] float4 }
+  // patch position pos lives in float4 slot pos + pos/8 (one unused slot after every 8): tiles are 4 pixels = 64 B
+  // apart, so without the skew the 16 tile lanes of a window read hit 2 of the 8 four-bank groups (8-way conflict)
+  const int rawF4 = p.rawF4;
+  const int sliceF4 = rawF4 + 9 * NT * 64;
+  const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) float4*)smem;
 
   // ---- this lane's tile -------------------------------------------------------------------------------------------
   const int s0 = blockIdx.x * p.NI;
@@ -86,8 +102,11 @@ __device__ __forceinline__ void wino4_wave(const W4Params& p, float4* smem, int 
 #pragma unroll
   for (int k = 0; k < W4_MAXP; ++k) {
     goff[k] = -1;
-    const uint32_t pos = (uint32_t)(tid + k * 512);
-    if (pos < (uint32_t)p.npos) {
+    const uint32_t slot = (uint32_t)((wave + 8 * k) * 64 + lane);    // piece wave + 8k, lane = slot inside the piece
+    const uint32_t k9 = __umulhi(slot, 477218589u);                  // slot / 9 (exact for slot < 2^16)
+    const uint32_t r9 = slot - 9 * k9;
+    const uint32_t pos = 8 * k9 + r9;
+    if (r9 < 8 && pos < (uint32_t)p.npos) {
       const uint32_t psl = fdiv(pos, p.dSlab);
       const uint32_t prem = pos - psl * (uint32_t)(p.PR * p.PW);
       const uint32_t prow = fdiv(prem, p.dPW);
@@ -101,67 +120,91 @@ __device__ __forceinline__ void wino4_wave(const W4Params& p, float4* smem, int 
     }
   }
 
+  int woff[6][6];                                            // float offsets of this lane's 36 window elements in a slice
+#pragma unroll
+  for (int k = 0; k < 6; ++k)
+#pragma unroll
+    for (int sc = 0; sc < 6; ++sc) {
+      const int pos = base + k * p.PW + sc;
+      woff[k][sc] = (pos + (pos >> 3)) * 4 + g;
+    }
   f32x4 acc[9][NT];
 #pragma unroll
   for (int i = 0; i < 9; ++i)
 #pragma unroll
     for (int n = 0; n < NT; ++n) acc[i][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  for (int c4 = 0; c4 < p.nC4; ++c4) {
-    __syncthreads();                                        // everybody is done with the previous slice
-    // ---- stage the 4-channel slice: patch (zero padded) and U fragments ------------------------------------------------
-    const size_t coff = (size_t)(c4 >> 2) * p.in_ss + (c4 & 3) * 4;
+  const int npieces_raw = rawF4 >> 6;
+  auto issue_pair = [&](int m) {                            // slices 2m, 2m+1 -> buffer m & 1
 #pragma unroll
-    for (int k = 0; k < W4_MAXP; ++k) {
-      const int pos = tid + k * 512;
-      if (pos < p.npos) {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (goff[k] >= 0) v = *reinterpret_cast<const float4*>(p.in + goff[k] + coff);
-        raw[pos] = v;
+    for (int h = 0; h < 2; ++h) {
+      const int c4 = 2 * m + h;
+      const unsigned sb = lds_base + (unsigned)(((m & 1) * 2 + h) * sliceF4) * 16u;
+      const size_t coff = (size_t)(c4 >> 2) * p.in_ss + (c4 & 3) * 4;
+#pragma unroll
+      for (int k = 0; k < W4_MAXP; ++k) {
+        const int piece = wave + 8 * k;
+        if (piece < npieces_raw) {
+          const void* src = goff[k] >= 0 ? (const void*)(p.in + goff[k] + coff) : (const void*)g_zero_page_w4;
+          w4_dma16(src, (unsigned)__builtin_amdgcn_readfirstlane((int)(sb + (unsigned)piece * 1024u)));
+        }
+      }
+      for (int i = wave; i < 9 * NT; i += 8) {
+        const int quad = i / NT, n = i - quad * NT;
+        const float4* src = p.ufrag + (((size_t)c4 * 9 + quad) * p.nT16 + min(nt0 + n, p.nT16 - 1)) * 64 + lane;
+        w4_dma16(src, (unsigned)__builtin_amdgcn_readfirstlane((int)(sb + (unsigned)(rawF4 + i * 64) * 16u)));
       }
     }
-    for (int i = tid; i < 9 * NT * 64; i += 512) {
-      const int quad = i / (NT * 64), r2 = i - quad * (NT * 64), n = r2 >> 6, l = r2 & 63;
-      ul[i] = p.ufrag[(((size_t)c4 * 9 + quad) * p.nT16 + min(nt0 + n, p.nT16 - 1)) * 64 + l];
-    }
-    __syncthreads();
-    // ---- two rows of B^T d from the window, column by column ---------------------------------------------------------------
-    float t[2][6];
+  };
+  const int npairs = p.nC4 >> 1;
+  issue_pair(0);
+  for (int m = 0; m < npairs; ++m) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's pieces of pair m have landed
+    __syncthreads();                                        // ... everybody's; and everybody is done with pair m - 1
+    if (m + 1 < npairs) issue_pair(m + 1);
 #pragma unroll
-    for (int sc = 0; sc < 6; ++sc) {
-      float d[6];
+    for (int h = 0; h < 2; ++h) {
+      const float4* sbuf = smem + (size_t)((m & 1) * 2 + h) * sliceF4;
+      const float* rawf = reinterpret_cast<const float*>(sbuf);
+      const float4* ul = sbuf + rawF4;
+      // ---- two rows of B^T d from the window, column by column -------------------------------------------------------------
+      float t[2][6];
 #pragma unroll
-      for (int k = 0; k < 6; ++k) d[k] = rawf[(base + k * p.PW + sc) * 4 + g];
-      t[0][sc] = bt_row<RA>(d[0], d[1], d[2], d[3], d[4], d[5]);
-      t[1][sc] = bt_row<RA + 1>(d[0], d[1], d[2], d[3], d[4], d[5]);
-    }
-    // ---- this wave's 9 entries of V and their position GEMMs (one MFMA each per n-tile) ------------------------------------------
-    float4 uq[4][NT];                                       // the (up to 4) position quads this wave touches
-    constexpr int QD0 = P0 / 4, NQD = (P0 + 8) / 4 - QD0 + 1;
+      for (int sc = 0; sc < 6; ++sc) {
+        float d[6];
 #pragma unroll
-    for (int qd = 0; qd < NQD; ++qd)
-#pragma unroll
-      for (int n = 0; n < NT; ++n) uq[qd][n] = ul[((QD0 + qd) * NT + n) * 64 + lane];
-#pragma unroll
-    for (int i = 0; i < 9; ++i) {
-      const int pos = P0 + i;                               // compile-time after unrolling
-      const int xi = pos / 6, nu = pos - xi * 6;
-      const float* tr = t[xi - RA];
-      float v;
-      switch (nu) {
-        case 0: v = bt_row<0>(tr[0], tr[1], tr[2], tr[3], tr[4], tr[5]); break;
-        case 1: v = bt_row<1>(tr[0], tr[1], tr[2], tr[3], tr[4], tr[5]); break;
-        case 2: v = bt_row<2>(tr[0], tr[1], tr[2], tr[3], tr[4], tr[5]); break;
-        case 3: v = bt_row<3>(tr[0], tr[1], tr[2], tr[3], tr[4], tr[5]); break;
-        case 4: v = bt_row<4>(tr[0], tr[1], tr[2], tr[3], tr[4], tr[5]); break;
-        default: v = bt_row<5>(tr[0], tr[1], tr[2], tr[3], tr[4], tr[5]); break;
+        for (int k = 0; k < 6; ++k) d[k] = rawf[woff[k][sc]];
+        t[0][sc] = bt_row<RA>(d[0], d[1], d[2], d[3], d[4], d[5]);
+        t[1][sc] = bt_row<RA + 1>(d[0], d[1], d[2], d[3], d[4], d[5]);
       }
-      const int qd = pos / 4 - QD0, cj = pos & 3;
+      // ---- this wave's 9 entries of V and their position GEMMs (one MFMA each per n-tile) ----------------------------------------
+      float4 uq[4][NT];                                     // the (up to 4) position quads this wave touches
+      constexpr int QD0 = P0 / 4, NQD = (P0 + 8) / 4 - QD0 + 1;
 #pragma unroll
-      for (int n = 0; n < NT; ++n) {
-        const float4 a4 = uq[qd][n];
-        const float a = cj == 0 ? a4.x : cj == 1 ? a4.y : cj == 2 ? a4.z : a4.w;
-        acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, v, acc[i][n], 0, 0, 0);
+      for (int qd = 0; qd < NQD; ++qd)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) uq[qd][n] = ul[((QD0 + qd) * NT + n) * 64 + lane];
+#pragma unroll
+      for (int i = 0; i < 9; ++i) {
+        const int pos = P0 + i;                             // compile-time after unrolling
+        const int xi = pos / 6, nu = pos - xi * 6;
+        const float* tr = t[xi - RA];
+        float v;
+        switch (nu) {
+          case 0: v = bt_row<0>(tr[0], tr[1], tr[2], tr[3], tr[4], tr[5]); break;
+          case 1: v = bt_row<1>(tr[0], tr[1], tr[2], tr[3], tr[4], tr[5]); break;
+          case 2: v = bt_row<2>(tr[0], tr[1], tr[2], tr[3], tr[4], tr[5]); break;
+          case 3: v = bt_row<3>(tr[0], tr[1], tr[2], tr[3], tr[4], tr[5]); break;
+          case 4: v = bt_row<4>(tr[0], tr[1], tr[2], tr[3], tr[4], tr[5]); break;
+          default: v = bt_row<5>(tr[0], tr[1], tr[2], tr[3], tr[4], tr[5]); break;
+        }
+        const int qd = pos / 4 - QD0, cj = pos & 3;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          const float4 a4 = uq[qd][n];
+          const float a = cj == 0 ? a4.x : cj == 1 ? a4.y : cj == 2 ? a4.z : a4.w;
+          acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, v, acc[i][n], 0, 0, 0);
+        }
       }
     }
   }
@@ -239,7 +282,7 @@ conv_wino4_kernel(const W4Params p) {
   else wino4_wave<NT, 3>(p, smem, grp, nt0, lane, wave);
 }
 
-struct W4Geo { int R, NI, nbands, S, TX, PR, PW, npos, tps; };
+struct W4Geo { int R, NI, nbands, S, TX, PR, PW, npos, rawF4, tps; };
 bool w4geo(const ConvDesc& d, const ConvCfg& cfg, W4Geo* g) {
   if (d.ks != 3 || d.stride != 1 || cfg.NT < 1 || cfg.NT > 3 || cfg.WM != 2 || cfg.WN != 4 || d.Cin % 16 || d.Cout % 16) return false;
   if (cfg.R < 4 || (cfg.R & 3) || cfg.NI < 1) return false;
@@ -253,7 +296,9 @@ bool w4geo(const ConvDesc& d, const ConvCfg& cfg, W4Geo* g) {
   if (g->NI * g->tps > 32) return false;                      // two groups of 16 tiles
   g->PR = g->R + 2; g->PW = 4 * g->TX + 2;
   g->npos = g->NI * g->PR * g->PW;
-  if (g->npos > W4_MAXP * 512) return false;
+  g->rawF4 = (g->npos + g->npos / 8 + 1 + 63) & ~63;          // skewed slots, whole 64-slot DMA pieces
+  if (g->rawF4 > W4_MAXP * 512) return false;
+  if (4 * ((size_t)g->rawF4 + 9 * cfg.NT * 64) * sizeof(float4) > 160 * 1024) return false;
   if ((long)d.B * d.H * d.W * std::max(std::max(d.in_cs, d.out_cs), d.res_cs) >= (1L << 31)) return false;
   return true;
 }
@@ -296,7 +341,7 @@ void conv_wino4_pack_weights(const float* w_oihw, const float* scale, int Cout, 
 size_t conv_wino4_lds_bytes(const ConvDesc& d, const ConvCfg& cfg) {
   W4Geo g;
   if (!w4geo(d, cfg, &g)) return 0;
-  const size_t stage = (size_t)((g.npos + 63) & ~63) + 9 * cfg.NT * 64, xch = 8 * 2 * 4 * 64;
+  const size_t stage = 4 * ((size_t)g.rawF4 + 9 * cfg.NT * 64), xch = 8 * 2 * 4 * 64;   // 2 buffers x 2 slices
   return std::max(stage, xch) * sizeof(float4);
 }
 
@@ -314,7 +359,7 @@ int conv_wino4_launch(const ConvDesc& d, const ConvCfg& cfg, hipStream_t stream)
   p.ufrag = reinterpret_cast<const float4*>(d.wfrag_wino4); p.bias = d.bias;
   p.B = d.B; p.H = d.H; p.W = d.W; p.nC4 = d.Cin / 4; p.nT16 = d.Cout / 16;
   p.in_rs = d.in_cs * d.W; p.in_ss = d.W * 16; p.res_rs = d.res_cs * d.W; p.out_rs = d.out_cs * d.W; p.out_ss = d.W * 16;
-  p.R = g.R; p.NI = g.NI; p.S = g.S; p.nbands = g.nbands; p.TX = g.TX; p.PR = g.PR; p.PW = g.PW; p.npos = g.npos;
+  p.R = g.R; p.NI = g.NI; p.S = g.S; p.nbands = g.nbands; p.TX = g.TX; p.PR = g.PR; p.PW = g.PW; p.npos = g.npos; p.rawF4 = g.rawF4;
   p.tiles_per_slab = g.tps;
   p.act = d.act; p.res_after_act = d.res_after_act;
   p.dPW = make_fastdiv(g.PW); p.dSlab = make_fastdiv(g.PR * g.PW); p.dBands = make_fastdiv(g.nbands);

@@ -247,6 +247,10 @@ def _wino4_cfg(H, W, nt):
     TX, Hc = (W + 3) // 4, (H + 3) // 4 * 4
     R = Hc if (Hc // 4) * TX <= 32 else max(4, 32 // TX * 4)
     NI = max(1, min(32 // ((R // 4) * TX), 1024 // ((R + 2) * (4 * TX + 2)))) if R == Hc else 1
+    npos = lambda ni: ni * (R + 2) * (4 * TX + 2)
+    lds = lambda ni: 4 * ((npos(ni) + npos(ni) // 8 + 1 + 63) // 64 * 64 + 9 * nt * 64) * 16     # 2 buffers x 2 slices, skewed slots
+    while NI > 1 and (lds(NI) > 160 * 1024 or (npos(NI) + npos(NI) // 8 + 1 + 63) // 64 * 64 > 1024):
+        NI -= 1
     return (1, nt, 2, 4, R, NI, 7)
 
 
