@@ -58,6 +58,9 @@ __host__ __device__ constexpr float at_c(int i, int k) {
   return A[i][k];
 }
 
+#ifndef W4_EXP
+#define W4_EXP 0      // timing probes (tools/build_exp.sh conv_wino4.hip W4_EXP n): 1 no window reads/transform, 2 no U reads,
+#endif                // 4 no DMA after the first pair, 8 no MFMAs; non-zero values compute garbage
 constexpr int W4_MAXP = 2;      // 64-position patch pieces per wave (npos <= 2 * 8 * 64)
 
 __device__ float4 g_zero_page_w4[1];   // 16 B of zeros: source of the padding lanes
@@ -161,7 +164,7 @@ __device__ __forceinline__ void wino4_wave(const W4Params& p, float4* smem, int 
   for (int m = 0; m < npairs; ++m) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's pieces of pair m have landed
     __syncthreads();                                        // ... everybody's; and everybody is done with pair m - 1
-    if (m + 1 < npairs) issue_pair(m + 1);
+    if (m + 1 < npairs && !(W4_EXP & 4)) issue_pair(m + 1);
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const float4* sbuf = smem + (size_t)((m & 1) * 2 + h) * sliceF4;
@@ -173,7 +176,7 @@ __device__ __forceinline__ void wino4_wave(const W4Params& p, float4* smem, int 
       for (int sc = 0; sc < 6; ++sc) {
         float d[6];
 #pragma unroll
-        for (int k = 0; k < 6; ++k) d[k] = rawf[woff[k][sc]];
+        for (int k = 0; k < 6; ++k) d[k] = (W4_EXP & 1) ? (float)(k + sc + h) : rawf[woff[k][sc]];
         t[0][sc] = bt_row<RA>(d[0], d[1], d[2], d[3], d[4], d[5]);
         t[1][sc] = bt_row<RA + 1>(d[0], d[1], d[2], d[3], d[4], d[5]);
       }
@@ -183,7 +186,7 @@ __device__ __forceinline__ void wino4_wave(const W4Params& p, float4* smem, int 
 #pragma unroll
       for (int qd = 0; qd < NQD; ++qd)
 #pragma unroll
-        for (int n = 0; n < NT; ++n) uq[qd][n] = ul[((QD0 + qd) * NT + n) * 64 + lane];
+        for (int n = 0; n < NT; ++n) uq[qd][n] = (W4_EXP & 2) ? make_float4(1.f + qd, 2.f + n, 3.f + h, 4.f) : ul[((QD0 + qd) * NT + n) * 64 + lane];
 #pragma unroll
       for (int i = 0; i < 9; ++i) {
         const int pos = P0 + i;                             // compile-time after unrolling
@@ -203,7 +206,8 @@ __device__ __forceinline__ void wino4_wave(const W4Params& p, float4* smem, int 
         for (int n = 0; n < NT; ++n) {
           const float4 a4 = uq[qd][n];
           const float a = cj == 0 ? a4.x : cj == 1 ? a4.y : cj == 2 ? a4.z : a4.w;
-          acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, v, acc[i][n], 0, 0, 0);
+          if (W4_EXP & 8) acc[i][n][0] += a * v;
+          else acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, v, acc[i][n], 0, 0, 0);
         }
       }
     }
