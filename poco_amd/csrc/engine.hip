@@ -37,7 +37,7 @@ struct ParamDecl {
 
 enum OpType {
   OP_STEM, OP_CONV, OP_MAXPOOL, OP_BILINEAR, OP_FUSE, OP_AVGPOOL, OP_ATTN, OP_LC2D, OP_ROT6D, OP_COPY,
-  OP_BCAST, OP_SMPL, OP_CAMERA, OP_NCHW_OUT, OP_CHAIN
+  OP_BCAST, OP_SMPL, OP_CAMERA, OP_NCHW_OUT, OP_CHAIN, OP_DUAL1X1
 };
 
 // external buffer slots (inputs / outputs of poco_forward)
@@ -182,6 +182,8 @@ struct Builder {
   bool kcat = [] { const char* v = getenv("POCO_NO_KCAT"); return !(v && atoi(v)); }();
   // POCO_NO_CHAIN=1 (experiments): conv3 of a layer1 block and conv1 of the next one as two launches
   bool chain = [] { const char* v = getenv("POCO_NO_CHAIN"); return !(v && atoi(v)); }();
+  // POCO_NO_DUAL=1 (experiments): stride-2 Bottlenecks keep conv3 and the projection shortcut as two launches
+  bool dual = [] { const char* v = getenv("POCO_NO_DUAL"); return !(v && atoi(v)); }();
   void begin_parallel(int kind = 0) { ++cur_phase; cur_lane = 0; in_parallel = true; region_seq = (seq_mask >> kind) & 1; }
   void end_parallel() { in_parallel = false; }
   void lane(int k) { cur_lane = region_seq ? 0 : k % 4; }
@@ -316,6 +318,37 @@ struct Builder {
     }
     int y = conv_bn(p + ".conv1", p + ".bn1", x, Cin, planes, 1, 1, 1);
     y = conv_bn(p + ".conv2", p + ".bn2", y, planes, planes, 3, stride, 1);
+    if (down && stride == 2 && dual && !in_parallel && (planes * 4) % 64 == 0) {
+      // bn3(conv3(t)) + bn_d(conv_d(x, stride 2)) as one GEMM over [t ; x(2y,2x)] (launch_gemm1x1_dual): no separate
+      // shortcut tensor, no residual read
+      const int Cout = planes * 4;
+      const HostParam* w3 = P(p + ".conv3.weight", {Cout, planes, 1, 1});
+      const HostParam* wd = P(p + ".downsample.0.weight", {Cout, Cin, 1, 1});
+      std::vector<float> s3, b3, sd, bd;
+      bn_fold(p + ".bn3", nullptr, Cout, s3, b3);
+      bn_fold(p + ".downsample.1", nullptr, Cout, sd, bd);
+      const Act at = e.acts[y];
+      Op op;
+      op.type = OP_DUAL1X1; op.name = p + ".conv3+downsample";
+      op.in = R(y); op.in2 = R(x); op.Cin = planes; op.C = Cin; op.Cout = Cout; op.stride = 2; op.actfn = 1;
+      const int o = new_act(Cout, at.H, at.W);
+      op.out = R(o);
+      op.flops = 2.0 * at.H * at.W * (double)Cout * (planes + Cin);
+      if (!declare && w3 && wd) {
+        const int K = planes + Cin;
+        std::vector<float> wm((size_t)Cout * K), bm(Cout), ones(Cout, 1.f);
+        for (int c = 0; c < Cout; ++c) {
+          for (int k = 0; k < planes; ++k) wm[(size_t)c * K + k] = (float)((double)s3[c] * w3->data[(size_t)c * planes + k]);
+          for (int k = 0; k < Cin; ++k) wm[(size_t)c * K + planes + k] = (float)((double)sd[c] * wd->data[(size_t)c * Cin + k]);
+          bm[c] = (float)((double)b3[c] + (double)bd[c]);
+        }
+        std::vector<float> packed(conv_packed_weight_floats(K, Cout, 1));
+        conv_pack_weights(wm.data(), ones.data(), Cout, K, 1, Cout, packed.data());
+        op.wdev = upload(packed); op.bdev = upload(bm);
+      }
+      push(std::move(op));
+      return o;
+    }
     int r = x;
     if (down) r = conv_bn(p + ".downsample.0", p + ".downsample.1", x, Cin, planes * 4, 1, stride, 0);
     return conv_bn(p + ".conv3", p + ".bn3", y, planes, planes * 4, 1, 1, 1, r);
@@ -1096,6 +1129,12 @@ int run_op(Engine& e, Op& op, int B, const IO& io, hipStream_t s) {
       const Act& a = e.acts[op.in.act];
       return launch_bneck_chain(aptr(e, op.in), a.C, aptr(e, op.res), e.acts[op.res.act].C, aptr(e, op.out), e.acts[op.out.act].C,
                                 aptr(e, op.out2), e.acts[op.out2.act].C, op.wdev, op.bdev, op.wdev2, op.bdev2, B, a.H, a.W, s);
+    }
+    case OP_DUAL1X1: {
+      const Act& a = e.acts[op.in.act];
+      const Act& x = e.acts[op.in2.act];
+      return launch_gemm1x1_dual(aptr(e, op.in), a.C, op.Cin, aptr(e, op.in2), x.C, op.C, x.H, x.W, op.stride, op.wdev, op.bdev,
+                                 aptr(e, op.out), e.acts[op.out.act].C, op.Cout, B, a.H, a.W, op.actfn, s);
     }
     case OP_COPY: {
       const float* src; int sstride;

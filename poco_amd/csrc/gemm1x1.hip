@@ -27,9 +27,12 @@ struct G1Params {
   int in_rs, in_ss, res_rs, out_rs, out_ss;
   int act, res_after_act, relu_from;
   FastDiv dWo, dHo;
+  // second source (DUAL instances): K slices >= nC16a come from in2, read at (stride2 * y, stride2 * x) of its H2 x W2 plane
+  const float* in2;
+  int nC16a, in2_rs, in2_ss, H2, stride2;
 };
 
-template <int MT, int NT, int D, bool HAS_RES>
+template <int MT, int NT, int D, bool HAS_RES, bool DUAL = false>
 __global__ void __launch_bounds__(512)
 gemm1x1_kernel(const G1Params p) {
   const int lane = threadIdx.x & 63;
@@ -41,6 +44,7 @@ gemm1x1_kernel(const G1Params p) {
   if (nt0 >= p.nT16 || mt0 * 16 >= p.P) return;         // wave-uniform; there are no barriers in this kernel
 
   int boff[MT];      // float offset of this lane's pixel (slice 0, channel quad g) in the input
+  int boff2[DUAL ? MT : 1];   // ... in the second source
   int orow[MT];      // output image row (b*Ho + y) or -1
   int ox16[MT];      // 16 * x
 #pragma unroll
@@ -56,6 +60,11 @@ gemm1x1_kernel(const G1Params p) {
       ix = x * 2;
     }
     boff[m] = (int)(irow * (uint32_t)p.in_rs + ix * 16u) + 4 * g;
+    if constexpr (DUAL) {
+      const uint32_t b2 = fdiv(row, p.dHo);
+      const uint32_t irow2 = b2 * (uint32_t)p.H2 + (row - b2 * (uint32_t)p.Ho) * (uint32_t)p.stride2;
+      boff2[m] = (int)(irow2 * (uint32_t)p.in2_rs + x * (uint32_t)p.stride2 * 16u) + 4 * g;
+    }
     orow[m] = pix < p.P ? (int)row : -1;
     ox16[m] = (int)x * 16;
   }
@@ -75,8 +84,15 @@ gemm1x1_kernel(const G1Params p) {
   auto load = [&](int s, int c) {                        // unconditional (c is clamped by the caller)
 #pragma unroll
     for (int n = 0; n < NT; ++n) a[s][n] = wl[(size_t)c * wslice + woff[n]];
+    if constexpr (DUAL) {
+      const bool first = c < p.nC16a;                      // wave-uniform
+      const float* src = first ? p.in + (size_t)c * p.in_ss : p.in2 + (size_t)(c - p.nC16a) * p.in2_ss;
 #pragma unroll
-    for (int m = 0; m < MT; ++m) b[s][m] = *reinterpret_cast<const float4*>(p.in + boff[m] + (size_t)c * p.in_ss);
+      for (int m = 0; m < MT; ++m) b[s][m] = *reinterpret_cast<const float4*>(src + (first ? boff[m] : boff2[m]));
+    } else {
+#pragma unroll
+      for (int m = 0; m < MT; ++m) b[s][m] = *reinterpret_cast<const float4*>(p.in + boff[m] + (size_t)c * p.in_ss);
+    }
   };
   auto mma = [&](int s) {
 #pragma unroll
@@ -209,4 +225,30 @@ int gemm1x1_launch(const ConvDesc& d, const ConvCfg& cfg, hipStream_t stream) {
 #undef G1_CASE
   poco_set_error("gemm1x1: unsupported tile");
   return POCO_ERR_ARG;
+}
+
+// out = act( [Wa | Wb] . [a ; b(stride2)] + bias ): the K-concatenated form of  bn3(conv3(a)) + bn_d(conv_d(b))  for the
+// stride-2 Bottlenecks of ResNet-50 (resnet.py:101-121, layer2-4 .0): a [B,Ho,Wo,Ca of a_cs] is conv2's output, b
+// [B,H2,W2,Cb of b_cs] the block input, sampled at (2y, 2x).  wfrag: conv_pack_weights(ks = 1) over Ca + Cb input channels.
+int launch_gemm1x1_dual(const float* a, int a_cs, int Ca, const float* b, int b_cs, int Cb, int H2, int W2, int stride2,
+                        const float* wfrag, const float* bias, float* out, int out_cs, int Cout, int B, int Ho, int Wo, int act,
+                        hipStream_t stream) {
+  if ((Ca | Cb | Cout) % 16 || Cout % 64 || (stride2 != 1 && stride2 != 2) || (long)B * Ho * Wo >= (1L << 27)) {
+    poco_set_error("gemm1x1_dual: Ca, Cb multiples of 16, Cout a multiple of 64, stride 1|2");
+    return POCO_ERR_ARG;
+  }
+  G1Params p{};
+  p.in = a; p.in2 = b; p.res = nullptr; p.out = out;
+  p.wfrag = reinterpret_cast<const float4*>(wfrag); p.bias = bias;
+  p.H = Ho; p.W = Wo; p.Ho = Ho; p.Wo = Wo; p.stride = 1;
+  p.P = B * Ho * Wo; p.nC16 = (Ca + Cb) / 16; p.nC16a = Ca / 16; p.nT16 = Cout / 16; p.WM = 1; p.WN = 1;
+  p.in_rs = a_cs * Wo; p.in_ss = Wo * 16; p.in2_rs = b_cs * W2; p.in2_ss = W2 * 16; p.H2 = H2; p.stride2 = stride2;
+  p.out_rs = out_cs * Wo; p.out_ss = Wo * 16; p.res_rs = p.out_rs;
+  p.act = act; p.res_after_act = 0; p.relu_from = 0;
+  p.dWo = make_fastdiv(Wo); p.dHo = make_fastdiv(Ho);
+  const int mtiles = (p.P + 15) / 16;
+  const dim3 grid((mtiles + 6) / 7, p.nT16 / 4);
+  hipLaunchKernelGGL((gemm1x1_kernel<7, 4, 2, false, true>), grid, dim3(64), 0, stream, p);
+  POCO_HIP_CHECK(hipGetLastError());
+  return POCO_OK;
 }

@@ -16,6 +16,10 @@ void launch_stem_conv(const float* img_nchw, const float* w, const float* shift,
 int launch_bneck_chain(const float* t, int t_cs, const float* res, int res_cs, float* y, int y_cs, float* u, int u_cs,
                        const float* w3, const float* b3, const float* w1, const float* b1, int B, int H, int W,
                        hipStream_t s);
+// K-concatenated projection shortcut with a strided second source (gemm1x1.hip)
+int launch_gemm1x1_dual(const float* a, int a_cs, int Ca, const float* b, int b_cs, int Cb, int H2, int W2, int stride2,
+                        const float* wfrag, const float* bias, float* out, int out_cs, int Cout, int B, int Ho, int Wo, int act,
+                        hipStream_t stream);
 void launch_maxpool3x3s2(const float* in, float* out, int B, int H, int W, int C, int out_cs, hipStream_t s);
 // x2 bilinear upsample, align_corners=True, NHWC (hrnet.py:440).
 void launch_bilinear_up2x(const float* in, float* out, int B, int H, int W, int C, hipStream_t s);

@@ -100,6 +100,23 @@ def test_kconcat_shortcut_matches_separate_convs(variant, cuda, monkeypatch):
         assert (a[k] - b[k]).abs().max().item() < 2e-5, k
 
 
+def test_strided_kconcat_shortcut_matches_separate_convs(cuda, monkeypatch):
+    """ResNet-50 layer2-4 .0: bn3(conv3(t)) + bn_d(conv_d(x, stride 2)) as one GEMM with two B-operand sources
+    (gemm1x1.hip, launch_gemm1x1_dual) against the two-launch form of resnet.py:101-121."""
+    variant = "resnet50-cliff"
+    batch = util.cuda_batch(synth.synth_batch(5, 41), cuda)
+    merged = util.make_engine(variant, max_batch=5)
+    monkeypatch.setenv("POCO_NO_DUAL", "1")
+    separate = util.make_engine(variant, max_batch=5)
+    monkeypatch.delenv("POCO_NO_DUAL")
+    names = lambda m: [n for n, _, _ in m.ops()]
+    assert sum(n.endswith(".0.conv3+downsample") for n in names(merged)) == 4          # layer1.0 (K-concat buffer) + layer2-4.0
+    assert len(names(separate)) == len(names(merged)) + 3
+    a, b = merged(batch), separate(batch)
+    for k in ("pred_pose", "pred_shape", "pred_cam", "var_pose", "smpl_vertices"):
+        assert (a[k] - b[k]).abs().max().item() < 2e-5, k
+
+
 @pytest.mark.parametrize("variant", ["hrnet_w32-pare", "resnet50-cliff"])
 def test_chained_bottleneck_matches_separate_convs(variant, cuda, monkeypatch):
     """layer1: conv3 + residual + ReLU of block k and conv1 + ReLU of block k+1 as one kernel (csrc/bneck_chain.hip: the
