@@ -164,9 +164,13 @@ __device__ __forceinline__ void wino4_wave(const W4Params& p, float4* smem, int 
   for (int m = 0; m < npairs; ++m) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's pieces of pair m have landed
     __syncthreads();                                        // ... everybody's; and everybody is done with pair m - 1
-    if (m + 1 < npairs && !(W4_EXP & 4)) issue_pair(m + 1);
+    // the two waves of a SIMD (same quarter of the two tile groups) issue their DMA share at different points of the pair,
+    // so that one of them keeps the MFMA pipe busy while the other sits in the DMA issue
+    const bool more = m + 1 < npairs && !(W4_EXP & 4);
+    if (more && (grp == 0 || (W4_EXP & 16))) issue_pair(m + 1);
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
+      if (h == 1 && more && grp == 1 && !(W4_EXP & 16)) issue_pair(m + 1);
       const float4* sbuf = smem + (size_t)((m & 1) * 2 + h) * sliceF4;
       const float* rawf = reinterpret_cast<const float*>(sbuf);
       const float4* ul = sbuf + rawF4;
