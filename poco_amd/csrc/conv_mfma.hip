@@ -168,7 +168,7 @@ int conv_launch(const ConvDesc& d, const ConvCfg& cfg, hipStream_t stream) {
       poco_set_error("conv: channel counts/strides must be multiples of 16/4");
       return POCO_ERR_ARG;
     }
-    if (d.act == 3) { poco_set_error("conv: the Winograd kernels have no per-channel ReLU split"); return POCO_ERR_ARG; }
+    if (d.act == 3 || d.act == 2) { poco_set_error("conv: the Winograd kernels support no activation or ReLU only"); return POCO_ERR_ARG; }
     return conv_wino_launch(d, cfg, stream);
   }
   if (!(d.ks == 1 || d.ks == 3) || !(d.stride == 1 || d.stride == 2)) {

@@ -104,6 +104,7 @@ __device__ __forceinline__ void wino_store_impl(const WinoParams& p, f32x4 (&v)[
     orow[k] = ok[k] ? ob * p.H + yy : 0;
     ocol[k] = ok[k] ? xx * 16 : 0;
   }
+  const float lo = p.act == 1 ? 0.f : -INFINITY;      // act is none | ReLU here (conv_wino_launch rejects the others)
   float4 sh[NT];
 #pragma unroll
   for (int n = 0; n < NT; ++n) sh[n] = *reinterpret_cast<const float4*>(p.bias + min(nt0 + n, p.nT16 - 1) * 16 + g * 4);
@@ -126,12 +127,7 @@ __device__ __forceinline__ void wino_store_impl(const WinoParams& p, f32x4 (&v)[
       float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
       if constexpr (HAS_RES) r = rr[n][k];
       if (!p.res_after_act) { v4[0] += r.x; v4[1] += r.y; v4[2] += r.z; v4[3] += r.w; }
-      if (p.act == 1) {
-        v4[0] = fmaxf(v4[0], 0.f); v4[1] = fmaxf(v4[1], 0.f); v4[2] = fmaxf(v4[2], 0.f); v4[3] = fmaxf(v4[3], 0.f);
-      } else if (p.act == 2) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v4[e] = 1.f / (1.f + __expf(-v4[e]));
-      }
+      v4[0] = fmaxf(v4[0], lo); v4[1] = fmaxf(v4[1], lo); v4[2] = fmaxf(v4[2], lo); v4[3] = fmaxf(v4[3], lo);   // ReLU as a clamp
       if (p.res_after_act) { v4[0] += r.x; v4[1] += r.y; v4[2] += r.z; v4[3] += r.w; }
       if (nok && ok[k])
         *reinterpret_cast<float4*>(p.out + (size_t)orow[k] * p.out_rs + ocol[k] + (nt0 + n) * p.out_ss + g * 4) = make_float4(v4[0], v4[1], v4[2], v4[3]);

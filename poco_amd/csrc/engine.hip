@@ -1390,7 +1390,7 @@ extern "C" int poco_set_conv_cfg(poco_handle_t h, int op_index, int B, const int
   const ConvCfg c = conv_cfg_from(cfg7);
   const size_t lds = conv_lds_bytes(d, c);
   if (B < 1 || lds == 0 || lds > 160 * 1024 || ((c.ALG == 3 || c.ALG == 4) && (op.wdev_wino == nullptr && e->finalized)) ||
-      ((c.ALG == 3 || c.ALG == 4) && op.actfn == 3) || c.ALG == 7 /* stand-alone operator only */) {
+      ((c.ALG == 3 || c.ALG == 4) && (op.actfn == 3 || op.actfn == 2)) || c.ALG == 7 /* stand-alone operator only */) {
     poco_set_error("poco_set_conv_cfg: configuration does not fit op '" + op.name + "' at this batch size");
     return POCO_ERR_ARG;
   }
