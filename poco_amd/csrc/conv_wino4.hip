@@ -393,8 +393,12 @@ int conv_wino4_launch(const ConvDesc& d, const ConvCfg& cfg, hipStream_t stream)
   const dim3 grid((g.S + g.NI - 1) / g.NI, (p.nT16 + cfg.NT - 1) / cfg.NT);
   auto fn = cfg.NT == 3 ? conv_wino4_kernel<3> : cfg.NT == 2 ? conv_wino4_kernel<2> : conv_wino4_kernel<1>;
   if (lds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) { poco_set_error(std::string("hipFuncSetAttribute: ") + hipGetErrorString(e)); return POCO_ERR_HIP; }
+    static thread_local bool configured[4] = {false, false, false, false};
+    if (!configured[cfg.NT]) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (e != hipSuccess) { poco_set_error(std::string("hipFuncSetAttribute: ") + hipGetErrorString(e)); return POCO_ERR_HIP; }
+      configured[cfg.NT] = true;
+    }
   }
   hipLaunchKernelGGL(fn, grid, dim3(512), lds, stream, p);
   POCO_HIP_CHECK(hipGetLastError());
