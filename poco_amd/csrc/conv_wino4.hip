@@ -24,7 +24,10 @@
 //     (global_load_lds_dwordx4: 64 patch positions x 16 B, or one 1 KiB fragment, per wave instruction) into the other
 //     half of a double buffer while pair m computes; every wave issues 1/8 of the pieces and waits for its own
 //     (s_waitcnt vmcnt(0)) before the barrier that publishes the pair.
-// State: correct, first pipelined version; not yet persistent, no XCD-aware walk, epilogue not overlapped.
+//   * blocks are persistent over (slab group, n-tile group) items; the first pair of the next item streams in during the
+//     Z exchange / epilogue of the current one (no measurable gain yet: the epilogue's 16 stores per lane dominate the
+//     fixed cost).
+// State: correct and pipelined; no XCD-aware walk, epilogue not overlapped with the next item's compute.
 #include "conv_mfma_types.h"
 
 namespace {
@@ -38,6 +41,7 @@ struct W4Params {
   int B, H, W, nC4, nT16;
   int in_rs, in_ss, res_rs, out_rs, out_ss;
   int R, NI, S, nbands, TX, PR, PW, npos, rawF4, tiles_per_slab;
+  int nblocks_m, nb_n;   // work items walked by the persistent blocks: slab groups x n-tile groups
   int act, res_after_act;
   FastDiv dPW, dSlab, dBands, dTX, dTslab;
 };
@@ -75,7 +79,7 @@ __device__ __forceinline__ void w4_dma16(const void* gsrc, unsigned lds_dst) {
 }
 
 template <int NT, int Q>
-__device__ __forceinline__ void wino4_wave(const W4Params& p, float4* smem, int grp, int nt0, int lane, int wave) {
+__device__ __forceinline__ void wino4_wave(const W4Params& p, float4* smem, int grp, int lane, int wave) {
   constexpr int P0 = 9 * Q;                 // first position of this wave
   constexpr int RA = P0 / 6;                // its two position rows: RA (from column P0 % 6 on) and RA + 1
   const int idx = lane & 15, g = lane >> 4;
@@ -84,10 +88,70 @@ __device__ __forceinline__ void wino4_wave(const W4Params& p, float4* smem, int 
   // apart, so without the skew the 16 tile lanes of a window read hit 2 of the 8 four-bank groups (8-way conflict)
   const int rawF4 = p.rawF4;
   const int sliceF4 = rawF4 + 9 * NT * 64;
+  const int bufF4 = max(2 * sliceF4, 8 * 2 * 4 * 64);      // a stage buffer also hosts the 64 KiB exchange area
   const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) float4*)smem;
 
+  // Persistent: the block walks work items w = blockIdx.x, + gridDim.x, ... (item = slab group x n-tile group); the
+  // slice pairs of consecutive items form ONE pipeline (running pair counter `it` selects the LDS buffer), so the first
+  // pair of item k+1 streams in during the exchange / epilogue of item k.
+  const int nitems = p.nblocks_m * p.nb_n;
+  int it = 0;
+  auto decode_goff = [&](int item, int* go) {
+    const int s0g = (item % p.nblocks_m) * p.NI;
+#pragma unroll
+    for (int k = 0; k < W4_MAXP; ++k) {
+      go[k] = -1;
+      const uint32_t slot = (uint32_t)((wave + 8 * k) * 64 + lane);    // piece wave + 8k, lane = slot inside the piece
+      const uint32_t k9 = __umulhi(slot, 477218589u);                  // slot / 9 (exact for slot < 2^16)
+      const uint32_t r9 = slot - 9 * k9;
+      const uint32_t pos = 8 * k9 + r9;
+      if (r9 < 8 && pos < (uint32_t)p.npos) {
+        const uint32_t psl = fdiv(pos, p.dSlab);
+        const uint32_t prem = pos - psl * (uint32_t)(p.PR * p.PW);
+        const uint32_t prow = fdiv(prem, p.dPW);
+        const int pcol = (int)(prem - prow * (uint32_t)p.PW);
+        const uint32_t ps = (uint32_t)s0g + psl;
+        const uint32_t pb = fdiv(ps, p.dBands);
+        const int pband = (int)(ps - pb * (uint32_t)p.nbands);
+        const int iy = pband * p.R - 1 + (int)prow, ix = pcol - 1;
+        if (ps < (uint32_t)p.S && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
+          go[k] = (int)((pb * (uint32_t)p.H + (uint32_t)iy) * (uint32_t)p.in_rs) + ix * 16;
+      }
+    }
+  };
+  const int npieces_raw = rawF4 >> 6;
+  auto issue_pair = [&](int m, int buf, const int* go, int nt0i) {      // slices 2m, 2m+1 of an item -> buffer buf
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int c4 = 2 * m + h;
+      const unsigned sb = lds_base + (unsigned)(buf * bufF4 + h * sliceF4) * 16u;
+      const size_t coff = (size_t)(c4 >> 2) * p.in_ss + (c4 & 3) * 4;
+#pragma unroll
+      for (int k = 0; k < W4_MAXP; ++k) {
+        const int piece = wave + 8 * k;
+        if (piece < npieces_raw) {
+          const void* src = go[k] >= 0 ? (const void*)(p.in + go[k] + coff) : (const void*)g_zero_page_w4;
+          w4_dma16(src, (unsigned)__builtin_amdgcn_readfirstlane((int)(sb + (unsigned)piece * 1024u)));
+        }
+      }
+      for (int i = wave; i < 9 * NT; i += 8) {
+        const int quad = i / NT, n = i - quad * NT;
+        const float4* src = p.ufrag + (((size_t)c4 * 9 + quad) * p.nT16 + min(nt0i + n, p.nT16 - 1)) * 64 + lane;
+        w4_dma16(src, (unsigned)__builtin_amdgcn_readfirstlane((int)(sb + (unsigned)(rawF4 + i * 64) * 16u)));
+      }
+    }
+  };
+  int goff[W4_MAXP], goffN[W4_MAXP];
+  if ((int)blockIdx.x >= nitems) return;
+  decode_goff(blockIdx.x, goff);
+  issue_pair(0, 0, goff, ((int)blockIdx.x / p.nblocks_m) * NT);
+  for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+  const int nt0 = (item / p.nblocks_m) * NT;
+  const int inext = item + gridDim.x;
+  const bool has_next = inext < nitems;
+  if (has_next) decode_goff(inext, goffN);
   // ---- this lane's tile -------------------------------------------------------------------------------------------
-  const int s0 = blockIdx.x * p.NI;
+  const int s0 = (item % p.nblocks_m) * p.NI;
   const uint32_t tidx = (uint32_t)(grp * 16 + idx);
   const uint32_t sl = fdiv(tidx, p.dTslab);
   const uint32_t rem = tidx - sl * (uint32_t)p.tiles_per_slab;
@@ -99,29 +163,6 @@ __device__ __forceinline__ void wino4_wave(const W4Params& p, float4* smem, int 
   const int oy0 = band * p.R + 4 * (int)tyl;
   const bool tvalid = sl < (uint32_t)p.NI && s < (uint32_t)p.S && oy0 < p.H;
   const int base = tvalid ? (int)((sl * (uint32_t)p.PR + 4 * tyl) * (uint32_t)p.PW) + 4 * tx : 0;   // window top-left in the patch
-
-  // ---- patch positions this thread stages (decoded once) ----------------------------------------------------------
-  int goff[W4_MAXP];
-#pragma unroll
-  for (int k = 0; k < W4_MAXP; ++k) {
-    goff[k] = -1;
-    const uint32_t slot = (uint32_t)((wave + 8 * k) * 64 + lane);    // piece wave + 8k, lane = slot inside the piece
-    const uint32_t k9 = __umulhi(slot, 477218589u);                  // slot / 9 (exact for slot < 2^16)
-    const uint32_t r9 = slot - 9 * k9;
-    const uint32_t pos = 8 * k9 + r9;
-    if (r9 < 8 && pos < (uint32_t)p.npos) {
-      const uint32_t psl = fdiv(pos, p.dSlab);
-      const uint32_t prem = pos - psl * (uint32_t)(p.PR * p.PW);
-      const uint32_t prow = fdiv(prem, p.dPW);
-      const int pcol = (int)(prem - prow * (uint32_t)p.PW);
-      const uint32_t ps = (uint32_t)s0 + psl;
-      const uint32_t pb = fdiv(ps, p.dBands);
-      const int pband = (int)(ps - pb * (uint32_t)p.nbands);
-      const int iy = pband * p.R - 1 + (int)prow, ix = pcol - 1;
-      if (ps < (uint32_t)p.S && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
-        goff[k] = (int)((pb * (uint32_t)p.H + (uint32_t)iy) * (uint32_t)p.in_rs) + ix * 16;
-    }
-  }
 
   int woff[6][6];                                            // float offsets of this lane's 36 window elements in a slice
 #pragma unroll
@@ -137,41 +178,24 @@ __device__ __forceinline__ void wino4_wave(const W4Params& p, float4* smem, int 
 #pragma unroll
     for (int n = 0; n < NT; ++n) acc[i][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  const int npieces_raw = rawF4 >> 6;
-  auto issue_pair = [&](int m) {                            // slices 2m, 2m+1 -> buffer m & 1
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int c4 = 2 * m + h;
-      const unsigned sb = lds_base + (unsigned)(((m & 1) * 2 + h) * sliceF4) * 16u;
-      const size_t coff = (size_t)(c4 >> 2) * p.in_ss + (c4 & 3) * 4;
-#pragma unroll
-      for (int k = 0; k < W4_MAXP; ++k) {
-        const int piece = wave + 8 * k;
-        if (piece < npieces_raw) {
-          const void* src = goff[k] >= 0 ? (const void*)(p.in + goff[k] + coff) : (const void*)g_zero_page_w4;
-          w4_dma16(src, (unsigned)__builtin_amdgcn_readfirstlane((int)(sb + (unsigned)piece * 1024u)));
-        }
-      }
-      for (int i = wave; i < 9 * NT; i += 8) {
-        const int quad = i / NT, n = i - quad * NT;
-        const float4* src = p.ufrag + (((size_t)c4 * 9 + quad) * p.nT16 + min(nt0 + n, p.nT16 - 1)) * 64 + lane;
-        w4_dma16(src, (unsigned)__builtin_amdgcn_readfirstlane((int)(sb + (unsigned)(rawF4 + i * 64) * 16u)));
-      }
-    }
-  };
   const int npairs = p.nC4 >> 1;
-  issue_pair(0);
-  for (int m = 0; m < npairs; ++m) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's pieces of pair m have landed
-    __syncthreads();                                        // ... everybody's; and everybody is done with pair m - 1
+  for (int m = 0; m < npairs; ++m, ++it) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's pieces of this pair have landed (and its stores retired)
+    __syncthreads();                                        // ... everybody's; and everybody is done with the previous pair
     // the two waves of a SIMD (same quarter of the two tile groups) issue their DMA share at different points of the pair,
     // so that one of them keeps the MFMA pipe busy while the other sits in the DMA issue
-    const bool more = m + 1 < npairs && !(W4_EXP & 4);
-    if (more && (grp == 0 || (W4_EXP & 16))) issue_pair(m + 1);
+    // what streams in next: the following pair of this item, or the first pair of the block's next item
+    const bool last = m + 1 == npairs;
+    const bool more = (!last || has_next) && !(W4_EXP & 4);
+    auto issue_next = [&]() {
+      if (!last) issue_pair(m + 1, (it + 1) & 1, goff, nt0);
+      else issue_pair(0, (it + 1) & 1, goffN, (inext / p.nblocks_m) * NT);
+    };
+    if (more && (grp == 0 || (W4_EXP & 16))) issue_next();
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      if (h == 1 && more && grp == 1 && !(W4_EXP & 16)) issue_pair(m + 1);
-      const float4* sbuf = smem + (size_t)((m & 1) * 2 + h) * sliceF4;
+      if (h == 1 && more && grp == 1 && !(W4_EXP & 16)) issue_next();
+      const float4* sbuf = smem + (size_t)(it & 1) * bufF4 + (size_t)h * sliceF4;
       const float* rawf = reinterpret_cast<const float*>(sbuf);
       const float4* ul = sbuf + rawF4;
       // ---- two rows of B^T d from the window, column by column -------------------------------------------------------------
@@ -218,14 +242,13 @@ __device__ __forceinline__ void wino4_wave(const W4Params& p, float4* smem, int 
   }
 
   // ---- Z = M A (partial over this wave's columns), exchanged one n-tile at a time; wave Q finishes n-tile Q ------------------
-  // exchange area [2][8 waves][2 rows][4 cols][64] float4, double-buffered over the n-tile rounds: one barrier per round (a
-  // buffer is rewritten two rounds later, i.e. after the barrier its finishing wave has to pass first)
+  // exchange area [8 waves][2 rows][4 cols][64] float4 (64 KiB) inside the stage buffer of the item's LAST pair (dead
+  // now); the other stage buffer is receiving the next item's first pair
   const int oyb = oy0, oxb = 4 * tx;
-  if (W4_EXP & 32) { if (acc[0][0][0] == 12345.f) p.out[0] = acc[8][NT - 1][1]; return; }
-  __syncthreads();                                           // K loop finished everywhere: the staging buffers are dead
+  float4* xch = smem + (size_t)((it - 1) & 1) * bufF4;
 #pragma unroll
   for (int n = 0; n < NT; ++n) {
-    float4* xch = smem + (n & 1) * (8 * 2 * 4 * 64);
+    __syncthreads();                                         // K loop / previous round finished everywhere
 #pragma unroll
     for (int r = 0; r < 2; ++r)
 #pragma unroll
@@ -291,6 +314,11 @@ __device__ __forceinline__ void wino4_wave(const W4Params& p, float4* smem, int 
       }
     }
   }
+  if (has_next) {
+#pragma unroll
+    for (int k = 0; k < W4_MAXP; ++k) goff[k] = goffN[k];
+  }
+  }   // item loop
 }
 
 template <int NT>
@@ -300,11 +328,10 @@ conv_wino4_kernel(const W4Params p) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int grp = wave >> 2, q = wave & 3;
-  const int nt0 = blockIdx.y * NT;
-  if (q == 0) wino4_wave<NT, 0>(p, smem, grp, nt0, lane, wave);
-  else if (q == 1) wino4_wave<NT, 1>(p, smem, grp, nt0, lane, wave);
-  else if (q == 2) wino4_wave<NT, 2>(p, smem, grp, nt0, lane, wave);
-  else wino4_wave<NT, 3>(p, smem, grp, nt0, lane, wave);
+  if (q == 0) wino4_wave<NT, 0>(p, smem, grp, lane, wave);
+  else if (q == 1) wino4_wave<NT, 1>(p, smem, grp, lane, wave);
+  else if (q == 2) wino4_wave<NT, 2>(p, smem, grp, lane, wave);
+  else wino4_wave<NT, 3>(p, smem, grp, lane, wave);
 }
 
 struct W4Geo { int R, NI, nbands, S, TX, PR, PW, npos, rawF4, tps; };
@@ -323,7 +350,7 @@ bool w4geo(const ConvDesc& d, const ConvCfg& cfg, W4Geo* g) {
   g->npos = g->NI * g->PR * g->PW;
   g->rawF4 = (g->npos + g->npos / 8 + 1 + 63) & ~63;          // skewed slots, whole 64-slot DMA pieces
   if (g->rawF4 > W4_MAXP * 512) return false;
-  if (4 * ((size_t)g->rawF4 + 9 * cfg.NT * 64) * sizeof(float4) > 160 * 1024) return false;
+  if (2 * std::max<size_t>(2 * ((size_t)g->rawF4 + 9 * cfg.NT * 64), 8 * 2 * 4 * 64) * sizeof(float4) > 160 * 1024) return false;
   if ((long)d.B * d.H * d.W * std::max(std::max(d.in_cs, d.out_cs), d.res_cs) >= (1L << 31)) return false;
   return true;
 }
@@ -366,8 +393,9 @@ void conv_wino4_pack_weights(const float* w_oihw, const float* scale, int Cout, 
 size_t conv_wino4_lds_bytes(const ConvDesc& d, const ConvCfg& cfg) {
   W4Geo g;
   if (!w4geo(d, cfg, &g)) return 0;
-  const size_t stage = 4 * ((size_t)g.rawF4 + 9 * cfg.NT * 64), xch = 2 * 8 * 2 * 4 * 64;   // 2 buffers x 2 slices | 2 exchange buffers
-  return std::max(stage, xch) * sizeof(float4);
+  // 2 stage buffers of 2 slices each; a buffer also hosts the 64 KiB exchange area after its item's last pair
+  const size_t buf = std::max<size_t>(2 * ((size_t)g.rawF4 + 9 * cfg.NT * 64), 8 * 2 * 4 * 64);
+  return 2 * buf * sizeof(float4);
 }
 
 int conv_wino4_launch(const ConvDesc& d, const ConvCfg& cfg, hipStream_t stream) {
@@ -390,7 +418,11 @@ int conv_wino4_launch(const ConvDesc& d, const ConvCfg& cfg, hipStream_t stream)
   p.dPW = make_fastdiv(g.PW); p.dSlab = make_fastdiv(g.PR * g.PW); p.dBands = make_fastdiv(g.nbands);
   p.dTX = make_fastdiv(g.TX); p.dTslab = make_fastdiv(g.tps);
   const size_t lds = conv_wino4_lds_bytes(d, cfg);
-  const dim3 grid((g.S + g.NI - 1) / g.NI, (p.nT16 + cfg.NT - 1) / cfg.NT);
+  p.nblocks_m = (g.S + g.NI - 1) / g.NI; p.nb_n = (p.nT16 + cfg.NT - 1) / cfg.NT;
+  // balanced persistent grid: every block walks the same number of items (one block per CU: the stage buffers take ~152 KiB)
+  const long items = (long)p.nblocks_m * p.nb_n;
+  const long rounds = (items + 255) / 256;
+  const dim3 grid((unsigned)((items + rounds - 1) / rounds), 1);
   auto fn = cfg.NT == 3 ? conv_wino4_kernel<3> : cfg.NT == 2 ? conv_wino4_kernel<2> : conv_wino4_kernel<1>;
   if (lds > 64 * 1024) {
     static thread_local bool configured[4] = {false, false, false, false};

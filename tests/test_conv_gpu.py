@@ -239,6 +239,7 @@ WINO4 = [
     (1, 13, 9, 16, 32, True),       # ragged plane
     (1, 1, 1, 16, 16, False),       # one pixel
     (7, 12, 8, 160, 80, True),      # K = 10 slices; tiles not a multiple of the 16 / 32 per block
+    (40, 56, 56, 16, 48, True),     # 280 work items at NT = 3 (840 at NT = 1) > 256 blocks: persistent blocks walk several items
 ]
 
 
