@@ -262,7 +262,7 @@ __device__ __forceinline__ void wino4_wave(const W4Params& p, float4* smem, int 
         xch[((wave * 2 + r) * 4 + j) * 64 + lane] = make_float4(z[0], z[1], z[2], z[3]);
       }
     __syncthreads();
-    if (Q == n && nt0 + n < p.nT16) {
+    if (nt0 + n < p.nT16) {                                  // every wave finishes output row Q of the 4x4 blocks of n-tile n
       // rows of Z: 0 = q0.r0 | 1 = q0.r1 + q1.r0 | 2 = q1.r1 | 3 = q2.r0 | 4 = q2.r1 + q3.r0 | 5 = q3.r1
       const int w0 = grp * 4;
       auto ld = [&](int q, int r, int j) {
@@ -273,15 +273,18 @@ __device__ __forceinline__ void wino4_wave(const W4Params& p, float4* smem, int 
       const float lo = p.act == 1 ? 0.f : -INFINITY;          // ReLU as a clamp: no branch in the store loop
       const bool has_res = p.res != nullptr;
       // per-row output offsets (clamped: dead pixels load/compute harmlessly and are masked at the store only)
-      size_t ooff[4], roff[4];
-      bool oky[4];
+      constexpr int i = Q;
+      const int oy = oyb + i;
+      const bool oky = tvalid && oy < p.H;
+      const size_t orow = (size_t)b * p.H + min(oy, p.H - 1);
+      const size_t ooff = orow * p.out_rs + (size_t)(nt0 + n) * p.out_ss + g * 4;
+      const size_t roff = orow * p.res_rs + (size_t)(nt0 + n) * p.out_ss + g * 4;
+      float4 rr[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int oy = oyb + i;
-        oky[i] = tvalid && oy < p.H;
-        const size_t orow = (size_t)b * p.H + min(oy, p.H - 1);
-        ooff[i] = orow * p.out_rs + (size_t)(nt0 + n) * p.out_ss + g * 4;
-        roff[i] = orow * p.res_rs + (size_t)(nt0 + n) * p.out_ss + g * 4;
+      for (int j = 0; j < 4; ++j) rr[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (has_res) {                                          // wave-uniform; the four loads of the row are issued together
+#pragma unroll
+        for (int j = 0; j < 4; ++j) rr[j] = *reinterpret_cast<const float4*>(p.res + roff + min(oxb + j, p.W - 1) * 16);
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -289,28 +292,17 @@ __device__ __forceinline__ void wino4_wave(const W4Params& p, float4* smem, int 
         zr[0] = ld(0, 0, j); zr[1] = ld(0, 1, j) + ld(1, 0, j); zr[2] = ld(1, 1, j);
         zr[3] = ld(2, 0, j); zr[4] = ld(2, 1, j) + ld(3, 0, j); zr[5] = ld(3, 1, j);
         const int ox = oxb + j;
-        const bool okx = ox < p.W;
         const int xo = min(ox, p.W - 1) * 16;
-        float4 rr[4];
+        f32x4 v = (f32x4){sh.x, sh.y, sh.z, sh.w};
 #pragma unroll
-        for (int i = 0; i < 4; ++i) rr[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (has_res) {                                          // wave-uniform; the four loads of a column are issued together
-#pragma unroll
-          for (int i = 0; i < 4; ++i) rr[i] = *reinterpret_cast<const float4*>(p.res + roff[i] + xo);
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          f32x4 v = (f32x4){sh.x, sh.y, sh.z, sh.w};
-#pragma unroll
-          for (int k = 0; k < 6; ++k)
-            if (at_c(i, k) != 0.f) v += at_c(i, k) * zr[k];
-          const float4 r = rr[i];
-          if (!p.res_after_act) { v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w; }
-          v[0] = fmaxf(v[0], lo); v[1] = fmaxf(v[1], lo); v[2] = fmaxf(v[2], lo); v[3] = fmaxf(v[3], lo);
-          if (p.res_after_act) { v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w; }
-          if ((W4_EXP & 128) && (v[0] != 12345.f || i + j > 0)) continue;       // probe: compute everything, store (almost) nothing
-          if (oky[i] && okx) *reinterpret_cast<float4*>(p.out + ooff[i] + xo) = make_float4(v[0], v[1], v[2], v[3]);
-        }
+        for (int k = 0; k < 6; ++k)
+          if (at_c(i, k) != 0.f) v += at_c(i, k) * zr[k];
+        const float4 r = rr[j];
+        if (!p.res_after_act) { v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w; }
+        v[0] = fmaxf(v[0], lo); v[1] = fmaxf(v[1], lo); v[2] = fmaxf(v[2], lo); v[3] = fmaxf(v[3], lo);
+        if (p.res_after_act) { v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w; }
+        if ((W4_EXP & 128) && (v[0] != 12345.f || j > 0)) continue;       // probe: compute everything, store (almost) nothing
+        if (oky && ox < p.W) *reinterpret_cast<float4*>(p.out + ooff + xo) = make_float4(v[0], v[1], v[2], v[3]);
       }
     }
   }
