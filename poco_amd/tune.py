@@ -108,6 +108,23 @@ def candidates(B, H, W, Cin, Cout, ks, stride, lds_cap=150 * 1024) -> List[Tuple
                     lds = (8 * plane + 2 * 16 * NT * 64) * 16
                     if lds <= 160 * 1024 and (plane // 64 + WM - 1) // WM <= 6 and (nT % NT == 0 or nT < NT):
                         out.add((1, NT, WM, 2, R, ni, 4))
+    if ks == 3 and stride == 1 and H >= 28 and W >= 28:      # Winograd F(4x4,3x3) (ALG 7): 2 tile groups x 4 position quarters
+        TX4, Hc = (W + 3) // 4, (H + 3) // 4 * 4
+        for NT in (1, 2, 3):
+            if nT % NT and nT > NT:
+                continue
+            for R in range(4, Hc + 1, 4):
+                tps = (R // 4) * TX4
+                if tps > 32:
+                    break
+                nis = {1} if R < Hc else {1, max(1, 32 // tps)}
+                for ni in nis:
+                    if ni * tps < 20:
+                        continue
+                    npos = ni * (R + 2) * (4 * TX4 + 2)
+                    raw = (npos + npos // 8 + 1 + 63) // 64 * 64
+                    if raw <= 1024 and 2 * max(2 * (raw + 9 * NT * 64), 4096) * 16 <= 160 * 1024:
+                        out.add((1, NT, 2, 4, R, ni, 7))
     return sorted(out)
 
 
