@@ -40,7 +40,7 @@ struct ConvCfg {
                // 2: ALG 1 persistent over tiles; 3: Winograd F(2x2,3x3) (MT ignored, NT in {1,2}, R even);
                // 4: Winograd, half-position waves + pipelined transform (WN = 2 halves, WM <= 4, NT <= 3)
                // 5: small-M linear (H = W = 1, ks = 1): K split over WM waves per 16 outputs (linear_mfma.hip)
-               // 7: Winograd F(4x4,3x3), experimental, stand-alone operator only (conv_wino4.hip): NT 1..3, WM = 2 tile
+               // 7: Winograd F(4x4,3x3) for planes >= 28x28 (conv_wino4.hip): NT 1..3, WM = 2 tile
                //    groups, WN = 4 position quarters, R = output rows per slab (multiple of 4), NI slabs (<= 32 tiles)
                // 6: 1x1 conv (stride 1|2) as a register-direct GEMM, no LDS / barriers (gemm1x1.hip):
                //    (MT,NT) in {(2,4),(4,2),(4,4),(7,2),(7,4),(8,2)}, R = operand prefetch depth (2|3), NI = 1
@@ -62,7 +62,7 @@ struct ConvDesc {
   float*       out; int out_cs, out_co;
   const float* wfrag;                     // weights in MFMA fragment order (see conv_pack_weights)
   const float* wfrag_wino;                // 3x3 stride-1 only: Winograd-transformed weights (ALG 3), nullable
-  const float* wfrag_wino4 = nullptr;     // 3x3 stride-1 only: F(4x4,3x3) weights, 36 positions (ALG 7, experimental), nullable
+  const float* wfrag_wino4 = nullptr;     // 3x3 stride-1 only: F(4x4,3x3) weight fragments, 36 positions (ALG 7), nullable
   const float* bias;                      // [Cout_padded] folded BN shift / conv bias
   int B, H, W, Cin, Cout;                 // Cout = padded to a multiple of 16
   int ks, stride;                         // ks in {1,3}; pad = (ks-1)/2; stride in {1,2}
@@ -93,7 +93,7 @@ bool gemm1x1_cfg_valid(const ConvDesc& d, const ConvCfg& cfg);
 int gemm1x1_launch(const ConvDesc& d, const ConvCfg& cfg, hipStream_t stream);
 
 #include <vector>
-// ---- Winograd F(4x4,3x3), experimental (conv_wino4.hip), ALG 7 -------------------------------------------
+// ---- Winograd F(4x4,3x3) (conv_wino4.hip), ALG 7 -------------------------------------------
 size_t conv_wino4_packed_floats(int Cin, int Cout16);
 void conv_wino4_pack_weights(const float* w_oihw, const float* scale, int Cout, int Cin, int Cout16, float* dst);
 size_t conv_wino4_lds_bytes(const ConvDesc& d, const ConvCfg& cfg);

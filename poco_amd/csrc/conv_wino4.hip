@@ -1,4 +1,4 @@
-// ALG 7 (experimental, stand-alone operator only): Winograd F(4x4,3x3) on the fp32 MFMA.
+// ALG 7: Winograd F(4x4,3x3) on the fp32 MFMA (3x3 stride-1 convs on planes >= 28x28; hrnet.py:42-58).
 //
 // 36 position GEMMs M_xi[co][tile] += U_xi[co][ci] V_xi[ci][tile] per 4x4 output tile = 2.25 MFMA-MACs per output
 // pixel and input channel instead of 4 for F(2x2,3x3) (ALG 3/4) and 9 for the direct conv: the lever beyond the MFMA

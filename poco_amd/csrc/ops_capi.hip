@@ -54,7 +54,7 @@ static int conv_common(const float* d_in, int B, int H, int W, int Cin, const fl
     conv_pack_weights(wt.data(), h_scale, Cout, Cin, 4, Cout16, pu.data());
     POCO_HIP_CHECK(dwu.upload(pu));
     d.wfrag_wino = dwu.p;
-    if (cfg7 && cfg7[6] == 7) {                   // experimental F(4x4,3x3): 36-position fragments
+    if (cfg7 && cfg7[6] == 7) {                   // F(4x4,3x3): 36-position fragments
       std::vector<float> pu4(conv_wino4_packed_floats(Cin, Cout16));
       conv_wino4_pack_weights(h_w, h_scale, Cout, Cin, Cout16, pu4.data());
       POCO_HIP_CHECK(dwu4.upload(pu4));

@@ -257,8 +257,8 @@ def _wino4_cfg(H, W, nt):
 
 @pytest.mark.parametrize("nt", [1, 2, 3])
 @pytest.mark.parametrize("case", WINO4, ids=lambda c: "x".join(map(str, c)))
-def test_conv_winograd_f4x4_experimental(case, nt, cuda):
-    """ALG 7 (experimental, not in the tuning table): Winograd F(4x4,3x3) for the 3x3 stride-1 convs of hrnet.py:42-58.
+def test_conv_winograd_f4x4(case, nt, cuda):
+    """ALG 7: Winograd F(4x4,3x3) for the 3x3 stride-1 convs of hrnet.py:42-58.
     Tolerance 2e-4 * max|ref|: the F(4x4) transforms (constants up to 8) amplify fp32 rounding ~10x over F(2x2)."""
     from poco_amd import ops
     B, H, W, Cin, Cout, has_res = case
