@@ -142,13 +142,23 @@ __device__ __forceinline__ void wino4_wave(const W4Params& p, float4* smem, int 
     }
   };
   int goff[W4_MAXP], goffN[W4_MAXP];
-  if ((int)blockIdx.x >= nitems) return;
-  decode_goff(blockIdx.x, goff);
-  issue_pair(0, 0, goff, ((int)blockIdx.x / p.nblocks_m) * NT);
-  for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+  // XCD-aware walk: workgroup b runs on XCD b % 8 (round-robin dispatch), so XCD x owns the contiguous item range
+  // [x*per, (x+1)*per) and its gridDim/8 blocks stride through it: neighbouring row bands (shared halo rows) meet in
+  // one L2 instead of eight (W4_EXP & 512: plain walk)
+  int first = blockIdx.x, istep = gridDim.x, iend = nitems;
+  if (!(W4_EXP & 512) && (gridDim.x & 7) == 0 && nitems >= (int)gridDim.x) {
+    const int per = (nitems + 7) >> 3;
+    first = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    istep = gridDim.x >> 3;
+    iend = min(nitems, ((int)(blockIdx.x & 7) + 1) * per);
+  }
+  if (first >= iend) return;
+  decode_goff(first, goff);
+  issue_pair(0, 0, goff, (first / p.nblocks_m) * NT);
+  for (int item = first; item < iend; item += istep) {
   const int nt0 = (item / p.nblocks_m) * NT;
-  const int inext = item + gridDim.x;
-  const bool has_next = inext < nitems;
+  const int inext = item + istep;
+  const bool has_next = inext < iend;
   if (has_next) decode_goff(inext, goffN);
   // ---- this lane's tile -------------------------------------------------------------------------------------------
   const int s0 = (item % p.nblocks_m) * p.NI;
@@ -414,7 +424,9 @@ int conv_wino4_launch(const ConvDesc& d, const ConvCfg& cfg, hipStream_t stream)
   // balanced persistent grid: every block walks the same number of items (one block per CU: the stage buffers take ~152 KiB)
   const long items = (long)p.nblocks_m * p.nb_n;
   const long rounds = (items + 255) / 256;
-  const dim3 grid((unsigned)((items + rounds - 1) / rounds), 1);
+  long g4 = (items + rounds - 1) / rounds;
+  if (g4 > 8) g4 = std::min(256L, (g4 + 7) / 8 * 8);           // multiple of 8 for the XCD-aware walk
+  const dim3 grid((unsigned)g4, 1);
   auto fn = cfg.NT == 3 ? conv_wino4_kernel<3> : cfg.NT == 2 ? conv_wino4_kernel<2> : conv_wino4_kernel<1>;
   if (lds > 64 * 1024) {
     static thread_local bool configured[4] = {false, false, false, false};
