@@ -1,3 +1,7 @@
+"""Wider in-context tuning pass than `python -m poco_amd.tune --in-context`:
+    tools/tune_context_wide.py <variant> <batch> <top_shapes> <top_cands> <iters> <out.json>
+Re-picks the configuration of the <top_shapes> most expensive conv shapes inside the whole 4-lane forward, trying the
+<top_cands> best solo candidates each, and writes the merged table to <out.json> (and to poco_amd/tuned/gfx950.json)."""
 import json, sys
 sys.path.insert(0, '/root/repo')
 from pathlib import Path
