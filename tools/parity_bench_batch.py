@@ -3,7 +3,9 @@ sys.path.insert(0, '/root/repo')
 import numpy as np, torch
 from poco_amd import synth
 from tests import util
-for variant, B in (("hrnet_w48_cls-cliff", 64), ("hrnet_w32-pare", 32)):
+import os
+CASES = [(v, int(b)) for v, b in (c.split(":") for c in os.environ.get("CASES", "hrnet_w48_cls-cliff:64,hrnet_w32-pare:32").split(","))]
+for variant, B in CASES:
     m = util.make_engine(variant, max_batch=B)
     bnp = synth.synth_batch(B, 1234)
     out = m(util.cuda_batch(bnp, torch.device("cuda:0")))
