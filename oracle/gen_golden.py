@@ -7,6 +7,9 @@ pin oracle/poco_ref.py against them.
 What is recorded (data only - inputs are re-derived from seeds by poco_amd/synth.py):
   tests/golden/spec_<variant>.json     state_dict key -> shape of the reference modules
   tests/golden/model_<variant>.npz     reference outputs for B=2 (pose/shape/cam/var/features ...)
+  tests/golden/model_<variant>_stress.npz   the same with the "stress" weight profile (every BN gamma in [0.5,1.5])
+  poco_amd/calib/stress_<variant>.json ONLY with the argument `calibrate`: the per-BN input statistics the
+                                       stress profile needs (data; poco_amd/synth.py reads it on every machine)
   tests/golden/smooth.npz              One Euro filtered rotation tracks (one_euro_filter.py via smooth_pose.py)
   tests/golden/ops.npz                 per-op vectors (KeypointAttention, LocallyConnected2d,
                                        rot6d_to_rotmat, camera conversions, RealNVP, uncert post-proc)
@@ -61,25 +64,81 @@ def sample_idx(n, k, seed):
     return np.sort(np.random.default_rng(seed).choice(n, size=min(k, n), replace=False))
 
 
-def run_variant(variant, kw):
-    parts = build_reference(variant, kw)
+def ref_spec(parts):
     spec = []
     for pname, m in parts.items():
         for k, v in m.state_dict().items():
             spec.append((f"{pname}.{k}", tuple(v.shape)))
-    (GOLD / f"spec_{variant}.json").write_text(json.dumps([[n, list(s)] for n, s in spec]))
-    w = synth.synth_state_dict(spec, SEED_W)
+    return spec
+
+
+def load_into(parts, w):
     for pname, m in parts.items():
         sd = {k[len(pname) + 1:]: torch.from_numpy(v) for k, v in w.items() if k.startswith(pname + ".")}
         m.load_state_dict(sd, strict=True)
-    batch_np = synth.synth_batch(BATCH, SEED_IN)
+
+
+def ref_forward(parts, variant, batch):
+    hname = variant.split("-")[1]
+    feats = parts["backbone"](batch["img"])
+    return feats, (parts["head"](feats, batch) if hname == "cliff" else parts["head"](feats))
+
+
+CALIB_BATCH, CALIB_SEED = 4, 4242
+
+
+def calibrate(variant, kw):
+    """"stress" weight profile (poco_amd/synth.py): measure, layer by layer in execution order, the mean and
+    variance of every BatchNorm2d's input on a seeded batch through the REFERENCE modules, with all earlier BNs
+    already carrying their calibrated running statistics.  Writes poco_amd/calib/stress_<variant>.json."""
+    parts = build_reference(variant, kw)
+    spec = ref_spec(parts)
+    load_into(parts, synth.synth_state_dict(spec, SEED_W, "stress", {}))
+    calib = {}
+
+    def make_hook(full):
+        def hook(mod, inp):
+            x = inp[0]
+            m, v = float(np.float32(x.mean())), float(np.float32(x.var()))
+            calib[full] = [m, v]
+            mini = [(f"{full}.{leaf}", tuple(mod.running_mean.shape)) for leaf in ("running_mean", "running_var")]
+            t = synth.synth_state_dict(mini, SEED_W, "stress", {full: (m, v)})
+            mod.running_mean.copy_(torch.from_numpy(t[f"{full}.running_mean"]))
+            mod.running_var.copy_(torch.from_numpy(t[f"{full}.running_var"]))
+        return hook
+
+    for pname, m in parts.items():
+        for name, mod in m.named_modules():
+            if isinstance(mod, (torch.nn.BatchNorm2d, torch.nn.BatchNorm1d)):
+                mod.register_forward_pre_hook(make_hook(f"{pname}.{name}"))
+    with torch.no_grad():
+        feats, ho = ref_forward(parts, variant, poco_ref.to_torch(synth.synth_batch(CALIB_BATCH, CALIB_SEED, profile="stress")))
+    nbn = sum(1 for n, _ in spec if n.endswith(".running_mean"))
+    assert len(calib) == nbn, (len(calib), nbn)
+    synth.CALIB_DIR.mkdir(exist_ok=True)
+    (synth.CALIB_DIR / f"stress_{variant}.json").write_text(json.dumps(calib, indent=0, sort_keys=True))
+    vs = np.array([v for _, v in calib.values()])
+    print(variant, f"calibrated {nbn} BNs; input variance range [{vs.min():.3g}, {vs.max():.3g}];",
+          "feat rms", float(feats.pow(2).mean().sqrt()))
+
+
+def run_variant(variant, kw, profile="default"):
+    parts = build_reference(variant, kw)
+    spec = ref_spec(parts)
+    tag = "" if profile == "default" else f"_{profile}"
+    if profile == "default":
+        (GOLD / f"spec_{variant}.json").write_text(json.dumps([[n, list(s)] for n, s in spec]))
+        w = synth.synth_state_dict(spec, SEED_W)
+    else:
+        w = synth.synth_state_dict(spec, SEED_W, profile, synth.load_calib(variant))
+    load_into(parts, w)
+    batch_np = synth.synth_batch(BATCH, SEED_IN, profile=profile)
     batch = poco_ref.to_torch(batch_np)
     smpl_np_model = synth.synth_smpl(7)
     smpl_t = poco_ref.to_torch(smpl_np_model)
     hname = variant.split("-")[1]
     with torch.no_grad():
-        feats = parts["backbone"](batch["img"])
-        ho = parts["head"](feats, batch) if hname == "cliff" else parts["head"](feats)
+        feats, ho = ref_forward(parts, variant, batch)
         verts64, j49_64 = smpl_np.smpl_lbs_np(smpl_np_model, ho["pred_shape"].numpy(), ho["pred_pose"].numpy())
         so = {"smpl_vertices": torch.from_numpy(verts64).float()}
         uo = parts["uncert_head"](ho, so, batch)
@@ -96,7 +155,7 @@ def run_variant(variant, kw):
     pins["smpl_vertices(fp32 torch vs f64 numpy)"] = float(np.abs(mine["smpl_vertices"].numpy() - verts64).max())
     if hname == "pare":
         pins["pred_segm_mask"] = float((ho["pred_segm_mask"] - mine["pred_segm_mask"]).abs().max())
-    print(variant, "oracle-vs-reference max abs:", json.dumps(pins))
+    print(variant, profile, "oracle-vs-reference max abs:", json.dumps(pins))
     assert max(pins.values()) < 2e-4, pins
     # --- fixtures -----------------------------------------------------------------------------
     f_flat = feats.reshape(BATCH, -1).numpy()
@@ -122,7 +181,10 @@ def run_variant(variant, kw):
         m = ho["pred_segm_mask"].reshape(BATCH, -1).numpy()
         out["segm_idx"] = sample_idx(m.shape[1], 256, 14)
         out["segm_samples"] = m[:, out["segm_idx"]]
-    np.savez_compressed(GOLD / f"model_{variant}.npz", **out)
+    np.savez_compressed(GOLD / f"model_{variant}{tag}.npz", **out)
+    spread = {k: float(np.abs(out[k][0] - out[k][1]).max()) for k in ("pred_pose", "pred_shape", "pred_cam", "var_pose")}
+    spread["vertices"] = float(np.abs(verts64[0] - verts64[1]).max())
+    print(variant, profile, "inter-crop spread (max |crop0 - crop1|):", json.dumps(spread))
     print(variant, "feat |mean|", out["feat_abs_mean"], "var_pose range", float(uo["var_pose"].min()),
           float(uo["var_pose"].max()), "cam", ho["pred_cam"].numpy().round(3).tolist())
 
@@ -257,8 +319,12 @@ def main():
     if not only or "smooth" in only:
         run_smooth()
     for v, kw in VARIANTS.items():
-        if not only or v in only:
+        if "calibrate" in only:
+            calibrate(v, kw)
+        if not only or v in only or "models" in only:
             run_variant(v, kw)
+        if not only or v in only or "stress" in only or "calibrate" in only:
+            run_variant(v, kw, "stress")
 
 
 if __name__ == "__main__":

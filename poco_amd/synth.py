@@ -8,13 +8,30 @@ independent of iteration order.
 
 Scale rules keep ~300 stacked conv/BN/ReLU layers O(1) (the reference's own init, std=0.001 at
 pocolib/models/backbone/hrnet.py:535, collapses activations to 0 and would make parity vacuous).
+
+Two weight profiles:
+  "default"  every BN gamma in [0.8,1.2] but the last BN of a residual branch / fuse path damped
+             (gamma ~0.1) so that un-normalised stacks stay O(1).  Used by bench.py and the tuner
+             (timing does not depend on the values).
+  "stress"   SURVEY.md 8(c): EVERY BN gamma in [0.5,1.5], beta in [-0.2,0.2]; the residual branches
+             carry as much signal as the trunk.  Activations stay O(1..10) the way they do in a
+             trained network: each BN's running statistics track its input.  The per-layer scalars
+             (mean, variance of the conv output feeding each BN) were measured once, layer by layer,
+             on a seeded calibration batch through the reference's own modules
+             (oracle/gen_golden.py calibrate) and are committed as data in poco_amd/calib/.
+             running_mean_c = m + sqrt(v)*U(-0.2,0.2), running_var_c = v*U(0.5,1.5).
+             Decoder / MLP gains are raised too, so pose/shape/confidence move O(0.1..1) between crops.
 """
 from __future__ import annotations
 
 import zlib
-from typing import Dict, Iterable, Sequence, Tuple
+import json
+from pathlib import Path
+from typing import Dict, Iterable, Optional, Sequence, Tuple
 
 import numpy as np
+
+CALIB_DIR = Path(__file__).resolve().parent / "calib"
 
 Spec = Sequence[Tuple[str, Tuple[int, ...]]]
 
@@ -30,7 +47,30 @@ def alter_masks(num_rv: int, num_flow_layers: int) -> np.ndarray:
     return np.array([a, b] * num_flow_layers, dtype=np.float32)
 
 
-def synth_state_dict(spec: Spec, seed: int = 0) -> Dict[str, np.ndarray]:
+def load_calib(variant: str) -> Dict[str, Tuple[float, float]]:
+    """BN name -> (mean, variance) of its input on the calibration batch ("stress" profile)."""
+    f = CALIB_DIR / f"stress_{variant}.json"
+    if not f.exists():
+        raise FileNotFoundError(f"{f}: run oracle/gen_golden.py calibrate (needs the reference)")
+    return {k: (float(m), float(v)) for k, (m, v) in json.loads(f.read_text()).items()}
+
+
+STRESS_LINEAR_GAIN = {"decpose": 0.25, "decshape": 0.25, "deccam": 0.08, "fc1": 1.0, "fc2": 1.0,
+                      "cam_mlp": 0.1, "shape_mlp": 1.0, "uncert_fc_featNet": 2.0, "uncert_fc_poseNet": 2.0,
+                      "uncert_fc1": 3.0, "uncert_fc2": 3.0}
+DEFAULT_LINEAR_GAIN = {"decpose": 0.05, "decshape": 0.05, "deccam": 0.05, "fc1": 0.5, "fc2": 0.5,
+                       "cam_mlp": 0.1, "shape_mlp": 0.5}
+
+
+def synth_state_dict(spec: Spec, seed: int = 0, profile: str = "default",
+                     calib: Optional[Dict[str, Tuple[float, float]]] = None) -> Dict[str, np.ndarray]:
+    """profile "stress": `calib` maps BN module names to the (mean, var) of their input; a BN without
+    an entry gets (0, 1) - that is how the calibration pass itself starts."""
+    if profile not in ("default", "stress"):
+        raise ValueError(profile)
+    stress = profile == "stress"
+    calib = calib or {}
+    gains = STRESS_LINEAR_GAIN if stress else DEFAULT_LINEAR_GAIN
     names = {n for n, _ in spec}
     out: Dict[str, np.ndarray] = {}
     for name, shape in spec:
@@ -41,7 +81,10 @@ def synth_state_dict(spec: Spec, seed: int = 0) -> Dict[str, np.ndarray]:
         if leaf == "num_batches_tracked":
             out[name] = np.zeros(shape, dtype=np.int64)
         elif is_bn:
-            if leaf == "weight":
+            m0, v0 = calib.get(stem, (0.0, 1.0)) if stress else (0.0, 1.0)
+            if leaf == "weight" and stress:
+                v = r.uniform(0.5, 1.5, shape)
+            elif leaf == "weight":
                 lo, hi = 0.8, 1.2
                 last = stem.rsplit(".", 1)[-1]
                 parent = stem.rsplit(".", 1)[0]
@@ -54,9 +97,9 @@ def synth_state_dict(spec: Spec, seed: int = 0) -> Dict[str, np.ndarray]:
             elif leaf == "bias":
                 v = r.uniform(-0.2, 0.2, shape)
             elif leaf == "running_mean":
-                v = r.uniform(-0.2, 0.2, shape)
+                v = m0 + np.sqrt(v0) * r.uniform(-0.2, 0.2, shape)
             elif leaf == "running_var":
-                v = r.uniform(0.5, 1.5, shape)
+                v = v0 * r.uniform(0.5, 1.5, shape)
             else:
                 raise ValueError(name)
             out[name] = v.astype(np.float32)
@@ -77,16 +120,7 @@ def synth_state_dict(spec: Spec, seed: int = 0) -> Dict[str, np.ndarray]:
         elif leaf == "weight" and len(shape) == 6:          # LocallyConnected2d [1,O,C,J,1,1]
             out[name] = (r.standard_normal(shape) / np.sqrt(shape[2])).astype(np.float32)
         elif leaf == "weight" and len(shape) == 2:          # Linear [out,in]
-            gain = 1.0
-            mod = stem.rsplit(".", 1)[-1]
-            if mod in ("decpose", "decshape", "deccam"):
-                gain = 0.05
-            elif mod in ("fc1", "fc2"):
-                gain = 0.5
-            elif mod == "cam_mlp":
-                gain = 0.1
-            elif mod == "shape_mlp":
-                gain = 0.5
+            gain = gains.get(stem.rsplit(".", 1)[-1], 1.0)
             out[name] = (gain * r.standard_normal(shape) / np.sqrt(shape[1])).astype(np.float32)
         elif leaf == "bias":
             v = r.uniform(-0.05, 0.05, shape)
@@ -162,9 +196,21 @@ def bbox_info_from(center: np.ndarray, scale: np.ndarray, orig_shape: np.ndarray
     return info.astype(np.float32)
 
 
-def synth_batch(B: int, seed: int = 1234, img_w: int = 1920, img_h: int = 1080) -> Dict[str, np.ndarray]:
+def synth_batch(B: int, seed: int = 1234, img_w: int = 1920, img_h: int = 1080,
+                profile: str = "default") -> Dict[str, np.ndarray]:
+    """profile "default": white-noise crops.  profile "stress": every crop additionally carries
+    its own low-frequency pattern (a random 7x7x3 grid, x32 nearest), contrast and colour offset, so that globally
+    pooled features - and with them cam / confidence - differ between crops by far more than the parity gate."""
     r = np.random.default_rng(seed)
     img = r.standard_normal((B, 3, 224, 224), dtype=np.float32)
+    if profile == "stress":
+        rs = np.random.default_rng([seed, 1])
+        grid = rs.standard_normal((B, 3, 7, 7)).astype(np.float32)
+        contrast = rs.uniform(0.4, 2.0, (B, 1, 1, 1)).astype(np.float32)
+        offset = rs.uniform(-0.7, 0.7, (B, 3, 1, 1)).astype(np.float32)
+        img = contrast * (0.6 * img + 0.8 * grid.repeat(32, axis=2).repeat(32, axis=3)) + offset
+    elif profile != "default":
+        raise ValueError(profile)
     center = np.array([img_w / 2.0, img_h / 2.0]) + r.uniform(-0.25, 0.25, (B, 2)) * np.array([img_w, img_h])
     side = r.uniform(150.0, 600.0, B)
     scale = side / 200.0

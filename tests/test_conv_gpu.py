@@ -3,6 +3,8 @@
 Call sites replaced: pocolib/models/backbone/hrnet.py:42-58,79-99 (conv->bn->relu, += residual).
 Tolerance: 2e-5 * max|ref| (fp32 MFMA is an exact fmaf chain; only the summation order differs).
 """
+import zlib
+
 import numpy as np
 import pytest
 import torch
@@ -273,3 +275,80 @@ def test_conv_winograd_f4x4(case, nt, cuda):
     out = ops.conv2d_nhwc(torch.from_numpy(x).to(cuda), w, scale, shift, 1,
                           None if res is None else torch.from_numpy(res).to(cuda), True, cfg=cfg).cpu().numpy()
     assert np.abs(out - ref).max() <= 2e-4 * max(1.0, np.abs(ref).max())
+
+
+# ------------------------------------------------------------------------------------------------------------
+# Table-driven: every (shape, cfg) pair the engine actually runs at the bench batch sizes
+# ------------------------------------------------------------------------------------------------------------
+def _tuned_entries(batches=(32, 64, 128)):
+    import re
+    from poco_amd import tune
+    out = []
+    for key, cfg in sorted(tune.load_table().items()):
+        B, H, W, Cin, Cout, ks, stride = map(int, re.fullmatch(r"(\d+)x(\d+)x(\d+)x(\d+)x(\d+)k(\d+)s(\d+)", key).groups())
+        if B in batches and cfg and cfg[0] > 0:
+            out.append((key, (B, H, W, Cin, Cout, ks, stride), tuple(cfg)))
+    return out
+
+
+def _conv_fp64_gpu(x, w, shift, stride, res, relu):
+    """fp64 conv on the GPU from fp64 matmuls only (no vendor conv library): x NHWC fp32 cuda, w OIHW numpy."""
+    B, H, W, Cin = x.shape
+    Cout, _, ks, _ = w.shape
+    pad = (ks - 1) // 2
+    Ho, Wo = (H + 2 * pad - ks) // stride + 1, (W + 2 * pad - ks) // stride + 1
+    xp = F.pad(x.double(), (0, 0, pad, pad, pad, pad))
+    wd = torch.from_numpy(w).to(x.device).double()
+    y = torch.zeros(B * Ho * Wo, Cout, device=x.device, dtype=torch.float64)
+    for r in range(ks):
+        for s in range(ks):
+            v = xp[:, r:r + (Ho - 1) * stride + 1:stride, s:s + (Wo - 1) * stride + 1:stride, :]
+            y.addmm_(v.reshape(-1, Cin), wd[:, :, r, s].t())
+    y = y.view(B, Ho, Wo, Cout) + torch.from_numpy(shift).to(x.device).double()
+    if res is not None:
+        y = y + res.double()
+    return y.clamp_min(0) if relu else y
+
+
+ALG_TOL = {3: 1e-4, 4: 1e-4, 7: 2e-4}     # Winograd F(2x2): transforms amplify fp32 rounding ~5x, F(4x4) ~10x
+
+
+@pytest.mark.parametrize("batch", [32, 64, 128])
+def test_tuned_table_entries(batch, cuda):
+    """EVERY distinct (shape, cfg) of poco_amd/tuned/gfx950.json at the bench batch sizes goes
+    through poco_op_conv2d at that batch size against an fp64 conv (all crops, all pixels), so a wrong tile in a tuned
+    Winograd / persistent / LDS-DMA entry cannot hide behind an insensitive whole-model output.  Entries the library
+    refuses for the shape (the engine then keeps its heuristic, tune.apply_table) are counted, not failed."""
+    from poco_amd import ops
+    from poco_amd._lib import PocoHipError
+    entries = _tuned_entries((batch,))
+    assert entries, "no tuned entries for this batch size"
+    gen = torch.Generator(device=cuda)
+    worst, refused, by_alg = {}, [], {}
+    for key, (B, H, W, Cin, Cout, ks, stride), cfg in entries:
+        gen.manual_seed(zlib.crc32(key.encode()) % (2 ** 31))
+        x = torch.randn((B, H, W, Cin), device=cuda, generator=gen)
+        rng = np.random.default_rng(zlib.crc32(key.encode()))
+        w = (rng.standard_normal((Cout, Cin, ks, ks)) / np.sqrt(Cin * ks * ks)).astype(np.float32)
+        shift = rng.uniform(-0.5, 0.5, Cout).astype(np.float32)
+        pad = (ks - 1) // 2
+        Ho, Wo = (H + 2 * pad - ks) // stride + 1, (W + 2 * pad - ks) // stride + 1
+        res = torch.randn((B, Ho, Wo, Cout), device=cuda, generator=gen)
+        try:
+            out = ops.conv2d_nhwc(x, w, None, shift, stride, res, True, cfg=cfg)
+        except (PocoHipError, RuntimeError) as e:
+            refused.append((key, cfg, str(e)[:80]))
+            continue
+        ref = _conv_fp64_gpu(x, w, shift, stride, res, True)
+        err = float((out.double() - ref).abs().max())
+        tol = ALG_TOL.get(cfg[6], 2e-5) * max(1.0, float(ref.abs().max()))
+        by_alg[cfg[6]] = max(by_alg.get(cfg[6], 0.0), err / max(1.0, float(ref.abs().max())))
+        if err > tol:
+            worst[key] = (cfg, err, tol)
+        del x, res, out, ref
+    print(f"B={batch}: {len(entries)} tuned entries, {len(refused)} refused by the library; worst relative deviation per ALG:",
+          {a: "%.1e" % v for a, v in sorted(by_alg.items())})
+    for r in refused:
+        print("  refused:", r)
+    assert not worst, worst
+    assert len(refused) <= len(entries) // 10, refused

@@ -18,11 +18,14 @@ def _np(t):
     return t.detach().cpu().numpy()
 
 
+@pytest.mark.parametrize("profile", ["default", "stress"])
 @pytest.mark.parametrize("variant", VARIANTS)
-def test_golden_b2(variant, cuda):
-    g = dict(np.load(util.GOLD / f"model_{variant}.npz"))
-    m = util.make_engine(variant, max_batch=4)
-    out = m(util.cuda_batch(synth.synth_batch(2, 1234), cuda))
+def test_golden_b2(variant, profile, cuda):
+    """Fixtures made by the reference's own modules.  profile "stress" = every BN gamma in [0.5,1.5] + structured
+    crops (poco_amd/synth.py): the two crops of the fixture differ by >= 44x the gate on every compared output."""
+    g = dict(np.load(util.GOLD / (f"model_{variant}.npz" if profile == "default" else f"model_{variant}_stress.npz")))
+    m = util.make_engine(variant, max_batch=4, profile=profile)
+    out = m(util.cuda_batch(synth.synth_batch(2, 1234, profile=profile), cuda))
     torch.cuda.synchronize()
     errs = {k: float(np.abs(_np(out[k]) - g[k]).max()) for k in ("pred_pose", "pred_shape", "pred_cam", "var_pose")}
     p6 = out["pred_pose6d"] if "pred_pose6d" in out else out["pred_pose_6d"]
@@ -41,7 +44,14 @@ def test_golden_b2(variant, cuda):
     else:
         seg = _np(out["pred_segm_mask"]).reshape(2, -1)[:, g["segm_idx"]]
         errs["segm"] = float(np.abs(seg - g["segm_samples"]).max())
-    print(variant, errs)
+    print(variant, profile, errs)
+    if profile == "stress":       # features are O(1..10) here: gate them relative to their size
+        for k, idx, samp in (("uncert_feat", "uncert_feat_idx", "uncert_feat_samples"),):
+            errs[k] /= max(1.0, float(np.abs(g[samp]).max()))
+        if "body_feat2" in errs:
+            errs["body_feat2"] /= max(1.0, float(np.abs(g["body_feat2_samples"]).max()))
+        if "segm" in errs:
+            errs["segm"] /= max(1.0, float(np.abs(g["segm_samples"]).max()))
     assert max(errs.values()) < TOL, errs
     assert out["log_phi"] is None and out["gt_pose_cond_idx"] == []
 
@@ -135,25 +145,50 @@ def test_chained_bottleneck_matches_separate_convs(variant, cuda, monkeypatch):
         assert (a[k] - b[k]).abs().max().item() < 2e-5, k
 
 
-@pytest.mark.parametrize("variant,B", [("hrnet_w48_cls-cliff", 64), ("hrnet_w32-pare", 32), ("resnet50-cliff", 64)])
-def test_bench_batch_with_tuned_table(variant, B, cuda):
-    """The batch sizes bench.py runs use the measured tile table (Winograd / LDS-DMA / persistent variants,
-    poco_amd/tuned/gfx950.json): same 1e-3 gate, checked on the first and last crops of the batch."""
-    from poco_amd import tune
+GATED = ("pred_pose", "pred_shape", "pred_cam", "var_pose", "smpl_vertices", "smpl_joints3d")   # north_star: abs 1e-3
+FEATS = ("uncert_feat", "body_feat2", "pred_segm_mask")                                            # relative 1e-3
+
+
+def bench_batch_deviation(variant, B, cuda, profile="stress", seed=2024, pick=None, engine=None):
+    """Engine (tuned table applied for this batch size) vs the CPU oracle on `pick` crops of a B-crop batch.
+    Returns ({key: max-abs deviation}, {key: inter-crop spread of the reference}, {key: max |ref|})."""
     torch.set_num_threads(16)
-    assert any(k.startswith(f"{B}x") for k in tune.load_table()), "tuned table missing for the bench batch size"
-    bnp = synth.synth_batch(B, 2024)
-    pick = np.r_[0:3, B - 3:B]
-    ref = util.oracle_forward(variant, {k: v[pick] for k, v in bnp.items()})
-    m = util.make_engine(variant, max_batch=B)
+    bnp = synth.synth_batch(B, seed, profile=profile)
+    pick = np.r_[0:3, B - 3:B] if pick is None else np.asarray(pick)
+    ref = util.oracle_forward(variant, {k: v[pick] for k, v in bnp.items()}, profile=profile)
+    m = engine or util.make_engine(variant, max_batch=B, profile=profile)
     out = m(util.cuda_batch(bnp, cuda))
     torch.cuda.synchronize()
-    worst = 0.0
-    for k in ("pred_pose", "pred_shape", "pred_cam", "var_pose", "smpl_vertices", "smpl_joints3d"):
-        err = float(np.abs(_np(out[k])[pick] - ref[k].numpy()).max())
-        worst = max(worst, err)
-        assert err < TOL, (k, err)
-    print(variant, B, "max-abs deviation with tuned kernels", worst)
+    dev, spread, mag = {}, {}, {}
+    for k in GATED + FEATS:
+        if k not in ref or k not in out:
+            continue
+        r = ref[k].numpy()
+        dev[k] = float(np.abs(_np(out[k])[pick] - r).max())
+        spread[k] = float(np.abs(r[0] - r[1]).max())
+        mag[k] = float(np.abs(r).max())
+    return dev, spread, mag
+
+
+@pytest.mark.parametrize("profile", ["stress", "default"])
+@pytest.mark.parametrize("variant,B", [("hrnet_w48_cls-cliff", 64), ("hrnet_w32-pare", 32), ("resnet50-cliff", 64),
+                                       ("hrnet_w48_cls-cliff", 128)])
+def test_bench_batch_with_tuned_table(variant, B, profile, cuda):
+    """The batch sizes bench.py runs use the measured tile table (Winograd F(2x2)/F(4x4), LDS-DMA, persistent variants,
+    poco_amd/tuned/gfx950.json).  Same 1e-3 abs gate on the north_star outputs; backbone/head features
+    (uncert_feat, body_feat2, pred_segm_mask) within 1e-3 of their magnitude.  With the stress profile (undamped
+    residual branches) the test also asserts it is not vacuous: the reference's crop-to-crop variation
+    of every compared output is >= 10x the tolerance applied to it."""
+    from poco_amd import tune
+    assert any(k.startswith(f"{B}x") for k in tune.load_table()), "tuned table missing for the bench batch size"
+    dev, spread, mag = bench_batch_deviation(variant, B, cuda, profile)
+    print(variant, B, profile, "max-abs deviation with tuned kernels:", {k: "%.2e" % v for k, v in dev.items()},
+          "| inter-crop spread:", {k: "%.2e" % v for k, v in spread.items()})
+    for k, e in dev.items():
+        tol = TOL if k in GATED else TOL * max(1.0, mag[k])
+        assert e < tol, (k, e, tol)
+        if profile == "stress":
+            assert spread[k] >= 10 * tol, ("vacuous comparison", k, spread[k], tol)
 
 
 def test_graph_replay_matches_eager(cuda):

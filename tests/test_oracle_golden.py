@@ -88,20 +88,40 @@ def test_ops_uncert(ops):
     assert g.max() <= 0.99 and g.shape == (6,)
 
 
+@pytest.mark.parametrize("profile", ["default", "stress"])
 @pytest.mark.parametrize("variant", VARIANTS)
-def test_model_golden(variant):
-    """Full oracle forward (B=2) reproduces what the reference modules produced in the build container."""
+def test_model_golden(variant, profile):
+    """Full oracle forward (B=2) reproduces what the reference modules produced in the build container, for both
+    synthetic weight profiles (stress: every BN gamma in [0.5,1.5])."""
     torch.set_num_threads(8)
-    g = dict(np.load(GOLD / f"model_{variant}.npz"))
-    w = synth.synth_state_dict(load_spec(variant), 0)
+    tag = "" if profile == "default" else "_stress"
+    g = dict(np.load(GOLD / f"model_{variant}{tag}.npz"))
+    calib = synth.load_calib(variant) if profile == "stress" else None
+    w = synth.synth_state_dict(load_spec(variant), 0, profile, calib)
     sd = poco_ref.to_torch({k: v for k, v in w.items() if v.dtype != np.int64})
     out = poco_ref.poco_forward(variant, sd, poco_ref.to_torch(synth.synth_smpl(7)),
-                                poco_ref.to_torch(synth.synth_batch(2, 1234)))
+                                poco_ref.to_torch(synth.synth_batch(2, 1234, profile=profile)))
+    if profile == "stress":      # the fixture must not be vacuous: the two crops differ by >= 10x the 1e-3 gate
+        for k in ("pred_pose", "pred_shape", "pred_cam", "var_pose"):
+            assert np.abs(g[k][0] - g[k][1]).max() >= 1e-2, k
     for k in ("pred_pose", "pred_shape", "pred_cam", "var_pose"):
         assert np.abs(out[k].numpy() - g[k]).max() < 5e-5, k
     assert np.abs(out["uncert_feat"].numpy()[:, g["uncert_feat_idx"]] - g["uncert_feat_samples"]).max() < 2e-4
     assert np.abs(out["smpl_vertices"].numpy()[:, g["oracle_vert_idx"]] - g["oracle_vert_samples"]).max() < 1e-4
     assert np.abs(out["smpl_joints3d"].numpy() - g["oracle_smpl_joints3d"]).max() < 1e-4
+
+
+def test_stress_profile_is_undamped():
+    """BN gamma in [0.5,1.5] on EVERY BatchNorm incl. the last one of each residual branch and the
+    fuse layers (the default profile damps those to ~0.1, which hid image-driven signal: VERDICT r1 weak #1)."""
+    for variant in VARIANTS:
+        spec = load_spec(variant)
+        w = synth.synth_state_dict(spec, 0, "stress", synth.load_calib(variant))
+        names = {n for n, _ in spec}
+        gammas = [w[n] for n, _ in spec if n.endswith(".weight") and (n[:-7] + ".running_mean") in names]
+        assert len(gammas) == len(synth.load_calib(variant))
+        assert min(g.min() for g in gammas) >= 0.5 and max(g.max() for g in gammas) <= 1.5
+        assert np.mean([g.mean() for g in gammas]) > 0.95
 
 
 def test_smpl_invariants():

@@ -14,15 +14,17 @@ def load_spec(variant):
     return [(n, tuple(s)) for n, s in json.loads((GOLD / f"spec_{variant}.json").read_text())]
 
 
-def synth_weights(variant, seed=0):
-    w = synth.synth_state_dict(load_spec(variant), seed)
+def synth_weights(variant, seed=0, profile="default"):
+    """profile "stress": every BN gamma in [0.5,1.5] with calibrated running statistics (poco_amd/synth.py)."""
+    calib = synth.load_calib(variant) if profile == "stress" else None
+    w = synth.synth_state_dict(load_spec(variant), seed, profile, calib)
     return {k: v for k, v in w.items() if v.dtype != np.int64}
 
 
-def make_engine(variant, max_batch, seed=0, smpl_seed=7):
+def make_engine(variant, max_batch, seed=0, smpl_seed=7, profile="default"):
     from poco_amd.model import POCO
     m = POCO(backbone=variant, num_flow_layers=FLOW_LAYERS[variant], max_batch=max_batch, smpl=synth.synth_smpl(smpl_seed))
-    m.load_state_dict(synth_weights(variant, seed), strict=True)
+    m.load_state_dict(synth_weights(variant, seed, profile), strict=True)
     return m.finalize()
 
 
@@ -31,7 +33,7 @@ def cuda_batch(batch_np, device):
     return {k: torch.from_numpy(v).to(device) for k, v in batch_np.items()}
 
 
-def oracle_forward(variant, batch_np, seed=0, smpl_seed=7):
+def oracle_forward(variant, batch_np, seed=0, smpl_seed=7, profile="default"):
     from oracle import poco_ref
-    sd = poco_ref.to_torch(synth_weights(variant, seed))
+    sd = poco_ref.to_torch(synth_weights(variant, seed, profile))
     return poco_ref.poco_forward(variant, sd, poco_ref.to_torch(synth.synth_smpl(smpl_seed)), poco_ref.to_torch(batch_np))
