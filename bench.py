@@ -8,6 +8,11 @@ of the named architecture (the reference's checkpoints and the SMPL model are li
 N>1: one process per GPU (torch.distributed / RCCL), `--batch` crops per GPU (weak scaling), and a
 RCCL all-gather of the packed SMPL parameters [pose 216 | betas 10 | cam 3 | var 24 | conf 1] per
 step.  Rank 0 prints ONE JSON line.
+
+`python bench.py --gpus N` on its own STARTS the N ranks (it re-executes itself under
+`python -m torch.distributed.run --nproc-per-node N`, rendezvous on 127.0.0.1); launched by torchrun
+(WORLD_SIZE set) it is one of the ranks.  With the nccl backend it refuses to run with fewer visible
+GPUs than ranks.  The line carries `dist` = what the process group itself reports (backend, world size).
 """
 from __future__ import annotations
 
@@ -96,11 +101,29 @@ def cpu_baseline(variant, seconds_budget=25.0):
                       f"{variant}, median of {len(times)} passes at the best of 16/32/64/128 threads"}
 
 
+def spawn_ranks(args) -> int:
+    """`python bench.py --gpus N` without a launcher: start N ranks of this same script, one per GPU."""
+    import socket
+    import subprocess
+    ndev = torch.cuda.device_count()
+    if args.backend == "nccl" and ndev < args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus}: only {ndev} GPU(s) visible and the nccl (RCCL) backend needs one "
+                         f"per rank (use --backend gloo to exercise the multi-rank path on fewer devices)")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("OMP_NUM_THREADS", "8")
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--variant", default="hrnet_w48_cls-cliff", choices=list(FLOW_LAYERS))
     ap.add_argument("--batch", type=int, default=64, help="crops per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -113,16 +136,21 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend (nccl = RCCL; gloo only to exercise the multi-rank path on a "
                          "box with fewer GPUs than ranks: ranks then share devices round-robin)")
+    ap.add_argument("--check-gather", action="store_true",
+                    help="N>1: after the timed region rank 0 recomputes every rank's batch and checks the gathered rows "
+                         "bitwise against them (and every rank checks its own rows)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != max(1, args.gpus) and world > 1:
+    if world != max(1, args.gpus):
         raise SystemExit(f"WORLD_SIZE={world} but --gpus {args.gpus}")
     ndev = torch.cuda.device_count()
-    if args.backend == "nccl" and world > 1 and local_rank >= ndev:
-        raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but only {ndev} GPUs visible")
+    if args.backend == "nccl" and world > 1 and world > ndev:
+        raise SystemExit(f"rank {rank}: {world} ranks but only {ndev} GPU(s) visible; RCCL needs one GPU per rank")
     device = torch.device(f"cuda:{local_rank % max(ndev, 1)}")
     torch.cuda.set_device(device)
     dist = None
@@ -133,6 +161,12 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
+        dist_info = {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
+                     "collective": "RCCL all_gather_into_tensor over xGMI" if args.backend == "nccl"
+                     else "gloo all_gather staged through the host (smoke path)",
+                     "devices_visible": ndev}
+    else:
+        dist_info = {"backend": None, "world_size": 1, "collective": None, "devices_visible": ndev}
 
     from poco_amd import synth
     B = args.batch
@@ -150,7 +184,7 @@ def main():
         else:
             model.graph_forward(batch, out)
         if world > 1 and not args.no_gather:
-            rec = pdist.pack_records(out)
+            rec = pdist.pack_records(out, head=args.variant)
             if args.backend == "nccl":
                 dist.all_gather_into_tensor(gathered, rec)          # RCCL over xGMI, device buffers
             else:                                                   # gloo smoke path: staged through the host
@@ -181,6 +215,20 @@ def main():
         elapsed = float(t.item())
     step_ms = [ev[i].elapsed_time(ev[i + 1]) for i in range(args.steps)]
     ev_ms = float(np.mean(step_ms))
+    ev_med = float(np.median(step_ms))
+
+    gather_check = None
+    if world > 1 and args.check_gather and not args.no_gather:
+        mine = pdist.pack_records(out, head=args.variant)
+        ok = bool(torch.equal(gathered[rank * B:(rank + 1) * B], mine))
+        if rank == 0:
+            for r in range(1, world):       # same device type, deterministic kernels: bitwise equality is expected
+                br = {k: torch.from_numpy(v).to(device) for k, v in synth.synth_batch(B, 1234 + r).items()}
+                o = model(br)
+                ok = ok and bool(torch.equal(gathered[r * B:(r + 1) * B], pdist.pack_records(o, head=args.variant)))
+        flag = torch.tensor([1.0 if ok else 0.0], device=device if args.backend == "nccl" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        gather_check = bool(flag.item() == 1.0)
 
     dominant = None
     if rank == 0 and world == 1 and not args.no_dominant:
@@ -209,7 +257,12 @@ def main():
             "metric": "person-crops/sec (224x224) POCO-CLIFF bs=64" if args.variant.endswith("cliff")
                       else "person-crops/sec (224x224) POCO-PARE",
             "value": round(value, 2), "unit": "crops/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "step_ms_events": {"mean": round(ev_ms, 4), "median": round(ev_med, 4), "min": round(min(step_ms), 4),
+                               "max": round(max(step_ms), 4),
+                               "crops_per_s_at_median": round(B / (ev_med * 1e-3), 1),
+                               "note": "per-step HIP events on rank 0's launch stream (SURVEY 8(d): median of the steps)"},
+            "higher_is_better": True, "scaling": "weak", "dist": dist_info,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.variant} forward (backbone+head+SMPL-LBS+confidence MLP), "
                                    f"{B} crops/GPU of 224x224, fp32 MFMA", "variant": args.variant,
@@ -223,6 +276,9 @@ def main():
                                  "of the kernel time, profiles/); `dominant` = the kernel symbol with the most time, "
                                  "algorithmic flops of its launches / their HIP-event time on one stream"},
         }
+        if gather_check is not None:
+            line["dist"]["gather_check"] = ("ok: all gathered rows bitwise equal to the per-rank forwards" if gather_check
+                                            else "FAILED")
         if dominant is not None:
             dominant["frac"] = round(dominant["tflops"] / PEAK_F32_MFMA_TFLOPS, 4)
             line["roofline"]["dominant"] = dominant
@@ -231,6 +287,8 @@ def main():
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
+    if gather_check is False:
+        raise SystemExit("gathered records differ from the per-rank outputs")
 
 
 if __name__ == "__main__":

@@ -213,6 +213,8 @@ def run_ops():
     o["ka_out"] = KeypointAttention(use_conv=False, in_channels=(20, 8), out_channels=(20, 8))(feat, heat).numpy()
     # LocallyConnected2d (locallyconnected2d.py:27-37)
     lc = LocallyConnected2d(in_channels=128, out_channels=6, output_size=[24, 1], kernel_size=1, stride=1)
+    with torch.no_grad():       # seeded weights: the module's own init draws from torch's global RNG (VERDICT r1 c)
+        lc.weight.copy_(torch.from_numpy(synth.synth_state_dict([("lc.weight", tuple(lc.weight.shape))], 3)["lc.weight"]))
     x = torch.from_numpy(r.standard_normal((3, 128, 24, 1)).astype(np.float32))
     with torch.no_grad():
         o["lc_x"], o["lc_w"], o["lc_out"] = x.numpy(), lc.weight.detach().numpy(), lc(x).numpy()
@@ -262,6 +264,39 @@ def run_ops():
     for i in skel[:, 1]:
         v2[:, i] += v2[:, skel[i - 1, 0]]
     o["uncert_var"], o["uncert_kin"] = var, v2
+    # ---- host formulas, produced by the reference's own functions (a16 / a17 / a18) ---------------------------
+    hu = ref_import.setup_host_utils()
+    assert np.array_equal(hu["poco_utils"].get_kinematic_uncert(var.copy()), v2)
+    var_hi = var.copy()
+    var_hi[1, 0], var_hi[4, 0] = 0.93, 0.55          # rows above the cliff (0.8) / pare (0.4) thresholds
+    o["uncert_var2"] = var_hi
+    for bb in ("hrnet_w48_cls-cliff", "hrnet_w32-pare"):
+        for kin in (True, False):
+            pu = ref_import.poco_utils_instance(hu, bb, kin)
+            tag = f"{bb.split('-')[1]}_{'kin' if kin else 'nokin'}"
+            v = pu.prepare_uncert(torch.from_numpy(var_hi.copy()))                 # folder mode, tester.py:242-245
+            o[f"uncert_{tag}_var"] = v.copy()
+            o[f"uncert_{tag}_global"] = np.clip(pu.get_global_uncert(v.copy()), 0, 0.99)
+            vt = pu.prepare_uncert(torch.from_numpy(var_hi.copy()), True)          # video mode, tester.py:416-419
+            o[f"uncert_{tag}_var_video"] = vt.clone().numpy()
+            o[f"uncert_{tag}_global_video"] = pu.get_global_uncert(vt.clone()).numpy()
+    nb = 7
+    ctr = np.stack([r.uniform(100, 1800, nb), r.uniform(50, 1000, nb)], 1)
+    scl = r.uniform(0.6, 3.5, nb)
+    shp = np.array([[1080, 1920], [720, 1280], [1080, 1920], [480, 640], [2160, 3840], [1080, 1920], [1000, 1000]], np.float64)
+    o["bbinfo_center"], o["bbinfo_scale"], o["bbinfo_shape"] = ctr, scl, shp
+    o["bbinfo_out"] = np.stack([hu["image_utils"].calculate_bbox_info(c, s_, sh) for c, s_, sh in zip(ctr, scl, shp)])
+    o["bbinfo_focal"] = np.array([hu["image_utils"].calculate_focal_length(sh[0], sh[1]) for sh in shp])
+    bbox = np.stack([ctr[:, 0], ctr[:, 1], scl * 200.0, scl * 200.0], 1).astype(np.float32)
+    camc = np.stack([r.uniform(0.5, 1.2, nb), r.uniform(-.3, .3, nb), r.uniform(-.3, .3, nb)], 1).astype(np.float32)
+    kp = r.uniform(-1.2, 1.2, (nb, 49, 2)).astype(np.float32)
+    o["ccam_bbox"], o["ccam_cam"], o["ccam_kp"] = bbox, camc, kp
+    o["ccam_orig_cam"] = hu["demo_utils"].convert_crop_cam_to_orig_img(camc, bbox, 1920, 1080)
+    o["ccam_orig_kp"] = hu["demo_utils"].convert_crop_coords_to_orig_img(bbox, kp.copy(), 224)
+    C = hu["constants"]
+    o["joint_map"] = np.array([C.JOINT_MAP[n] for n in C.JOINT_NAMES], np.int32)       # smpl_head.py:17
+    assert np.array_equal(o["joint_map"], synth.JOINT_MAP_49)
+    o["img_norm_mean"], o["img_norm_std"] = np.array(C.IMG_NORM_MEAN), np.array(C.IMG_NORM_STD)
     np.savez_compressed(GOLD / "ops.npz", **o)
     # pin the oracle's small functions
     assert np.abs(poco_ref.rot6d_to_rotmat(torch.from_numpy(x6)).numpy() - o["rot6d_out"]).max() < 1e-6

@@ -83,3 +83,53 @@ def setup(mean_params: dict):
     sys.path.insert(0, REFERENCE)
     import pocolib.models as M   # noqa
     return M
+
+
+class _AnyModule(types.ModuleType):
+    """A module whose every attribute is another such module / a no-op callable: stands in for third-party packages
+    the reference's HOST utilities import at module level but the pinned formulas never call (cv2, trimesh, ...)."""
+
+    def __getattr__(self, k):
+        if k.startswith("__"):
+            raise AttributeError(k)
+        m = _AnyModule(self.__name__ + "." + k)
+        sys.modules[m.__name__] = m
+        setattr(self, k, m)
+        return m
+
+    def __call__(self, *a, **k):
+        return None
+
+
+HOST_STUBS = ["cv2", "trimesh", "trimesh.visual", "trimesh.visual.color", "jpeg4py", "skimage", "skimage.transform",
+              "skimage.util", "skimage.util.shape", "pytube", "scipy.misc", "pyrender", "torchvision.transforms",
+              "torchvision.utils"]
+
+
+def setup_host_utils():
+    """After setup(): make pocolib.utils.{image_utils,demo_utils,poco_utils} importable so that
+    calculate_bbox_info, convert_crop_*_to_orig_img, get_kinematic_uncert and POCOUtils.get_global_uncert /
+    prepare_uncert themselves produce the host-formula vectors in tests/golden/ops.npz."""
+    import importlib
+    import scipy  # noqa: F401  (parent of the scipy.misc stub)
+    assert "pocolib.models" in sys.modules, "call setup() first"
+    for n in HOST_STUBS:
+        if n not in sys.modules:
+            sys.modules[n] = _AnyModule(n)
+            if "." in n:
+                par = sys.modules.get(n.rsplit(".", 1)[0])
+                if par is not None:
+                    setattr(par, n.rsplit(".", 1)[1], sys.modules[n])
+    mods = {}
+    for name in ("image_utils", "demo_utils", "poco_utils"):
+        mods[name] = importlib.import_module(f"pocolib.utils.{name}")
+    mods["constants"] = importlib.import_module("pocolib.core.constants")
+    return mods
+
+
+def poco_utils_instance(mods, backbone: str, kinematic: bool):
+    """POCOUtils(hparams) as POCOTester builds it (tester.py:59-60) for the demo configs."""
+    hp = _CfgNode({"PL_LOGGING": False, "PREF_LOGGER": "none", "METHOD": "demo",
+                   "POCO": {"LOSS_VER": "norm_flow_res_gaus", "BACKBONE": backbone, "UNCERT_TYPE": ["pose"],
+                            "KINEMATIC_UNCERT": kinematic, "LOG_UNCERT_STAT": False, "EXCLUDE_UNCERT_IDX": ""}})
+    return mods["poco_utils"].POCOUtils(hp)

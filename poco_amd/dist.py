@@ -21,14 +21,31 @@ def shard_range(n: int, rank: int, world: int) -> Tuple[int, int]:
     return lo, lo + base + (1 if rank < extra else 0)
 
 
-def pack_records(out: Dict[str, torch.Tensor], var_global: torch.Tensor | None = None) -> torch.Tensor:
+def global_confidence(var_pose: torch.Tensor, head: str, kinematic: bool = True, thr: float = 0.40) -> torch.Tensor:
+    """The post-processed per-crop scalar of the reference, on the device (same arithmetic as postproc.prepare_uncert
+    + postproc.global_uncert = poco_utils.py:21-25,50-60 and the clip of tester.py:245): kinematic accumulation along
+    the SMPL tree, rows whose root exceeds the threshold set to 1, CLIFF: root value, PARE: mean over joints."""
+    from .synth import SMPL_PARENTS
+    var = var_pose.clone()
+    if kinematic:
+        for i in range(1, 24):
+            var[:, i] += var[:, int(SMPL_PARENTS[i])]
+    cliff = "cliff" in head
+    var[var[:, 0] > (2 * thr if cliff else thr)] = 1.0
+    g = var[:, 0] if cliff else var.mean(-1)
+    return g.clamp(0.0, 0.99)
+
+
+def pack_records(out: Dict[str, torch.Tensor], var_global: torch.Tensor | None = None, head: str = "cliff",
+                 kinematic: bool = True) -> torch.Tensor:
+    """[rotmat 216 | betas 10 | cam 3 | var_pose 24 (raw network output) | var_global 1 (post-processed)]."""
     B = out["pred_shape"].shape[0]
     rec = torch.empty(B, REC, device=out["pred_shape"].device, dtype=torch.float32)
     rec[:, 0:216] = out["pred_pose"].reshape(B, 216)
     rec[:, 216:226] = out["pred_shape"]
     rec[:, 226:229] = out["pred_cam"]
     rec[:, 229:253] = out["var_pose"]
-    rec[:, 253] = out["var_pose"][:, 0] if var_global is None else var_global
+    rec[:, 253] = global_confidence(out["var_pose"], head, kinematic) if var_global is None else var_global
     return rec
 
 

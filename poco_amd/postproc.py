@@ -39,6 +39,21 @@ def global_uncert(var: np.ndarray, backbone: str, thr: float = 0.40, clip: bool 
     return np.clip(g, 0, 0.99) if clip else g
 
 
+def folder_uncert(var_pose, backbone: str, kinematic: bool):
+    """(var, var_global) as POCOTester.run_on_image_folder stores them (tester.py:242-245): kinematic accumulation
+    governed by KINEMATIC_UNCERT (= not --no_kinematic_uncert), global value clipped to [0, 0.99]."""
+    var = prepare_uncert(var_pose, kinematic)
+    return var, global_uncert(var, backbone, clip=True)
+
+
+def video_uncert(var_pose, backbone: str, kinematic: bool):
+    """(var, var_global) as POCOTester.run_on_video stores them (tester.py:416-419).  The `True` the reference passes
+    to prepare_uncert there is `return_torch`, NOT a kinematic switch: accumulation is still governed by
+    KINEMATIC_UNCERT; the global value is not clipped in this mode."""
+    var = prepare_uncert(var_pose, kinematic)
+    return var, global_uncert(var, backbone, clip=False)
+
+
 def convert_crop_cam_to_orig_img(cam, bbox, img_width, img_height):
     cx, cy, h = bbox[:, 0], bbox[:, 1], bbox[:, 2]
     hw, hh = img_width / 2.0, img_height / 2.0

@@ -97,9 +97,8 @@ class POCOTester:
         if "cliff" not in self.backbone:                                             # tester.py:225-230
             j2d = postproc.convert_crop_coords_to_orig_img(dets, j2d, self.model_cfg.DATASET.IMG_RES)
         res["smpl_joints2d"] = np.concatenate([j2d, np.ones((len(dets), 49, 1), np.float32)], -1)
-        var = postproc.prepare_uncert(output["var_pose"], self.model_cfg.POCO.KINEMATIC_UNCERT)
-        res["var"] = var
-        res["var_global"] = postproc.global_uncert(var, self.backbone)               # tester.py:242-245
+        res["var"], res["var_global"] = postproc.folder_uncert(output["var_pose"], self.backbone,
+                                                               self.model_cfg.POCO.KINEMATIC_UNCERT)   # tester.py:242-245
         return res
 
     @torch.no_grad()
@@ -182,7 +181,8 @@ class POCOTester:
                 from .smooth import smooth_pose
                 verts, pose, j3d = smooth_pose(self.model, pose, betas, getattr(self.args, "min_cutoff", 0.004),
                                                getattr(self.args, "beta", 1.5))
-            var = postproc.prepare_uncert(torch.from_numpy(st["var_pose"]), True)       # tester.py:416-419
+            var, var_global = postproc.video_uncert(st["var_pose"], self.backbone,
+                                                    self.model_cfg.POCO.KINEMATIC_UNCERT)    # tester.py:416-419
             results[pid] = {
                 "pred_cam": st["pred_cam"],
                 "orig_cam": postproc.convert_crop_cam_to_orig_img(st["pred_cam"], bboxes, orig_width, orig_height),
@@ -190,7 +190,7 @@ class POCOTester:
                 "smpl_joints3d": j3d,
                 "smpl_joints2d": postproc.convert_crop_coords_to_orig_img(bboxes, st["smpl_joints2d"],
                                                                           self.model_cfg.DATASET.IMG_RES),
-                "var": var, "var_global": postproc.global_uncert(var, self.backbone, clip=False),
+                "var": var, "var_global": var_global,
                 "bboxes": bboxes, "frame_ids": np.asarray(tr["frames"]),
             }
         return results
