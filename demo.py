@@ -42,15 +42,49 @@ def parse_args(argv=None):
     p.add_argument("--save_obj", action="store_true", help="save results as .obj files (meshes/<image|person>/<idx>.obj)")
     p.add_argument("--detections", type=str, default=None,
                    help="json {image name: [[cx,cy,w,h],...]} or the reference's detection_results.pkl (per-image list)")
+    p.add_argument("--gpus", type=int, default=1,
+                   help="video mode: one process per GPU, whole tracks sharded across the ranks, ONE all-gather of the "
+                        "packed SMPL records (RCCL over xGMI); `demo.py --gpus N` starts the N ranks itself")
+    p.add_argument("--dist_backend", default="nccl", choices=["nccl", "gloo"],
+                   help="nccl = RCCL (one GPU per rank); gloo only to exercise the multi-rank path on fewer devices")
     p.add_argument("--smpl", type=str, default="data/smpl/SMPL_NEUTRAL.npz",
                    help="SMPL body model as .npz (tools/convert_smpl.py converts the licensed .pkl)")
     return p.parse_args(argv)
 
 
+def _spawn_ranks(args) -> int:
+    """`demo.py --gpus N` without a launcher: re-execute under torch.distributed.run, one rank per GPU."""
+    import socket
+    import subprocess
+    import torch
+    if args.dist_backend == "nccl" and torch.cuda.device_count() < args.gpus:
+        sys.exit(f"demo.py --gpus {args.gpus}: only {torch.cuda.device_count()} GPU(s) visible; RCCL needs one per rank")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+
+
 def main(args):
-    from poco_amd.tester import POCOTester, load_detections
     if args.mode in ("webcam",):
         sys.exit("webcam mode needs a capture device + renderer: out of scope")
+    if args.gpus > 1:
+        if args.mode != "video":
+            sys.exit("--gpus N shards whole tracks: video mode only (folder mode images are independent - run N demos)")
+        if "WORLD_SIZE" not in os.environ:
+            sys.exit(_spawn_ranks(args))
+        import torch
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if args.dist_backend == "nccl":
+            dev = torch.device("cuda", int(os.environ["LOCAL_RANK"]))
+            torch.cuda.set_device(dev)
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
+    from poco_amd.tester import POCOTester, load_detections
     folder = args.image_folder if args.mode in ("folder", "directory") else args.vid_file
     if not folder or not os.path.isdir(folder):
         sys.exit(f"input folder not found: {folder}")
@@ -60,7 +94,11 @@ def main(args):
         stats = tester.run_on_video_folder(folder, args.tracking, out_dir)
     else:
         stats = tester.run_on_image_folder(folder, load_detections(args.detections), out_dir)
-    print(json.dumps({"poco_fps": round(stats["fps"], 2), **stats}))     # reference logs 'poco FPS' (demo.py:136-145)
+    if "fps" in stats:                                                    # rank 0 (the reference logs 'poco FPS', demo.py:136-145)
+        print(json.dumps({"poco_fps": round(stats["fps"], 2), **stats}))
+    if args.gpus > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -1244,8 +1244,15 @@ extern "C" int poco_load_tensor(poco_handle_t h, const char* name, const float* 
   size_t n = 1, nd = 1;
   for (int k = 0; k < rank; ++k) n *= (size_t)shape[k];
   for (int64_t s : d.shape) nd *= (size_t)s;
-  if (n != nd) {
-    poco_set_error(std::string("shape mismatch for ") + name + ": got " + std::to_string(n) + " elements, expected " + std::to_string(nd));
+  // strict: the shapes must agree dimension by dimension once size-1 dimensions are dropped (a checkpoint may store
+  // init_pose as [1,144] or [144]); the same element count in a different arrangement (a transposed Linear weight,
+  // shapedirs stored [10,V,3]) is an error, as it is for the reference's load_state_dict
+  std::vector<int64_t> got, want;
+  for (int k = 0; k < rank; ++k) if (shape[k] != 1) got.push_back(shape[k]);
+  for (int64_t s : d.shape) if (s != 1) want.push_back(s);
+  if (n != nd || got != want) {
+    auto fmt = [](const int64_t* v, size_t m) { std::string t = "["; for (size_t k = 0; k < m; ++k) t += (k ? "," : "") + std::to_string(v[k]); return t + "]"; };
+    poco_set_error(std::string("shape mismatch for ") + name + ": got " + fmt(shape, (size_t)rank) + ", expected " + fmt(d.shape.data(), d.shape.size()));
     return POCO_ERR_SHAPE;
   }
   HostParam p;

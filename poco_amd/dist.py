@@ -88,20 +88,32 @@ def shard_tracks(tracking_results: dict, rank: int, world: int) -> dict:
     return mine
 
 
-def gather_track_records(local: Dict[str, torch.Tensor], group=None) -> Dict[str, torch.Tensor]:
+def collective_device(group=None) -> torch.device:
+    """Where the buffers of a collective must live for the group's backend: RCCL ("nccl") moves device memory,
+    gloo host memory."""
+    import torch.distributed as dist
+    if dist.get_backend(group) == "nccl":
+        return torch.device("cuda", torch.cuda.current_device())
+    return torch.device("cpu")
+
+
+def gather_track_records(local: Dict[str, torch.Tensor], group=None, device=None) -> Dict[str, torch.Tensor]:
     """All ranks end up with every track's [T, 254] records.  `local`: {person_id: [T,254] tensor} of this rank.
-    One all-gather of the concatenated rows (padded to the largest rank) + one object gather of the (id, T) index."""
+    One all-gather of the concatenated rows (padded to the largest rank) + one object gather of the (id, T) index.
+    The collective's buffers are allocated on `device` (default: what the group's backend needs), also on a rank that
+    owns no track at all (more ranks than people is the common video case)."""
     import torch.distributed as dist
     world = dist.get_world_size(group)
+    dev = torch.device(device) if device is not None else collective_device(group)
     ids = sorted(local, key=str)
     index = [(k, int(local[k].shape[0])) for k in ids]
     all_index: List[list] = [None] * world
     dist.all_gather_object(all_index, index, group=group)
-    rows = torch.cat([local[k] for k in ids], 0) if ids else torch.zeros(0, REC)
     nmax = max(1, max(sum(t for _, t in idx) for idx in all_index))
-    dev = rows.device
     send = torch.zeros(nmax, REC, device=dev, dtype=torch.float32)
-    send[: rows.shape[0]] = rows
+    if ids:
+        rows = torch.cat([local[k].to(dev) for k in ids], 0)
+        send[: rows.shape[0]] = rows
     buf = torch.empty(world * nmax, REC, device=dev, dtype=torch.float32)
     dist.all_gather_into_tensor(buf, send, group=group)
     out = {}

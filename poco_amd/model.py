@@ -76,7 +76,7 @@ class POCO:
                  num_flow_layers=3, sigma_dim=1, num_nf_rv=9, mask_params_id="", nflow_mask_type="alter",
                  exclude_uncert_idx="", use_dropout=False, use_iter_feats=False, cond_nflow=True, context_dim=512,
                  gt_pose_cond=False, gt_pose_cond_ds="h36m", gt_pose_cond_ratio=0.25, pretrained=None,
-                 inf_model="best", is_test=True, *, max_batch=64, smpl=None, device="cuda:0"):
+                 inf_model="best", is_test=True, *, max_batch=64, smpl=None, device="cuda:0", keep_state_dict=True):
         if img_res != 224:
             raise ValueError("the engine is built for 224x224 crops (configs/demo_poco_*.yaml DATASET.IMG_RES)")
         if uncert_layer != "diff_branch" or activation_type != "sigmoid" or sigma_dim != 1 or num_nf_rv != 9:
@@ -94,6 +94,7 @@ class POCO:
               "poco_create")
         self._finalized = False
         self._loaded = set()
+        self._state = {} if keep_state_dict else None    # host references for state_dict() (the engine packs its own copy)
         if smpl is not None:
             self.load_smpl(smpl)
         if pretrained is not None:
@@ -133,6 +134,8 @@ class POCO:
         check(self._L.poco_load_tensor(self._h, name.encode(), C.c_void_p(arr.ctypes.data), shp, arr.ndim),
               f"poco_load_tensor({name})")
         self._loaded.add(name)
+        if self._state is not None and not name.startswith("smpl."):
+            self._state[name] = arr
 
     def load_state_dict(self, state_dict: Dict[str, object], strict: bool = True):
         """Keys as in the reference checkpoint after `model.` stripping: backbone.*, head.*,
@@ -149,6 +152,20 @@ class POCO:
         if unexpected and strict:
             raise PocoHipError(f"unexpected keys in state_dict: {unexpected[:8]}{' ...' if len(unexpected) > 8 else ''}")
         return unexpected
+
+    def state_dict(self) -> "Dict[str, torch.Tensor]":
+        """The loaded parameters under the reference's state_dict keys (nn.Module.state_dict of pocolib.models.POCO,
+        poco.py:13-42, minus the `smpl.*` buffers), in the engine's declaration order, as CPU tensors.  The engine itself
+        keeps only BN-folded, MFMA-fragment-packed copies on the device; these are the host arrays handed to
+        load_state_dict (held by reference, `keep_state_dict=False` drops them)."""
+        if self._state is None:
+            raise PocoHipError("state_dict(): the model was built with keep_state_dict=False")
+        from collections import OrderedDict
+        out = OrderedDict()
+        for name, _, _ in self.expected_tensors():
+            if name in self._state:
+                out[name] = torch.from_numpy(self._state[name])
+        return out
 
     def load_smpl(self, smpl) -> None:
         if isinstance(smpl, (str, Path)):

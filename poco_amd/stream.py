@@ -42,8 +42,13 @@ class CropStream:
                       "center": torch.zeros(self.B, 2, device=self.dev, dtype=f),
                       "orig_shape": torch.tensor([[self.H, self.W]], device=self.dev, dtype=f).repeat(self.B, 1)}
         self.out = self.m._alloc_outputs(self.B, False)
-        self.meta_h = torch.empty(self.B, 10, dtype=f).pin_memory()   # boxes 4 | bbox_info 3 | focal 1 | scale 1 | pad
+        # boxes 4 | bbox_info 3 | focal 1 | scale 1 | pad.  One pinned staging buffer per in-flight run (indexed by
+        # `host_buf` like rec_h): run(i+1) is enqueued while run(i)'s H2D copy may still sit behind a ~30 ms forward,
+        # so a single buffer would be overwritten on the host before the copy has read it.
+        self.meta_h = [torch.empty(self.B, 10, dtype=f).pin_memory() for _ in range(2)]
+        self.ev_meta = [torch.cuda.Event() for _ in range(2)]         # H2D copy of meta_h[i] finished
         self.meta_d = torch.empty(self.B, 10, device=self.dev, dtype=f)
+        self._pending = [False] * ring                                # slot uploaded and not yet consumed by run()
         self.rec_d = torch.empty(self.B, REC, device=self.dev, dtype=f)
         self.rec_h = [torch.empty(self.B, REC, dtype=f).pin_memory() for _ in range(2)]
         self.want_vertices = want_vertices
@@ -56,7 +61,11 @@ class CropStream:
     # -- one frame: async upload into the ring ----------------------------------------------------------
     def upload(self, frame: np.ndarray) -> int:
         k = self._slot
+        if self._pending[k]:
+            raise RuntimeError(f"CropStream ring of {self.ring} frames is too small: slot {k} would be re-uploaded before "
+                               "run() consumed it (enqueue fewer frames ahead or build the stream with a larger ring)")
         self._slot = (k + 1) % self.ring
+        self._pending[k] = True
         self.ev_free[k].synchronize()                       # host: the slot's previous crops were consumed
         self.h_frames[k].numpy()[...] = frame
         with torch.cuda.stream(self.copy_stream):
@@ -65,11 +74,17 @@ class CropStream:
         return k
 
     # -- a full batch: (slot, [n,4] boxes) pairs with sum(n) <= B -----------------------------------------
-    def run(self, groups: Sequence[Tuple[int, np.ndarray]], host_buf: int = 0) -> Tuple[torch.Tensor, int]:
+    def run(self, groups: Sequence[Tuple[int, np.ndarray]], host_buf: int = 0,
+            keep: Sequence[int] = ()) -> Tuple[torch.Tensor, int]:
         """Crops + forward + packed record D2H (async).  Returns (pinned host records, n); the caller must
-        torch.cuda.current_stream().synchronize() (or wait on its own event) before reading them."""
+        torch.cuda.current_stream().synchronize() (or wait on its own event) before reading them.
+        `host_buf` (0/1) selects the pinned staging buffers of this run; alternate it between consecutive runs that
+        are in flight together.  `keep`: ring slots whose frame a later run() will crop from again (a frame with more
+        people than fit into this batch); all other slots in `groups` become free for upload() once this run's
+        crops are done."""
         st = torch.cuda.current_stream()
-        mh = self.meta_h.numpy()
+        self.ev_meta[host_buf].synchronize()                # host: the previous H2D copy out of this staging buffer is done
+        mh = self.meta_h[host_buf].numpy()
         n = 0
         spans = []
         for slot, boxes in groups:
@@ -85,7 +100,8 @@ class CropStream:
             spans.append((slot, n, k))
             n += k
         assert 0 < n <= self.B
-        self.meta_d.copy_(self.meta_h, non_blocking=True)
+        self.meta_d.copy_(self.meta_h[host_buf], non_blocking=True)
+        self.ev_meta[host_buf].record(st)
         self.batch["bbox_info"].copy_(self.meta_d[:, 4:7])
         self.batch["focal_length"].copy_(self.meta_d[:, 7])
         self.batch["scale"].copy_(self.meta_d[:, 8])
@@ -98,6 +114,8 @@ class CropStream:
                                               self.batch["img"][lo:lo + k].data_ptr(), C.c_void_p(st.cuda_stream)),
                   "poco_crop_normalize")
             self.ev_free[slot].record(st)
+            if slot not in keep:
+                self._pending[slot] = False
         out = self.m.graph_forward(self.batch, self.out)      # full-B replay; rows >= n are stale crops, ignored
         r = self.rec_d
         r[:, 0:216].copy_(out["pred_pose"].reshape(self.B, 216))

@@ -58,10 +58,14 @@ class POCOTester:
         # demo.py:305 passes store_false: default True = kinematic post-processing on
         self.model_cfg.POCO.KINEMATIC_UNCERT = getattr(args, "no_kinematic_uncert", True)
         self.backbone = self.model_cfg.POCO.BACKBONE
-        self.device = torch.device("cuda:0")
+        # one process per GPU (demo.py --gpus N): LOCAL_RANK picks the device; ranks beyond the visible devices
+        # (gloo smoke runs on a smaller box) share them round-robin
+        ndev = max(torch.cuda.device_count(), 1)
+        self.device = torch.device(f"cuda:{int(os.environ.get('LOCAL_RANK', '0')) % ndev}")
+        torch.cuda.set_device(self.device)
         kw = model_kwargs(self.model_cfg)
         self.model = POCO(**kw, pretrained=args.ckpt, inf_model=getattr(args, "inf_model", "best"),
-                          max_batch=max(int(args.batch_size), 1), smpl=args.smpl, device="cuda:0").finalize()
+                          max_batch=max(int(args.batch_size), 1), smpl=args.smpl, device=str(self.device)).finalize()
         self.faces = None                       # triangle list for --save_obj, if the body-model file carries one
         if isinstance(args.smpl, str) and os.path.isfile(args.smpl):
             with np.load(args.smpl) as z:
@@ -196,36 +200,40 @@ class POCOTester:
         return results
 
     def run_on_image_folder(self, image_folder: str, detections, output_path: str, bbox_scale=1.0):
+        """pocolib/core/tester.py:153-245: images are streamed one at a time (decode -> regress -> write), every
+        `--skip_frame`-th image of the sorted listing (tester.py:171), so host memory does not grow with the folder."""
         from PIL import Image
-        names = sorted(x for x in os.listdir(image_folder) if x.lower().endswith(IMG_EXT))
-        frames, dets = [], []
-        for n in names:
+        names_all = sorted(x for x in os.listdir(image_folder) if x.lower().endswith(IMG_EXT))
+        skip = max(int(getattr(self.args, "skip_frame", 1) or 1), 1)
+        os.makedirs(output_path, exist_ok=True)
+        n_img = n_crops = 0
+        dt = 0.0
+        for pos in range(0, len(names_all), skip):
+            n = names_all[pos]
             img = np.asarray(Image.open(os.path.join(image_folder, n)).convert("RGB"))
-            frames.append(img)
             d = None
             if isinstance(detections, dict):
                 d = detections.get(n)
-            elif detections is not None and len(frames) - 1 < len(detections):     # reference cache: indexed by image position
-                d = detections[len(frames) - 1]
+            elif detections is not None and pos < len(detections):      # reference cache: indexed by image position
+                d = detections[pos]
             if d is not None and len(d) > 0:
-                dets.append(np.asarray(d, dtype=np.float32).reshape(-1, 4))
+                d = np.asarray(d, dtype=np.float32).reshape(-1, 4)
             else:                       # no detector in scope: one centred square box over the image
                 H, W = img.shape[:2]
                 s = float(min(H, W))
-                dets.append(np.array([[W / 2.0, H / 2.0, s, s]], dtype=np.float32))
-        t0 = time.time()
-        results = self.run_on_frames(frames, dets, bbox_scale)
-        torch.cuda.synchronize()
-        dt = time.time() - t0
-        os.makedirs(output_path, exist_ok=True)
-        n_crops = sum(len(d) for d in dets)
-        for n, r in zip(names, results):
+                d = np.array([[W / 2.0, H / 2.0, s, s]], dtype=np.float32)
+            t0 = time.time()
+            r = self.run_on_frames([img], [d], bbox_scale)[0]
+            torch.cuda.synchronize()
+            dt += time.time() - t0
+            n_img += 1
+            n_crops += len(d)
             if r is not None:
                 np.savez_compressed(os.path.join(output_path, os.path.splitext(n)[0] + "_poco.npz"), **r)
                 if getattr(self.args, "save_obj", False):          # tester.py:300-303
                     self._save_meshes(os.path.join(output_path, "meshes", os.path.splitext(n)[0]), r["verts"],
                                       [f"{i:06d}" for i in range(len(r["verts"]))])
-        return {"images": len(names), "crops": n_crops, "seconds": dt, "fps": len(names) / max(dt, 1e-9),
+        return {"images": n_img, "crops": n_crops, "seconds": dt, "fps": n_img / max(dt, 1e-9),
                 "crops_per_s": n_crops / max(dt, 1e-9)}
 
 
@@ -248,10 +256,24 @@ def _run_on_video_folder(self, frame_folder: str, tracking_path: Optional[str], 
     if skip > 1:
         tracking = {k: {"bbox": v["bbox"][::skip], "frames": v["frames"][::skip]} for k, v in tracking.items()}
     load = lambda i: np.asarray(Image.open(os.path.join(frame_folder, names[i])).convert("RGB"))   # noqa: E731
+    import torch.distributed as tdist
+    world = tdist.get_world_size() if tdist.is_available() and tdist.is_initialized() else 1
+    rank = tdist.get_rank() if world > 1 else 0
     t0 = time.time()
-    results = self.run_on_video(tracking, load, W, H, bbox_scale)
+    if world > 1:
+        # whole tracks are the unit of sharding (temporal smoothing stays local); the only exchange is
+        # one all-gather of the packed per-frame SMPL records, everything else is re-derived from them
+        from . import dist as pdist
+        mine = pdist.shard_tracks(tracking, rank, world)
+        results = self.run_on_video(mine, load, W, H, bbox_scale) if mine else {}
+        results = self._merge_rank_results(results, tracking, W, H)
+    else:
+        results = self.run_on_video(tracking, load, W, H, bbox_scale)
     torch.cuda.synchronize()
     dt = time.time() - t0
+    if rank != 0:
+        tdist.barrier()
+        return {"rank": rank, "tracks_local": len(mine), "seconds": dt}
     os.makedirs(output_path, exist_ok=True)
     flat = {f"{pid}/{k}": v for pid, r in results.items() for k, v in r.items() if v is not None}
     np.savez_compressed(os.path.join(output_path, "poco_results.npz"), **flat)
@@ -261,11 +283,56 @@ def _run_on_video_folder(self, frame_folder: str, tracking_path: Optional[str], 
             self._save_meshes(os.path.join(output_path, "meshes", sub), r["verts"], [f"{int(f):06d}" for f in r["frame_ids"]])
     n_crops = sum(len(v["frames"]) for v in tracking.values())
     n_frames = len({int(f) for v in tracking.values() for f in v["frames"]})
-    return {"images": n_frames, "crops": n_crops, "tracks": len(tracking), "seconds": dt,
+    if world > 1:
+        tdist.barrier()
+    return {"images": n_frames, "crops": n_crops, "tracks": len(tracking), "seconds": dt, "ranks": world,
             "fps": n_frames / max(dt, 1e-9), "crops_per_s": n_crops / max(dt, 1e-9)}
 
 
+def _merge_rank_results(self, local: dict, tracking: dict, W: int, H: int) -> dict:
+    """Multi-GPU video mode: every rank packs its tracks' per-frame records [pose 216 | betas 10 | cam 3 | var 24 |
+    var_global 1] (after smoothing / uncertainty post-processing), ONE all-gather (RCCL when the group's backend is
+    nccl) hands every rank every track, and the mesh-level entries of tracks regressed elsewhere are re-derived from the
+    gathered parameters with the batched LBS operator - 1 KB per crop crosses xGMI instead of 83 KB of vertices."""
+    from . import dist as pdist
+    dev = pdist.collective_device()
+    recs = {}
+    for pid, r in local.items():
+        T = len(r["frame_ids"])
+        rec = np.empty((T, pdist.REC), np.float32)
+        rec[:, 0:216] = r["pose"].reshape(T, 216)
+        rec[:, 216:226], rec[:, 226:229], rec[:, 229:253], rec[:, 253] = r["betas"], r["pred_cam"], r["var"], r["var_global"]
+        recs[str(pid)] = torch.from_numpy(rec).to(dev)
+    full = pdist.gather_track_records(recs, device=dev)
+    out = {}
+    cliff = "cliff" in self.backbone
+    res = self.model_cfg.DATASET.IMG_RES
+    for pid, tr in tracking.items():
+        if pid in local:
+            out[pid] = local[pid]
+            continue
+        rec = full[str(pid)].cpu().numpy()
+        T = rec.shape[0]
+        pose, betas, cam = rec[:, 0:216].reshape(T, 24, 3, 3), rec[:, 216:226], rec[:, 226:229]
+        verts = np.empty((T, 6890, 3), np.float32)
+        j3d = np.empty((T, 49, 3), np.float32)
+        for lo in range(0, T, self.model.max_batch):
+            hi = min(T, lo + self.model.max_batch)
+            v, j = self.model.smpl_lbs(torch.from_numpy(np.ascontiguousarray(betas[lo:hi])).to(self.device),
+                                       torch.from_numpy(np.ascontiguousarray(pose[lo:hi])).to(self.device))
+            verts[lo:hi], j3d[lo:hi] = v.cpu().numpy(), j.cpu().numpy()
+        bboxes = np.asarray(tr["bbox"], np.float32).reshape(-1, 4)
+        j2d = postproc.joints2d_from_params(j3d, cam, bboxes, W, H, cliff, res)
+        out[pid] = {"pred_cam": cam, "orig_cam": postproc.convert_crop_cam_to_orig_img(cam, bboxes, W, H),
+                    "verts": verts, "pose": pose, "betas": betas, "joints2d": None, "smpl_joints3d": j3d,
+                    "smpl_joints2d": postproc.convert_crop_coords_to_orig_img(bboxes, j2d, res),
+                    "var": rec[:, 229:253], "var_global": rec[:, 253], "bboxes": bboxes,
+                    "frame_ids": np.asarray(tr["frames"])}
+    return out
+
+
 POCOTester.run_on_video_folder = _run_on_video_folder
+POCOTester._merge_rank_results = _merge_rank_results
 
 
 def _load_any(path: str):

@@ -192,3 +192,124 @@ def test_crop_stream_matches_batch_path(tmp_path, cuda):
             assert np.abs(rec[row:row + k, 226:229] - out["pred_cam"].cpu().numpy()).max() < 1e-5
             assert np.abs(rec[row:row + k, 229:253] - out["var_pose"].cpu().numpy()).max() < 1e-5
             row += k
+
+
+def test_demo_folder_pare_b1_stress(tmp_path, cuda):
+    """BASELINE.json config #1: POCO-PARE, ONE 224x224 crop, bs=1, through `demo.py --cfg configs/demo_poco_pare.yaml
+    --mode folder`, against the CPU oracle on the very same crop.  Stress weights (undamped residual branches), so the
+    1e-3 gate is far below the image-driven signal."""
+    from PIL import Image
+    import demo
+    from oracle import poco_ref
+    from oracle.crop_np import crop_normalize_np
+    variant = "hrnet_w32-pare"
+    w = util.synth_weights(variant, profile="stress")
+    torch.save({"state_dict": {"model." + k: torch.from_numpy(v) for k, v in w.items()}}, tmp_path / "poco_pare_synth.pt")
+    smpl = synth.synth_smpl(7)
+    np.savez(tmp_path / "smpl.npz", **smpl)
+    imgs = tmp_path / "one"
+    imgs.mkdir()
+    r = np.random.default_rng(11)
+    # a 224x224 image with structure (blocks + noise): the default centred box is the whole image = "a 224x224 crop"
+    frame = np.clip(128 + 60 * r.standard_normal((7, 7, 3)).repeat(32, 0).repeat(32, 1) + 25 * r.standard_normal((224, 224, 3)),
+                    0, 255).astype(np.uint8)
+    Image.fromarray(frame).save(imgs / "crop.png")
+    args = demo.parse_args(["--cfg", "configs/demo_poco_pare.yaml", "--ckpt", str(tmp_path / "poco_pare_synth.pt"),
+                            "--mode", "folder", "--image_folder", str(imgs), "--output_folder", str(tmp_path / "out"),
+                            "--batch_size", "1", "--smpl", str(tmp_path / "smpl.npz"), "--no_render"])
+    demo.main(args)
+    res = dict(np.load(tmp_path / "out" / "one_" / "crop_poco.npz"))
+    det = np.array([[112.0, 112.0, 224.0, 224.0]], np.float32)
+    assert np.array_equal(res["bboxes"], det)
+    batch = {"img": crop_normalize_np(frame, det)}
+    ref = poco_ref.poco_forward(variant, poco_ref.to_torch(w), poco_ref.to_torch(smpl), poco_ref.to_torch(batch))
+    dev = {"pose": np.abs(res["pose"] - ref["pred_pose"].numpy()).max(), "betas": np.abs(res["betas"] - ref["pred_shape"].numpy()).max(),
+           "cam": np.abs(res["pred_cam"] - ref["pred_cam"].numpy()).max(), "verts": np.abs(res["verts"] - ref["smpl_vertices"].numpy()).max(),
+           "joints3d": np.abs(res["joints3d"] - ref["smpl_joints3d"].numpy()).max()}
+    from poco_amd import postproc
+    var_ref, g_ref = postproc.folder_uncert(ref["var_pose"].numpy(), variant, True)
+    dev["var"] = np.abs(res["var"] - var_ref).max()
+    dev["var_global"] = np.abs(res["var_global"] - g_ref).max()
+    print("PARE bs=1 via demo.py, max-abs deviation vs the CPU oracle:", {k: "%.2e" % v for k, v in dev.items()})
+    assert max(dev.values()) < 1e-3, dev
+    assert res["verts"].shape == (1, 6890, 3) and res["smpl_joints2d"].shape == (1, 49, 3)
+
+
+def test_crop_stream_b128_w48_against_oracle(cuda):
+    """BASELINE.json config #5 shape on one GPU: HRNet-W48-CLIFF at bs=128 through CropStream (pinned 1080p frame ring
+    -> GPU crop/normalise -> hipGraph forward with the tuned table -> packed record), 4 people per frame; a 6-crop subset
+    (first / middle / last rows) against the CPU oracle on numpy-cropped inputs.  Stress weights."""
+    from oracle import poco_ref
+    from oracle.crop_np import crop_normalize_np
+    from poco_amd.stream import CropStream, REC
+    from poco_amd.tester import calculate_bbox_info, calculate_focal_length
+    variant, B, people, H, W = "hrnet_w48_cls-cliff", 128, 4, 1080, 1920
+    m = util.make_engine(variant, max_batch=B, profile="stress")
+    cs = CropStream(m, (H, W), B, ring=B // people)
+    r = np.random.default_rng(21)
+    base = [np.clip(128 + 70 * r.standard_normal((9, 16, 3)).repeat(120, 0).repeat(120, 1), 0, 255).astype(np.uint8) for _ in range(3)]
+    frames = [np.clip(base[i % 3].astype(np.int16) + r.integers(-30, 30, (H, W, 3)), 0, 255).astype(np.uint8) for i in range(B // people)]
+    boxes = [np.stack([np.array([r.uniform(0.2, 0.8) * W, r.uniform(0.3, 0.7) * H, s, s * r.uniform(0.8, 1.6)], np.float32)
+                       for s in r.uniform(150, 500, people)]) for _ in frames]
+    rec, n = cs.run([(cs.upload(f), b) for f, b in zip(frames, boxes)])
+    torch.cuda.synchronize()
+    assert n == B and rec.shape == (B, REC)
+    rec = rec.numpy().copy()
+    pick = [0, 1, 62, 65, 126, 127]
+    crops, info, scl, ctr = [], [], [], []
+    for row in pick:
+        f, d = frames[row // people], boxes[row // people][row % people:row % people + 1]
+        crops.append(crop_normalize_np(f, d)[0])
+        s = float(max(d[0, 2], d[0, 3]) / 200.0)
+        info.append(calculate_bbox_info(d[0, :2], s, (H, W))); scl.append(s); ctr.append(d[0, :2])
+    batch = {"img": np.stack(crops), "bbox_info": np.stack(info), "focal_length": np.full(len(pick), calculate_focal_length(H, W), np.float32),
+             "scale": np.array(scl, np.float32), "center": np.stack(ctr).astype(np.float32),
+             "orig_shape": np.tile([[float(H), float(W)]], (len(pick), 1)).astype(np.float32)}
+    torch.set_num_threads(16)
+    ref = poco_ref.poco_forward(variant, poco_ref.to_torch(util.synth_weights(variant, profile="stress")),
+                                poco_ref.to_torch(synth.synth_smpl(7)), poco_ref.to_torch(batch))
+    got = rec[pick]
+    dev = {"pose": np.abs(got[:, :216] - ref["pred_pose"].numpy().reshape(-1, 216)).max(),
+           "betas": np.abs(got[:, 216:226] - ref["pred_shape"].numpy()).max(),
+           "cam": np.abs(got[:, 226:229] - ref["pred_cam"].numpy()).max(),
+           "var": np.abs(got[:, 229:253] - ref["var_pose"].numpy()).max()}
+    spread = np.abs(ref["pred_pose"].numpy()[0] - ref["pred_pose"].numpy()[-1]).max()
+    print("W48-CLIFF bs=128 streaming, max-abs deviation vs the CPU oracle:", {k: "%.2e" % v for k, v in dev.items()},
+          "inter-crop spread of pose %.2e" % spread)
+    # crops differ from the numpy crop by <= 1 grey level on a few pixels (fp32 sample positions, test_crop_normalize_kernel)
+    assert max(dev.values()) < 1e-3, dev
+    assert spread > 1e-2
+
+
+def test_crop_stream_pipelined_batches_keep_their_own_boxes(tmp_path, cuda):
+    """two runs in flight with DIFFERENT boxes - the second run's host-side staging must not
+    overwrite the first run's boxes / bbox_info before its H2D copy has executed.  Also the ring guard."""
+    from poco_amd.stream import CropStream
+    t, _ = _tester(tmp_path)
+    r = np.random.default_rng(12)
+    frames = [r.integers(0, 256, (180, 240, 3), dtype=np.uint8) for _ in range(4)]
+    boxes_a = [np.array([[120, 90, 100, 100], [60, 70, 50, 80]], np.float32), np.array([[200, 50, 70, 60]], np.float32)]
+    boxes_b = [np.array([[40, 120, 60, 90]], np.float32), np.array([[150, 100, 150, 120], [30, 40, 40, 40]], np.float32)]
+    cs = CropStream(t.model, (180, 240), batch=5, ring=4)
+    # reference results, one run at a time
+    want = []
+    for fr, bx in ((frames[:2], boxes_a), (frames[2:], boxes_b)):
+        rec, n = cs.run([(cs.upload(f), b) for f, b in zip(fr, bx)], 0)
+        torch.cuda.synchronize()
+        want.append(rec.numpy()[:n].copy())
+    assert np.abs(want[0] - want[1]).max() > 1e-3
+    # now back to back without a host sync in between; a long-running kernel keeps the stream busy so that the second
+    # run()'s host code executes while the first run's H2D copy is still queued
+    big = torch.randn(8192, 8192, device=cuda)
+    for _ in range(3):
+        for _ in range(6):
+            big @ big
+        ra, na = cs.run([(cs.upload(f), b) for f, b in zip(frames[:2], boxes_a)], 0)
+        rb, nb = cs.run([(cs.upload(f), b) for f, b in zip(frames[2:], boxes_b)], 1)
+        torch.cuda.synchronize()
+        assert np.array_equal(ra.numpy()[:na], want[0]) and np.array_equal(rb.numpy()[:nb], want[1])
+    # ring guard: a third upload round without run() would overwrite unconsumed frames
+    cs2 = CropStream(t.model, (180, 240), batch=5, ring=2)
+    cs2.upload(frames[0]); cs2.upload(frames[1])
+    with pytest.raises(RuntimeError, match="ring"):
+        cs2.upload(frames[2])

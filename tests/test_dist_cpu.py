@@ -78,11 +78,11 @@ def test_shard_tracks_partition_and_balance():
         assert parts == [pdist.shard_tracks(tracks, r, world) for r in range(world)]   # deterministic
 
 
-def _track_worker(rank, world, port, q):
+def _track_worker(rank, world, port, q, lengths=(5, 2, 7, 1)):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    tracks = {f"p{i}": {"frames": list(range(n))} for i, n in enumerate([5, 2, 7, 1])}
+    tracks = {f"p{i}": {"frames": list(range(n))} for i, n in enumerate(lengths)}
     mine = pdist.shard_tracks(tracks, rank, world)
     rec = lambda k, t: torch.full((t, pdist.REC), float(int(k[1:]) + 1)) + torch.arange(t).view(t, 1)   # noqa: E731
     local = {k: rec(k, len(v["frames"])) for k, v in mine.items()}
@@ -93,13 +93,15 @@ def _track_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_two_rank_track_gather_gloo():
+@pytest.mark.parametrize("world,lengths", [(2, (5, 2, 7, 1)), (3, (4,)), (2, ())])
+def test_track_gather_gloo(world, lengths):
+    """Incl. more ranks than tracks (ranks 1, 2 own nothing: ADVICE r1) and no track at all."""
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_track_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_track_worker, args=(r, world, port, q, lengths)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=120) for _ in procs]

@@ -47,10 +47,31 @@ def test_strict_loading_errors():
         m.load_state_dict({"backbone.not_a_layer.weight": np.zeros((1,), np.float32)})
     with pytest.raises(_lib.PocoHipError, match="shape mismatch"):
         m.load_state_dict({"backbone.conv1.weight": np.zeros((64, 3, 3, 3), np.float32)})
+    # same element count, different arrangement (a transposed Linear weight): refused dimension by dimension
+    with pytest.raises(_lib.PocoHipError, match="shape mismatch"):
+        m.load_state_dict({"head.fc2.weight": np.zeros((1, 1024 * 1024), np.float32)})
+    with pytest.raises(_lib.PocoHipError, match="shape mismatch"):
+        m.load_state_dict({"head.decpose.weight": np.zeros((1024, 144), np.float32)})
+    m.load_state_dict({"head.init_pose": np.zeros((144,), np.float32)})          # [1,144] stored flat: size-1 dims are free
+    m.load_state_dict({"head.init_pose": np.zeros((1, 144), np.float32)})
     # finalize without weights: strict missing-key report (and no GPU needed to get there)
     with pytest.raises(_lib.PocoHipError, match="missing required tensors"):
         m._finalized = False
         _lib.check(m._L.poco_finalize(m._h), "poco_finalize")
+
+
+def test_state_dict_round_trip():
+    """the mirror class offers state_dict() under the reference's keys."""
+    from tests import util
+    variant = "resnet50-cliff"
+    w = util.synth_weights(variant)
+    m = POCO(backbone=variant, num_flow_layers=1, max_batch=1)
+    m.load_state_dict(w, strict=True)
+    sd = m.state_dict()
+    assert set(sd) == set(w) and all(np.array_equal(sd[k].numpy(), w[k]) for k in w)
+    m2 = POCO(backbone=variant, num_flow_layers=1, max_batch=1)
+    assert m2.load_state_dict(sd, strict=True) == []
+    assert list(sd)[:2] == [n for n, _, _ in m.expected_tensors() if n in w][:2]
 
 
 def test_forward_before_finalize_is_an_error():

@@ -1,0 +1,101 @@
+"""GPU box (1 device): the N>1 code paths run for real as separate processes - `bench.py --gpus N` and
+`demo.py --mode video --gpus N` start their own ranks; with `--backend gloo` the ranks share the one GPU, so everything
+except the RCCL transport itself (process group, sharding, packed-record gather, rank-0 merge) is exercised here.
+RCCL proper needs >= 2 GPUs: the driver's 8-GPU scaling run (`bench.py --gpus 8`, nccl) is that leg."""
+import json
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+from poco_amd import synth
+from tests import util
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _run(cmd, env=None, timeout=900):
+    e = dict(os.environ)
+    e.pop("WORLD_SIZE", None); e.pop("RANK", None); e.pop("LOCAL_RANK", None)
+    e.update(env or {})
+    return subprocess.run([sys.executable] + cmd, cwd=ROOT, env=e, capture_output=True, text=True, timeout=timeout)
+
+
+def _json_line(stdout):
+    lines = [ln for ln in stdout.splitlines() if ln.startswith("{")]
+    assert lines, stdout[-2000:]
+    return json.loads(lines[-1])
+
+
+def test_bench_gpus2_starts_two_ranks_and_gathers(cuda):
+    r = _run(["bench.py", "--gpus", "2", "--backend", "gloo", "--steps", "2", "--warmup", "1", "--variant", "resnet50-cliff",
+              "--batch", "8", "--check-gather", "--no-stream", "--no-cpu-baseline"])
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = _json_line(r.stdout)
+    assert line["n_gpus"] == 2 and line["dist"]["world_size"] == 2 and line["dist"]["backend"] == "gloo"
+    assert line["config"]["global_batch"] == 16 and line["scaling"] == "weak"
+    assert line["dist"]["gather_check"].startswith("ok"), line["dist"]
+    assert sum(ln.startswith("{") for ln in r.stdout.splitlines()) == 1          # ONE json line (rank 0 only)
+
+
+def test_bench_rccl_needs_one_gpu_per_rank(cuda):
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("box has >= 2 GPUs")
+    r = _run(["bench.py", "--gpus", "2", "--steps", "1", "--warmup", "0", "--no-stream", "--no-cpu-baseline"])
+    assert r.returncode != 0 and "GPU" in (r.stderr + r.stdout)
+    assert not any(ln.startswith("{") for ln in r.stdout.splitlines())            # no line pretending n_gpus = 2
+
+
+def test_bench_one_rank_under_a_launcher_equals_plain_run(cuda):
+    """`--gpus 1` with and without launcher environment: same code path, same number (within 2 %, one retry)."""
+    args = ["bench.py", "--gpus", "1", "--steps", "40", "--warmup", "10", "--variant", "resnet50-cliff", "--no-stream",
+            "--no-cpu-baseline", "--no-dominant"]
+    for attempt in range(2):
+        a = _json_line(_run(args).stdout)
+        b = _json_line(_run(args, env={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1",
+                                       "MASTER_PORT": "29555"}).stdout)
+        assert a["n_gpus"] == b["n_gpus"] == 1 and a["dist"]["world_size"] == 1
+        rel = abs(a["step_ms_events"]["median"] - b["step_ms_events"]["median"]) / a["step_ms_events"]["median"]
+        if rel < 0.02:
+            break
+    assert rel < 0.02, (a["step_ms_events"], b["step_ms_events"])
+
+
+def test_demo_video_two_ranks_matches_one_process(tmp_path, cuda):
+    """demo.py --mode video --gpus 2 (tracks sharded, records all-gathered, rank 0 re-derives the meshes of the other
+    rank's tracks with the LBS operator) writes the same poco_results.npz as the single-process run."""
+    from PIL import Image
+    variant = "resnet50-cliff"
+    w = util.synth_weights(variant, profile="stress")
+    torch.save({"state_dict": {"model." + k: torch.from_numpy(v) for k, v in w.items()}}, tmp_path / "ckpt.pt")
+    np.savez(tmp_path / "smpl.npz", **synth.synth_smpl(7))
+    fr = tmp_path / "frames"
+    fr.mkdir()
+    r = np.random.default_rng(4)
+    for i in range(6):
+        img = np.clip(128 + 60 * r.standard_normal((6, 8, 3)).repeat(40, 0).repeat(40, 1) + 20 * r.standard_normal((240, 320, 3)), 0, 255)
+        Image.fromarray(img.astype(np.uint8)).save(fr / f"{i:06d}.png")
+    tracks = {"0": {"bbox": [[160 + 3 * i, 120, 150, 150] for i in range(6)], "frames": list(range(6))},
+              "1": {"bbox": [[80, 100 + 2 * i, 90, 120] for i in range(4)], "frames": list(range(2, 6))},
+              "2": {"bbox": [[250, 60, 70, 70]], "frames": [3]}}
+    (tmp_path / "tracks.json").write_text(json.dumps(tracks))
+    base = ["demo.py", "--cfg", "configs/demo_poco_cliff_resnet50.yaml", "--ckpt", str(tmp_path / "ckpt.pt"), "--mode", "video",
+            "--vid_file", str(fr), "--batch_size", "4", "--smpl", str(tmp_path / "smpl.npz"), "--no_render", "--smooth",
+            "--tracking", str(tmp_path / "tracks.json")]
+    one = _run(base + ["--output_folder", str(tmp_path / "o1")])
+    assert one.returncode == 0, one.stderr[-3000:]
+    two = _run(base + ["--output_folder", str(tmp_path / "o2"), "--gpus", "2", "--dist_backend", "gloo"])
+    assert two.returncode == 0, two.stderr[-3000:]
+    assert _json_line(two.stdout)["ranks"] == 2
+    a = dict(np.load(tmp_path / "o1" / "frames_" / "poco_results.npz"))
+    b = dict(np.load(tmp_path / "o2" / "frames_" / "poco_results.npz"))
+    assert set(a) == set(b)
+    for k in a:
+        tol = 2e-2 if k.endswith("smpl_joints2d") else 1e-4            # 2-D joints in full-image pixels (values ~1e3)
+        assert a[k].shape == b[k].shape and np.abs(a[k].astype(np.float64) - b[k]).max() <= tol, (k, np.abs(a[k] - b[k]).max())
+    assert a["0/verts"].shape == (6, 6890, 3) and np.abs(a["0/pose"] - a["1/pose"][:1]).max() > 1e-2
