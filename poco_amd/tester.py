@@ -125,7 +125,8 @@ class POCOTester:
         return results
 
     @torch.no_grad()
-    def run_on_video(self, tracking_results: dict, frames, orig_width: int, orig_height: int, bbox_scale: float = 1.0):
+    def run_on_video(self, tracking_results: dict, frames, orig_width: int, orig_height: int, bbox_scale: float = 1.0,
+                     raw: bool = False):
         """Per-track results like pocolib/core/tester.py:362-479.
 
         tracking_results: {person_id: {'bbox': [T,4] (cx,cy,w,h), 'frames': [T] frame indices}} - what
@@ -135,7 +136,9 @@ class POCOTester:
         The reference walks person by person and re-reads every frame for every person
         (dataset/inference.py:72-135).  Here the stream is frame-major: a frame is decoded and uploaded once,
         all people visible in it are cropped on the GPU, crops of consecutive frames are packed into full
-        batches of `batch_size`, and the regressed rows are scattered back to the tracks."""
+        batches of `batch_size`, and the regressed rows are scattered back to the tracks.
+        raw=True: return the un-post-processed per-frame network outputs per track (multi-GPU merge, see
+        _merge_rank_results)."""
         get = frames if callable(frames) else (lambda i: frames[i])
         bs = self.model.max_batch
         # (frame, person, slot in that person's track), frame-major
@@ -175,29 +178,35 @@ class POCOTester:
             i = j
         flush()
 
-        results = {}
-        for pid, tr in tracking_results.items():
-            st = {k: np.stack(v) for k, v in store[pid].items()}
-            bboxes = np.asarray(tr["bbox"], np.float32).reshape(-1, 4)
-            pose, betas = st["pred_pose"], st["pred_shape"]
-            verts, j3d = st["smpl_vertices"], st["smpl_joints3d"]
-            if getattr(self.args, "smooth", False):               # tester.py:442-447
-                from .smooth import smooth_pose
-                verts, pose, j3d = smooth_pose(self.model, pose, betas, getattr(self.args, "min_cutoff", 0.004),
-                                               getattr(self.args, "beta", 1.5))
-            var, var_global = postproc.video_uncert(st["var_pose"], self.backbone,
-                                                    self.model_cfg.POCO.KINEMATIC_UNCERT)    # tester.py:416-419
-            results[pid] = {
-                "pred_cam": st["pred_cam"],
-                "orig_cam": postproc.convert_crop_cam_to_orig_img(st["pred_cam"], bboxes, orig_width, orig_height),
-                "verts": verts, "pose": pose, "betas": betas, "joints2d": None,
-                "smpl_joints3d": j3d,
-                "smpl_joints2d": postproc.convert_crop_coords_to_orig_img(bboxes, st["smpl_joints2d"],
-                                                                          self.model_cfg.DATASET.IMG_RES),
-                "var": var, "var_global": var_global,
-                "bboxes": bboxes, "frame_ids": np.asarray(tr["frames"]),
-            }
-        return results
+        stacked = {pid: {k: np.stack(v) for k, v in store[pid].items()} for pid in tracking_results}
+        if raw:
+            return stacked
+        return {pid: self._finish_track(tr, stacked[pid], orig_width, orig_height) for pid, tr in tracking_results.items()}
+
+    def _finish_track(self, tr: dict, st: Dict[str, np.ndarray], orig_width: int, orig_height: int) -> dict:
+        """Per-track post-processing of tester.py:416-479 on the raw per-frame network outputs `st` (keys: pred_cam,
+        smpl_vertices, pred_pose, pred_shape, smpl_joints3d, smpl_joints2d, var_pose): optional one-euro smoothing
+        (meshes / 3-D joints re-derived from the filtered pose; the 2-D joints stay those of the raw prediction, as in
+        the reference), uncertainty post-processing, camera / keypoint conversion to the original image."""
+        bboxes = np.asarray(tr["bbox"], np.float32).reshape(-1, 4)
+        pose, betas = st["pred_pose"], st["pred_shape"]
+        verts, j3d = st["smpl_vertices"], st["smpl_joints3d"]
+        if getattr(self.args, "smooth", False):               # tester.py:442-447
+            from .smooth import smooth_pose
+            verts, pose, j3d = smooth_pose(self.model, pose, betas, getattr(self.args, "min_cutoff", 0.004),
+                                           getattr(self.args, "beta", 1.5))
+        var, var_global = postproc.video_uncert(st["var_pose"], self.backbone,
+                                                self.model_cfg.POCO.KINEMATIC_UNCERT)    # tester.py:416-419
+        return {
+            "pred_cam": st["pred_cam"],
+            "orig_cam": postproc.convert_crop_cam_to_orig_img(st["pred_cam"], bboxes, orig_width, orig_height),
+            "verts": verts, "pose": pose, "betas": betas, "joints2d": None,
+            "smpl_joints3d": j3d,
+            "smpl_joints2d": postproc.convert_crop_coords_to_orig_img(bboxes, st["smpl_joints2d"],
+                                                                      self.model_cfg.DATASET.IMG_RES),
+            "var": var, "var_global": var_global,
+            "bboxes": bboxes, "frame_ids": np.asarray(tr["frames"]),
+        }
 
     def run_on_image_folder(self, image_folder: str, detections, output_path: str, bbox_scale=1.0):
         """pocolib/core/tester.py:153-245: images are streamed one at a time (decode -> regress -> write), every
@@ -265,8 +274,8 @@ def _run_on_video_folder(self, frame_folder: str, tracking_path: Optional[str], 
         # one all-gather of the packed per-frame SMPL records, everything else is re-derived from them
         from . import dist as pdist
         mine = pdist.shard_tracks(tracking, rank, world)
-        results = self.run_on_video(mine, load, W, H, bbox_scale) if mine else {}
-        results = self._merge_rank_results(results, tracking, W, H)
+        raw = self.run_on_video(mine, load, W, H, bbox_scale, raw=True) if mine else {}
+        results = self._merge_rank_results(raw, tracking, W, H)
     else:
         results = self.run_on_video(tracking, load, W, H, bbox_scale)
     torch.cuda.synchronize()
@@ -289,45 +298,40 @@ def _run_on_video_folder(self, frame_folder: str, tracking_path: Optional[str], 
             "fps": n_frames / max(dt, 1e-9), "crops_per_s": n_crops / max(dt, 1e-9)}
 
 
-def _merge_rank_results(self, local: dict, tracking: dict, W: int, H: int) -> dict:
-    """Multi-GPU video mode: every rank packs its tracks' per-frame records [pose 216 | betas 10 | cam 3 | var 24 |
-    var_global 1] (after smoothing / uncertainty post-processing), ONE all-gather (RCCL when the group's backend is
-    nccl) hands every rank every track, and the mesh-level entries of tracks regressed elsewhere are re-derived from the
-    gathered parameters with the batched LBS operator - 1 KB per crop crosses xGMI instead of 83 KB of vertices."""
+def _merge_rank_results(self, local_raw: dict, tracking: dict, W: int, H: int) -> dict:
+    """Multi-GPU video mode: every rank packs the RAW per-frame outputs of its tracks into records [pose 216 | betas 10 |
+    cam 3 | var_pose 24 | global confidence 1], ONE all-gather (RCCL when the group's backend is nccl) hands every rank
+    every track, and the mesh-level entries of tracks regressed elsewhere are re-derived from the gathered parameters
+    with the batched LBS operator - 1 KB per crop crosses xGMI instead of 83 KB of vertices.  Smoothing and the
+    uncertainty post-processing then run identically on every rank (_finish_track)."""
     from . import dist as pdist
     dev = pdist.collective_device()
     recs = {}
-    for pid, r in local.items():
-        T = len(r["frame_ids"])
-        rec = np.empty((T, pdist.REC), np.float32)
-        rec[:, 0:216] = r["pose"].reshape(T, 216)
-        rec[:, 216:226], rec[:, 226:229], rec[:, 229:253], rec[:, 253] = r["betas"], r["pred_cam"], r["var"], r["var_global"]
-        recs[str(pid)] = torch.from_numpy(rec).to(dev)
+    for pid, st in local_raw.items():
+        out = {k: torch.from_numpy(st[k]) for k in ("pred_pose", "pred_shape", "pred_cam", "var_pose")}
+        recs[str(pid)] = pdist.pack_records(out, head=self.backbone, kinematic=self.model_cfg.POCO.KINEMATIC_UNCERT).to(dev)
     full = pdist.gather_track_records(recs, device=dev)
     out = {}
     cliff = "cliff" in self.backbone
     res = self.model_cfg.DATASET.IMG_RES
     for pid, tr in tracking.items():
-        if pid in local:
-            out[pid] = local[pid]
-            continue
-        rec = full[str(pid)].cpu().numpy()
-        T = rec.shape[0]
-        pose, betas, cam = rec[:, 0:216].reshape(T, 24, 3, 3), rec[:, 216:226], rec[:, 226:229]
-        verts = np.empty((T, 6890, 3), np.float32)
-        j3d = np.empty((T, 49, 3), np.float32)
-        for lo in range(0, T, self.model.max_batch):
-            hi = min(T, lo + self.model.max_batch)
-            v, j = self.model.smpl_lbs(torch.from_numpy(np.ascontiguousarray(betas[lo:hi])).to(self.device),
-                                       torch.from_numpy(np.ascontiguousarray(pose[lo:hi])).to(self.device))
-            verts[lo:hi], j3d[lo:hi] = v.cpu().numpy(), j.cpu().numpy()
-        bboxes = np.asarray(tr["bbox"], np.float32).reshape(-1, 4)
-        j2d = postproc.joints2d_from_params(j3d, cam, bboxes, W, H, cliff, res)
-        out[pid] = {"pred_cam": cam, "orig_cam": postproc.convert_crop_cam_to_orig_img(cam, bboxes, W, H),
-                    "verts": verts, "pose": pose, "betas": betas, "joints2d": None, "smpl_joints3d": j3d,
-                    "smpl_joints2d": postproc.convert_crop_coords_to_orig_img(bboxes, j2d, res),
-                    "var": rec[:, 229:253], "var_global": rec[:, 253], "bboxes": bboxes,
-                    "frame_ids": np.asarray(tr["frames"])}
+        st = local_raw.get(pid)
+        if st is None:
+            rec = full[str(pid)].cpu().numpy()
+            T = rec.shape[0]
+            pose, betas, cam = rec[:, 0:216].reshape(T, 24, 3, 3), rec[:, 216:226], rec[:, 226:229]
+            verts = np.empty((T, 6890, 3), np.float32)
+            j3d = np.empty((T, 49, 3), np.float32)
+            for lo in range(0, T, self.model.max_batch):
+                hi = min(T, lo + self.model.max_batch)
+                v, j = self.model.smpl_lbs(torch.from_numpy(np.ascontiguousarray(betas[lo:hi])).to(self.device),
+                                           torch.from_numpy(np.ascontiguousarray(pose[lo:hi])).to(self.device))
+                verts[lo:hi], j3d[lo:hi] = v.cpu().numpy(), j.cpu().numpy()
+            bboxes = np.asarray(tr["bbox"], np.float32).reshape(-1, 4)
+            st = {"pred_cam": cam, "smpl_vertices": verts, "pred_pose": pose, "pred_shape": betas, "smpl_joints3d": j3d,
+                  "smpl_joints2d": postproc.joints2d_from_params(j3d, cam, bboxes, W, H, cliff, res),
+                  "var_pose": rec[:, 229:253]}
+        out[pid] = self._finish_track(tr, st, W, H)
     return out
 
 
