@@ -42,6 +42,8 @@ struct ConvCfg {
                // 5: small-M linear (H = W = 1, ks = 1): K split over WM waves per 16 outputs (linear_mfma.hip)
                // 7: Winograd F(4x4,3x3) for planes >= 28x28 (conv_wino4.hip): NT 1..3, WM = 2 tile
                //    groups, WN = 4 position quarters, R = output rows per slab (multiple of 4), NI slabs (<= 32 tiles)
+               // 8: ALG 7's arithmetic and geometry with specialised waves (conv_wino4p.hip): 8 MFMA waves + 4 producer
+               //    waves (LDS-DMA + input transform, V staged in LDS); same cfg fields as ALG 7
                // 6: 1x1 conv (stride 1|2) as a register-direct GEMM, no LDS / barriers (gemm1x1.hip):
                //    (MT,NT) in {(2,4),(4,2),(4,4),(7,2),(7,4),(8,2)}, R = operand prefetch depth (2|3), NI = 1
 };
@@ -63,6 +65,7 @@ struct ConvDesc {
   const float* wfrag;                     // weights in MFMA fragment order (see conv_pack_weights)
   const float* wfrag_wino;                // 3x3 stride-1 only: Winograd-transformed weights (ALG 3), nullable
   const float* wfrag_wino4 = nullptr;     // 3x3 stride-1 only: F(4x4,3x3) weight fragments, 36 positions (ALG 7), nullable
+  const float* wfrag_wino4p = nullptr;    // the same weights in the LDS order of ALG 8 (conv_wino4p.hip), nullable
   const float* bias;                      // [Cout_padded] folded BN shift / conv bias
   int B, H, W, Cin, Cout;                 // Cout = padded to a multiple of 16
   int ks, stride;                         // ks in {1,3}; pad = (ks-1)/2; stride in {1,2}
@@ -98,6 +101,12 @@ size_t conv_wino4_packed_floats(int Cin, int Cout16);
 void conv_wino4_pack_weights(const float* w_oihw, const float* scale, int Cout, int Cin, int Cout16, float* dst);
 size_t conv_wino4_lds_bytes(const ConvDesc& d, const ConvCfg& cfg);
 int conv_wino4_launch(const ConvDesc& d, const ConvCfg& cfg, hipStream_t stream);
+
+// ---- Winograd F(4x4,3x3) with specialised waves (conv_wino4p.hip), ALG 8 ---------------------
+size_t conv_wino4p_packed_floats(int Cin, int Cout16);
+void conv_wino4p_pack_weights(const float* w_oihw, const float* scale, int Cout, int Cin, int Cout16, float* dst);
+size_t conv_wino4p_lds_bytes(const ConvDesc& d, const ConvCfg& cfg);
+int conv_wino4p_launch(const ConvDesc& d, const ConvCfg& cfg, hipStream_t stream);
 
 // ---- Winograd F(2x2,3x3) variant (conv_wino.hip) --------------------------------------------------
 #include <vector>

@@ -28,7 +28,7 @@
 //     Z exchange / epilogue of the current one (no measurable gain yet: the epilogue's 16 stores per lane dominate the
 //     fixed cost).
 // State: correct and pipelined; no XCD-aware walk, epilogue not overlapped with the next item's compute.
-#include "conv_mfma_types.h"
+#include "conv_wino4_common.h"
 
 namespace {
 
@@ -46,21 +46,8 @@ struct W4Params {
   FastDiv dPW, dSlab, dBands, dTX, dTslab;
 };
 
-// row R of B^T applied to six values (input transform) [Lavin & Gray 2016]
-template <int R>
-__device__ __forceinline__ float bt_row(float a, float b, float c, float d, float e, float f) {
-  if constexpr (R == 0) return 4.f * a - 5.f * c + e;
-  else if constexpr (R == 1) return -4.f * (b + c) + d + e;
-  else if constexpr (R == 2) return 4.f * (b - c) - d + e;
-  else if constexpr (R == 3) return 2.f * (d - b) - c + e;
-  else if constexpr (R == 4) return 2.f * (b - d) - c + e;
-  else return 4.f * b - 5.f * d + f;
-}
-// A^T[i][k] (output transform)
-__host__ __device__ constexpr float at_c(int i, int k) {
-  constexpr float A[4][6] = {{1, 1, 1, 1, 1, 0}, {0, 1, -1, 2, -2, 0}, {0, 1, 1, 4, 4, 0}, {0, 1, -1, 8, -8, 1}};
-  return A[i][k];
-}
+using w4::at_c;
+using w4::bt_row;
 
 #ifndef W4_EXP
 #define W4_EXP 0      // timing probes (tools/build_exp.sh conv_wino4.hip W4_EXP n): 1 no window reads/transform, 2 no U reads,
@@ -69,14 +56,7 @@ constexpr int W4_MAXP = 2;      // 64-position patch pieces per wave (npos <= 2 
 
 __device__ float4 g_zero_page_w4[1];   // 16 B of zeros: source of the padding lanes
 
-__device__ __forceinline__ void w4_dma16(const void* gsrc, unsigned lds_dst) {
-  unsigned keep;
-  asm volatile(
-      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-      : "=&s"(keep)
-      : "v"(gsrc), "s"(lds_dst)
-      : "memory");
-}
+__device__ __forceinline__ void w4_dma16(const void* gsrc, unsigned lds_dst) { w4::dma16(gsrc, lds_dst); }
 
 template <int NT, int Q>
 __device__ __forceinline__ void wino4_wave(const W4Params& p, float4* smem, int grp, int lane, int wave) {
@@ -359,26 +339,11 @@ bool w4geo(const ConvDesc& d, const ConvCfg& cfg, W4Geo* g) {
 
 }  // namespace
 
-// U = G g G^T per (co, ci), float64 on the host -> [36][Cout][Cin]
-static void wino4_u(const float* w_oihw, int Cout, int Cin, std::vector<double>* u) {
-  static const double G[6][3] = {{1.0 / 4, 0, 0}, {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
-                                 {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0, 0, 1}};
-  u->assign((size_t)36 * Cout * Cin, 0.0);
-  for (size_t oc = 0; oc < (size_t)Cout * Cin; ++oc) {
-    const float* gk = w_oihw + oc * 9;
-    double t[6][3];
-    for (int i = 0; i < 6; ++i)
-      for (int j = 0; j < 3; ++j) t[i][j] = G[i][0] * gk[0 * 3 + j] + G[i][1] * gk[1 * 3 + j] + G[i][2] * gk[2 * 3 + j];
-    for (int i = 0; i < 6; ++i)
-      for (int j = 0; j < 6; ++j) (*u)[(size_t)(i * 6 + j) * Cout * Cin + oc] = t[i][0] * G[j][0] + t[i][1] * G[j][1] + t[i][2] * G[j][2];
-  }
-}
-
 // packed fragments for ALG 7: [Cin/4][9 quads][Cout16/16][64 lanes][4]; lane = g*16 + co_l, value j = U[4 quad + j][co][4 c4 + g] * scale[co]
 size_t conv_wino4_packed_floats(int Cin, int Cout16) { return (size_t)36 * Cin * Cout16; }
 void conv_wino4_pack_weights(const float* w_oihw, const float* scale, int Cout, int Cin, int Cout16, float* dst) {
   std::vector<double> u;
-  wino4_u(w_oihw, Cout, Cin, &u);
+  w4::u_transform(w_oihw, Cout, Cin, &u);
   const int nC4 = Cin / 4, nT16 = Cout16 / 16;
   for (int c4 = 0; c4 < nC4; ++c4)
     for (int quad = 0; quad < 9; ++quad)

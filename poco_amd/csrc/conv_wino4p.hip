@@ -1,0 +1,606 @@
+// ALG 8: Winograd F(4x4,3x3) on the fp32 MFMA with SPECIALISED WAVES (3x3 stride-1 convs on planes >= 28x28;
+// pocolib/models/backbone/hrnet.py:42-58, hrnet_cls.py BasicBlock convs).
+//
+// Same arithmetic and block geometry as ALG 7 (conv_wino4.hip): 36 position GEMMs M_p[co][tile] += U_p[co][ci] V_p[ci][tile]
+// per 4x4 output tile, K walked in slices of four input channels = one v_mfma_f32_16x16x4_f32 per (position, n-tile), a
+// block owns two groups of 16 tiles, a wave the 9 positions 9q..9q+8 of one group.  What differs is WHO does what.
+//
+// ALG 7 lets every wave read its tiles' 6x6 windows, transform them and then issue its MFMAs; its K loop is a serial
+// chain per wave and slice (ISA: ~28 ds_read_b32 -> s_waitcnt lgkmcnt(0) -> ~90 VALU -> 27 MFMAs with nine more
+// lgkmcnt(0) stalls for the U fragments in between), the two waves of a SIMD run that chain in lockstep, and the MFMA
+// pipe is busy 45 % of the loop (14 us per 16 channels against a 5.9 us MFMA floor).
+//
+// Here a block is 12 waves:
+//   * waves 0-7, the MFMA waves (q = wave & 3, group = wave >> 2): per slice they read 3 + 3 NT operand vectors
+//     (V and U, both stored in LDS in exactly the lane order of the MFMA B / A operands: two float4 quads + one float
+//     per wave and n-tile) and issue 9 NT MFMAs.  No window reads, no transform, no vector-memory instruction, no
+//     address arithmetic: ~50 instructions per 27 MFMAs instead of ~190.
+//   * waves 8-11, the producers (group = (wave-8) >> 1, transform rows 3h..3h+2 for h = (wave-8) & 1): they stream the
+//     raw patch and the U fragments of the coming slices into LDS rings with LDS-DMA (global_load_lds_dwordx4), and
+//     compute V = B^T d B of the NEXT slice for their group ONCE (a lane = one (tile, channel) pair: 36 window reads,
+//     18 + 18 row transforms, 4 ds_write_b128 + 2 ds_write_b32) while the MFMA waves work on the current one.  Their
+//     VALU / LDS / VMEM instructions issue in the slots the MFMA pipe leaves free on their SIMD (one MFMA occupies the
+//     pipe for 8 issue slots).  In ALG 7 the four waves of a group each read the whole window (144 reads per pair).
+//   * one s_barrier per slice hands V(s+1), U(s+1) and raw(s+2) over; raw ring 3 deep (LDS-DMA issued four slices ahead,
+//     waited for with a counted s_waitcnt vmcnt(n) by the wave that issued it), U and V double-buffered.
+//   * end of item: as ALG 7 - the MFMA waves exchange Z = M A through LDS one n-tile at a time and every wave finishes
+//     one output row of the 4x4 blocks (bias, residual, ReLU, 16-byte stores); the exchange area overlays ring slots
+//     that are dead by then.  The producers fetch the next item's first slices in the meantime.
+//
+// Weights: U = G g G^T in float64 on the host (BN scale folded), packed per (4-channel slice, n-tile) as one 9 KiB block
+// in LDS order: [q = 0..3][2 quads][64 lanes] float4 (positions 9q..9q+7), then [q][64 lanes] float (position 9q+8);
+// lane = (co & 15) + 16 (ci & 3).  One block = nine 1 KiB LDS-DMA pieces.
+#include "conv_wino4_common.h"
+
+namespace {
+
+using w4::at_c;
+using w4::bt_row;
+
+struct W4PParams {
+  const float* in;
+  const float* res;
+  float* out;
+  const float4* ufrag;   // [Cin/4][Cout16/16][9][64] float4 (see above)
+  const float* bias;
+  int B, H, W, nC4, nT16;
+  int in_rs, in_ss, res_rs, out_rs, out_ss;
+  int R, NI, S, nbands, TX, PR, PW, npos, rawF4, tiles_per_slab;
+  int nblocks_m, nb_n;   // work items walked by the persistent blocks: slab groups x n-tile groups
+  int act, res_after_act;
+  int uoff, voff, xoff;  // float4 offsets of the U ring, the V double buffer and the exchange area in LDS (raw ring at 0)
+  FastDiv dPW, dSlab, dBands, dTX, dTslab;
+};
+
+#ifndef W4P_EXP
+#define W4P_EXP 0     // timing probes (tools/build_exp.sh conv_wino4p.hip W4P_EXP n; results are then garbage): 1 producers skip the
+#endif                // transform, 2 no LDS-DMA inside the K loop, 4 MFMA waves skip the MFMAs, 8 ... skip their operand reads,
+                      // 16 no per-slice barrier work at all in the producers (neither DMA nor transform)
+#ifndef W4P_TRACE
+#define W4P_TRACE 0   // 1: block 0 accumulates s_memtime phase sums of MFMA wave 0 and producer wave 8 (tools/w4p_trace.py)
+#endif
+#if W4P_TRACE
+__device__ unsigned long long g_w4p_trace[64];
+#define W4P_T(var) const unsigned long long var = __builtin_readcyclecounter()
+#define W4P_ACC(slot, a, b) do { if (trace) tr[slot] += (b) - (a); } while (0)
+#else
+#define W4P_T(var)
+#define W4P_ACC(slot, a, b)
+#endif
+constexpr int W4P_NCONS = 8, W4P_NPROD = 4;
+constexpr int W4P_MAXP = 2;          // raw-patch DMA pieces per MFMA wave (npos slots <= 8 * 2 * 64)
+constexpr int W4P_UBLK = 9 * 64;     // float4 per (slice, n-tile) block of U; V of one group has the same shape
+constexpr int W4P_XCH = 8 * 2 * 4 * 64;   // float4 of the Z exchange area (64 KiB)
+
+__device__ float4 g_zero_page_w4p[1];   // 16 B of zeros: source of the padding lanes
+
+__device__ __forceinline__ void wait_vm(int n) {     // s_waitcnt vmcnt(n), n wave-uniform
+  switch (n) {
+    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+    case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+    case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+    case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+    case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+    case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+    case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+  }
+}
+
+// the persistent, XCD-aware walk over work items shared by both roles: workgroup b runs on XCD b % 8 (round-robin
+// dispatch), so XCD x owns the contiguous item range [x*per, (x+1)*per): neighbouring row bands meet in one L2
+struct Walk { int first, step, end; };
+__device__ __forceinline__ Walk item_walk(const W4PParams& p) {
+  const int nitems = p.nblocks_m * p.nb_n;
+  Walk w{(int)blockIdx.x, (int)gridDim.x, nitems};
+  if ((gridDim.x & 7) == 0 && nitems >= (int)gridDim.x) {
+    const int per = (nitems + 7) >> 3;
+    w.first = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    w.step = gridDim.x >> 3;
+    w.end = min(nitems, ((int)(blockIdx.x & 7) + 1) * per);
+  }
+  return w;
+}
+
+// tile of lane idx (0..15) in group grp of an item: validity, window top-left in the patch, output coordinates
+struct Tile { bool valid; int base, b, oy0, tx; };
+__device__ __forceinline__ Tile tile_of(const W4PParams& p, int item, int grp, int idx) {
+  const int s0 = (item % p.nblocks_m) * p.NI;
+  const uint32_t tidx = (uint32_t)(grp * 16 + idx);
+  const uint32_t sl = fdiv(tidx, p.dTslab);
+  const uint32_t rem = tidx - sl * (uint32_t)p.tiles_per_slab;
+  const uint32_t tyl = fdiv(rem, p.dTX);
+  Tile t;
+  t.tx = (int)(rem - tyl * (uint32_t)p.TX);
+  const uint32_t s = (uint32_t)s0 + sl;
+  t.b = (int)fdiv(s, p.dBands);
+  const int band = (int)(s - (uint32_t)t.b * (uint32_t)p.nbands);
+  t.oy0 = band * p.R + 4 * (int)tyl;
+  t.valid = sl < (uint32_t)p.NI && s < (uint32_t)p.S && t.oy0 < p.H;
+  t.base = t.valid ? (int)((sl * (uint32_t)p.PR + 4 * tyl) * (uint32_t)p.PW) + 4 * t.tx : 0;
+  return t;
+}
+
+__device__ __forceinline__ float f4c(const float4& v, int j) { return j == 0 ? v.x : j == 1 ? v.y : j == 2 ? v.z : v.w; }
+
+
+// ---- staging (LDS-DMA) shared by whoever issues it: `nw` waves take pieces w, w + nw, ... -------------------------------
+// global float offsets of this wave's raw-patch pieces (lane = slot inside the piece), -1 = padding / beyond the patch
+template <int MAXP>
+__device__ __forceinline__ void raw_piece_offsets(const W4PParams& p, int item, int w, int nw, int lane, int* goff) {
+  const int s0g = (item % p.nblocks_m) * p.NI;
+#pragma unroll
+  for (int k = 0; k < MAXP; ++k) {
+    goff[k] = -1;
+    const uint32_t slot = (uint32_t)((w + nw * k) * 64 + lane);
+    const uint32_t k9 = __umulhi(slot, 477218589u);                  // slot / 9 (exact for slot < 2^16)
+    const uint32_t r9 = slot - 9 * k9;
+    const uint32_t pos = 8 * k9 + r9;
+    if (r9 < 8 && pos < (uint32_t)p.npos) {
+      const uint32_t psl = fdiv(pos, p.dSlab);
+      const uint32_t prem = pos - psl * (uint32_t)(p.PR * p.PW);
+      const uint32_t prow = fdiv(prem, p.dPW);
+      const int pcol = (int)(prem - prow * (uint32_t)p.PW);
+      const uint32_t ps = (uint32_t)s0g + psl;
+      const uint32_t pb = fdiv(ps, p.dBands);
+      const int pband = (int)(ps - pb * (uint32_t)p.nbands);
+      const int iy = pband * p.R - 1 + (int)prow, ix = pcol - 1;
+      if (ps < (uint32_t)p.S && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
+        goff[k] = (int)((pb * (uint32_t)p.H + (uint32_t)iy) * (uint32_t)p.in_rs) + ix * 16;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// MFMA waves (they also issue the LDS-DMA of the coming slices in the shadow of their MFMAs: a wave that is stuck behind a
+// busy MFMA pipe issues vector-memory instructions for free, while a producer wave needs ~60 clk per such instruction)
+// ---------------------------------------------------------------------------------------------------------------------
+template <int NT, int Q>
+__device__ __forceinline__ void w4p_consumer(const W4PParams& p, float4* smem, int grp, int lane, int wave) {
+  constexpr int P0 = 9 * Q;                 // first position of this wave
+  constexpr int RA = P0 / 6;                // its two position rows: RA (from column P0 % 6 on) and RA + 1
+  const int idx = lane & 15, g = lane >> 4;
+  const int uF4 = NT * W4P_UBLK;
+  const int rawF4 = p.rawF4;
+  const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) float4*)smem;
+  const int npieces_raw = rawF4 >> 6;
+  const Walk wk = item_walk(p);
+  for (int item = wk.first; item < wk.end; item += wk.step) {
+    const int nt0 = (item / p.nblocks_m) * NT;
+    const Tile tl = tile_of(p, item, grp, idx);
+    // ---- staging duties of this wave: raw pieces wave, wave + 8 and U pieces wave, wave + 8, ... ------------------------------
+    int goff[W4P_MAXP];
+    raw_piece_offsets<W4P_MAXP>(p, item, wave, W4P_NCONS, lane, goff);
+    bool live[W4P_MAXP];                                    // pieces with at least one in-image position (wave-uniform)
+#pragma unroll
+    for (int k = 0; k < W4P_MAXP; ++k) live[k] = __ballot(goff[k] >= 0) != 0ull;
+    // (padding lanes of a piece are switched off in the DMA: the producers zeroed those slots for the whole item, so the source
+    // is ONE wave-uniform base + a 32-bit lane offset - no 64-bit VALU address arithmetic, no per-lane source select)
+    auto issue_raw = [&](int c4, int slot) __attribute__((always_inline)) -> int {   // 4-channel slice c4 of the patch -> raw ring slot
+      int cnt = 0;
+      const float* sbase = p.in + (size_t)(c4 >> 2) * p.in_ss + (c4 & 3) * 4;
+      const unsigned sb = lds_base + (unsigned)(slot * rawF4) * 16u;
+#pragma unroll
+      for (int k = 0; k < W4P_MAXP; ++k) {
+        const int piece = wave + W4P_NCONS * k;
+        if (piece < npieces_raw && live[k]) {
+          if (goff[k] >= 0)
+            w4::dma16_sv(sbase, (unsigned)goff[k] * 4u, (unsigned)__builtin_amdgcn_readfirstlane((int)(sb + (unsigned)piece * 1024u)));
+          ++cnt;
+        }
+      }
+      return cnt;
+    };
+    auto issue_u = [&](int c4, int slot) __attribute__((always_inline)) -> int {     // U of slice c4, n-tiles nt0.. -> U ring slot
+      int cnt = 0;
+      const unsigned sb = lds_base + (unsigned)(p.uoff + slot * uF4) * 16u;
+#pragma unroll
+      for (int i0 = 0; i0 < 9 * NT; i0 += W4P_NCONS) {
+        const int i = i0 + wave;
+        if (i < 9 * NT) {
+          const int n = i / 9, j = i - n * 9;
+          const float4* src = p.ufrag + (((size_t)c4 * p.nT16 + min(nt0 + n, p.nT16 - 1)) * 9 + j) * 64;
+          w4::dma16_sv(src, (unsigned)lane * 16u, (unsigned)__builtin_amdgcn_readfirstlane((int)(sb + (unsigned)i * 1024u)));
+          ++cnt;
+        }
+      }
+      return cnt;
+    };
+    const int S = p.nC4;
+    f32x4 acc[9][NT];
+#pragma unroll
+    for (int i = 0; i < 9; ++i)
+#pragma unroll
+      for (int n = 0; n < NT; ++n) acc[i][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+#if W4P_TRACE
+    const bool trace = blockIdx.x == 0 && wave == 0 && item == wk.first;
+    unsigned long long tr[4] = {0, 0, 0, 0};
+#endif
+    W4P_T(c_a);
+    // (the producers fetched raw(0..2), U(0) during the previous item's exchange rounds and U(1) just now)
+    __syncthreads();                                        // B0: the first fetches have landed (and the padding slots are zero)
+    __syncthreads();                                        // B1: V(0) is written; the windows of slices 0 and 1 are in the producers' registers
+    if (S > 3) issue_raw(3, 0);
+    W4P_T(c_b);
+    W4P_ACC(0, c_a, c_b);
+    int ring = 0;                                           // s % 3
+    for (int s = 0; s < S; ++s) {
+      W4P_T(c0);
+      const int r1 = ring == 2 ? 0 : ring + 1, r2 = r1 == 2 ? 0 : r1 + 1;
+      int nvm = 0;
+      if (s + 2 < S && !(W4P_EXP & 2)) nvm += issue_u(s + 2, r2);           // slot of U(s-1): consumed before the barrier that ended iteration s-1
+      if (s + 4 < S && !(W4P_EXP & 2)) nvm += issue_raw(s + 4, r1);         // slot of raw(s+1): its window was read during iteration s-1
+      const float4* U = smem + p.uoff + ring * uF4 + (2 * Q) * 64 + lane;
+      const float4* V = smem + p.voff + (s & 1) * (2 * W4P_UBLK) + grp * W4P_UBLK + (2 * Q) * 64 + lane;
+      const bool noread = (W4P_EXP & 8) != 0;
+      const float4 vq0 = noread ? make_float4(1.f, 2.f, 3.f, (float)s) : V[0], vq1 = noread ? make_float4(1.f, 2.f, 3.f, 4.f) : V[64];
+      const float vs = noread ? 2.f : reinterpret_cast<const float*>(V - (2 * Q) * 64 - lane + 512)[Q * 64 + lane];
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {                        // U of one n-tile at a time: 9 operand registers live, not 27
+        const float4 uq0 = noread ? make_float4(1.f, 2.f + n, 3.f, (float)s) : U[n * W4P_UBLK];
+        const float4 uq1 = noread ? make_float4(1.f, 2.f, 3.f + n, 4.f) : U[n * W4P_UBLK + 64];
+        const float us = noread ? 3.f : reinterpret_cast<const float*>(U - (2 * Q) * 64 - lane + n * W4P_UBLK + 512)[Q * 64 + lane];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+          const float a = i < 4 ? f4c(uq0, i) : i < 8 ? f4c(uq1, i - 4) : us;
+          const float v = i < 4 ? f4c(vq0, i) : i < 8 ? f4c(vq1, i - 4) : vs;
+          if (W4P_EXP & 4) acc[i][n][0] += a * v;
+          else acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, v, acc[i][n], 0, 0, 0);
+        }
+      }
+      wait_vm(nvm);                                         // what this wave issued BEFORE this iteration has landed: U(s+1), raw(s+3)
+      ring = r1;
+      W4P_T(c1);
+      __syncthreads();                                      // everybody is done with slice s; V(s+1), U(s+1), raw(s+2) are in place
+      W4P_T(c2);
+      W4P_ACC(1, c0, c1); W4P_ACC(2, c1, c2);
+    }
+    W4P_T(c_e0);
+
+    // ---- Z = M A (partial over this wave's columns), exchanged one n-tile at a time; wave Q finishes output column Q --------
+    // exchange area [8 waves][2 rows][4 cols][64] float4 (64 KiB) over ring slots that are dead now
+    const int oyb = tl.oy0, oxb = 4 * tl.tx;
+    float4* xch = smem + p.xoff;
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      __syncthreads();                                      // previous round's reads finished everywhere
+#pragma unroll
+      for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          f32x4 z = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int i = 0; i < 9; ++i) {
+            const int pos = P0 + i, xi = pos / 6, nu = pos - xi * 6;
+            if (xi - RA == r && at_c(j, nu) != 0.f) z += at_c(j, nu) * acc[i][n];
+          }
+          xch[((wave * 2 + r) * 4 + j) * 64 + lane] = make_float4(z[0], z[1], z[2], z[3]);
+        }
+      __syncthreads();
+      if (nt0 + n < p.nT16) {
+        // Every wave finishes one output COLUMN j = Q of the 4x4 blocks: Y[i][Q] = sum_k A^T[i][k] Z[k][Q] needs the six rows of Z
+        // for that one column only = 8 exchange reads (rows 1 and 4 are split between two waves) instead of the 32 an output
+        // row would need (the exchange rounds are LDS-bandwidth-bound: 8 KiB written + 8 KiB read per wave and round).
+        // rows of Z: 0 = q0.r0 | 1 = q0.r1 + q1.r0 | 2 = q1.r1 | 3 = q2.r0 | 4 = q2.r1 + q3.r0 | 5 = q3.r1
+        const int w0 = grp * 4;
+        constexpr int j = Q;
+        auto ld = [&](int q, int r) {
+          const float4 z = xch[(((w0 + q) * 2 + r) * 4 + j) * 64 + lane];
+          return (f32x4){z.x, z.y, z.z, z.w};
+        };
+        f32x4 zr[6];
+        zr[0] = ld(0, 0); zr[1] = ld(0, 1) + ld(1, 0); zr[2] = ld(1, 1);
+        zr[3] = ld(2, 0); zr[4] = ld(2, 1) + ld(3, 0); zr[5] = ld(3, 1);
+        const float4 sh = *reinterpret_cast<const float4*>(p.bias + (nt0 + n) * 16 + g * 4);
+        const float lo = p.act == 1 ? 0.f : -INFINITY;        // ReLU as a clamp: no branch in the store loop
+        const bool has_res = p.res != nullptr;
+        const int ox = oxb + j;
+        const int xo = min(ox, p.W - 1) * 16;
+        const bool okx = tl.valid && ox < p.W;
+        size_t ooff[4];
+        float4 rr[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {                         // per-row output offsets (clamped: dead pixels compute harmlessly, masked at the store)
+          const size_t orow = (size_t)tl.b * p.H + min(oyb + i, p.H - 1);
+          ooff[i] = orow * p.out_rs + (size_t)(nt0 + n) * p.out_ss + g * 4 + xo;
+          rr[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (has_res) rr[i] = *reinterpret_cast<const float4*>(p.res + orow * p.res_rs + (size_t)(nt0 + n) * p.out_ss + g * 4 + xo);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          f32x4 v = (f32x4){sh.x, sh.y, sh.z, sh.w};
+#pragma unroll
+          for (int k = 0; k < 6; ++k)
+            if (at_c(i, k) != 0.f) v += at_c(i, k) * zr[k];
+          const float4 r = rr[i];
+          if (!p.res_after_act) { v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w; }
+          v[0] = fmaxf(v[0], lo); v[1] = fmaxf(v[1], lo); v[2] = fmaxf(v[2], lo); v[3] = fmaxf(v[3], lo);
+          if (p.res_after_act) { v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w; }
+          if (okx && oyb + i < p.H) *reinterpret_cast<float4*>(p.out + ooff[i]) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+      }
+    }
+    __syncthreads();                                        // the exchange area is free again (next item's rings / V)
+#if W4P_TRACE
+    W4P_T(c_e1);
+    W4P_ACC(3, c_e0, c_e1);
+    if (trace && lane == 0) { for (int k = 0; k < 4; ++k) g_w4p_trace[k] = tr[k]; g_w4p_trace[4] = (unsigned long long)p.nC4; }
+#endif
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// producer waves: LDS-DMA of the raw patch + U fragments, input transform V = B^T d B for rows 3 RH .. 3 RH + 2
+// ---------------------------------------------------------------------------------------------------------------------
+template <int NT, int RH>
+__device__ __forceinline__ void w4p_producer(const W4PParams& p, float4* smem, int pw, int lane) {
+  const int grp = pw >> 1;
+  const int idx = lane & 15, g = lane >> 4;
+  const int rawF4 = p.rawF4;
+  const int uF4 = NT * W4P_UBLK;
+  const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) float4*)smem;
+  const int npieces_raw = rawF4 >> 6;
+  const Walk wk = item_walk(p);
+  // First fetches of an item: raw(0..2) and U(0) (U(1) follows once the exchange area, which overlays its slot, is free).
+  // The producers issue them for the NEXT item while the MFMA waves run the exchange rounds of the current one, and zero
+  // the padding positions of the item's patch in all ring slots (every later DMA into the ring skips those lanes).
+  auto prefetch_item = [&](int item) __attribute__((always_inline)) {
+    constexpr int MAXP = 4;                                 // raw pieces pw, pw + 4, ... (rawF4 <= 1024 slots)
+    int goff[MAXP];
+    raw_piece_offsets<MAXP>(p, item, pw, W4P_NPROD, lane, goff);
+    const int nt0 = (item / p.nblocks_m) * NT;
+#pragma unroll
+    for (int k = 0; k < MAXP; ++k) {
+      const int piece = pw + W4P_NPROD * k;
+      if (piece < npieces_raw) {
+        if (goff[k] < 0) {
+#pragma unroll
+          for (int slot = 0; slot < 3; ++slot) smem[slot * rawF4 + piece * 64 + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
+        } else {
+#pragma unroll
+          for (int c4 = 0; c4 < 3; ++c4)
+            if (c4 < p.nC4)
+              w4::dma16_sv(p.in + (size_t)(c4 >> 2) * p.in_ss + (c4 & 3) * 4, (unsigned)goff[k] * 4u,
+                           (unsigned)__builtin_amdgcn_readfirstlane((int)(lds_base + (unsigned)(c4 * rawF4 + piece * 64) * 16u)));
+        }
+      }
+    }
+#pragma unroll
+    for (int i0 = 0; i0 < 9 * NT; i0 += W4P_NPROD) {
+      const int i = i0 + pw;
+      if (i < 9 * NT) {
+        const int n = i / 9, j = i - n * 9;
+        const float4* src = p.ufrag + (((size_t)0 * p.nT16 + min(nt0 + n, p.nT16 - 1)) * 9 + j) * 64;
+        w4::dma16_sv(src, (unsigned)lane * 16u, (unsigned)__builtin_amdgcn_readfirstlane((int)(lds_base + (unsigned)(p.uoff + i * 64) * 16u)));
+      }
+    }
+  };
+  auto issue_u1 = [&](int item) __attribute__((always_inline)) {       // U(1) -> ring slot 1
+    const int nt0 = (item / p.nblocks_m) * NT;
+#pragma unroll
+    for (int i0 = 0; i0 < 9 * NT; i0 += W4P_NPROD) {
+      const int i = i0 + pw;
+      if (i < 9 * NT) {
+        const int n = i / 9, j = i - n * 9;
+        const float4* src = p.ufrag + (((size_t)1 * p.nT16 + min(nt0 + n, p.nT16 - 1)) * 9 + j) * 64;
+        w4::dma16_sv(src, (unsigned)lane * 16u, (unsigned)__builtin_amdgcn_readfirstlane((int)(lds_base + (unsigned)(p.uoff + uF4 + i * 64) * 16u)));
+      }
+    }
+  };
+  if (wk.first < wk.end) prefetch_item(wk.first);
+  // fp32 MFMAs run on the SIMD's vector ALUs: the two MFMA waves of this SIMD always have one ready and would starve this
+  // wave's VALU / LDS / VMEM instructions until they reach the slice barrier (measured: MFMA time + producer time add up).
+  // With a higher issue priority the producer's instructions slot in between their MFMAs and its stalls cost nothing.
+  if (!(W4P_EXP & 32)) __builtin_amdgcn_s_setprio(3);
+
+  for (int item = wk.first; item < wk.end; item += wk.step) {
+    const int nt0 = (item / p.nblocks_m) * NT;
+    // ---- this lane's (tile, channel) pair: float offsets of its 36 window elements in a raw slot -----------------------
+    const Tile tl = tile_of(p, item, grp, idx);
+    int woff[6][6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k)
+#pragma unroll
+      for (int sc = 0; sc < 6; ++sc) {
+        const int pos = tl.base + k * p.PW + sc;
+        woff[k][sc] = (pos + (pos >> 3)) * 4 + g;
+      }
+    float d[6][6];                                            // the window of the slice that is transformed next
+    auto load_window = [&](int rslot) {
+      const float* rawf = reinterpret_cast<const float*>(smem + rslot * rawF4);
+#pragma unroll
+      for (int k = 0; k < 6; ++k)
+#pragma unroll
+        for (int sc = 0; sc < 6; ++sc) d[k][sc] = rawf[woff[k][sc]];
+    };
+    auto transform = [&](int vbuf) {                          // d -> rows 3 RH .. 3 RH + 2 of V (18 positions) of group grp
+      float t[3][6];
+#pragma unroll
+      for (int sc = 0; sc < 6; ++sc) {
+        t[0][sc] = bt_row<3 * RH + 0>(d[0][sc], d[1][sc], d[2][sc], d[3][sc], d[4][sc], d[5][sc]);
+        t[1][sc] = bt_row<3 * RH + 1>(d[0][sc], d[1][sc], d[2][sc], d[3][sc], d[4][sc], d[5][sc]);
+        t[2][sc] = bt_row<3 * RH + 2>(d[0][sc], d[1][sc], d[2][sc], d[3][sc], d[4][sc], d[5][sc]);
+      }
+      float v[18];                                           // position 18 RH + j, j = 6 r + nu
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        const float* tr = t[r];
+        v[6 * r + 0] = bt_row<0>(tr[0], tr[1], tr[2], tr[3], tr[4], tr[5]);
+        v[6 * r + 1] = bt_row<1>(tr[0], tr[1], tr[2], tr[3], tr[4], tr[5]);
+        v[6 * r + 2] = bt_row<2>(tr[0], tr[1], tr[2], tr[3], tr[4], tr[5]);
+        v[6 * r + 3] = bt_row<3>(tr[0], tr[1], tr[2], tr[3], tr[4], tr[5]);
+        v[6 * r + 4] = bt_row<4>(tr[0], tr[1], tr[2], tr[3], tr[4], tr[5]);
+        v[6 * r + 5] = bt_row<5>(tr[0], tr[1], tr[2], tr[3], tr[4], tr[5]);
+      }
+      // positions 18 RH .. 18 RH + 17 = the 9-position sets of MFMA waves q = 2 RH and 2 RH + 1 (two quads + one single each)
+      float4* Vg = smem + p.voff + vbuf * (2 * W4P_UBLK) + grp * W4P_UBLK;
+      float* Vs = reinterpret_cast<float*>(Vg + 512);
+#pragma unroll
+      for (int ql = 0; ql < 2; ++ql) {
+        const int q = 2 * RH + ql;
+        Vg[(2 * q) * 64 + lane] = make_float4(v[9 * ql + 0], v[9 * ql + 1], v[9 * ql + 2], v[9 * ql + 3]);
+        Vg[(2 * q + 1) * 64 + lane] = make_float4(v[9 * ql + 4], v[9 * ql + 5], v[9 * ql + 6], v[9 * ql + 7]);
+        Vs[q * 64 + lane] = v[9 * ql + 8];
+      }
+    };
+
+    const int S = p.nC4;
+    if (S > 1) issue_u1(item);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                        // B0: raw(0..2), U(0..1) have landed
+    load_window(0);
+    transform(0);
+    if (S > 1) load_window(1);
+    __syncthreads();                                        // B1 (the compiler waits for this wave's LDS accesses before a barrier)
+    int ring = 0;                                           // s % 3
+#if W4P_TRACE
+    const bool trace = blockIdx.x == 0 && pw == 0 && item == wk.first;
+    unsigned long long tr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    for (int s = 0; s < S; ++s) {
+      const int r1 = ring == 2 ? 0 : ring + 1, r2 = r1 == 2 ? 0 : r1 + 1;
+      W4P_T(q0);
+      // V(s+1) from the window fetched during the previous iteration, then the window of slice s+2 (raw(s+2) landed before the
+      // barrier that ended iteration s-1)
+      if (s + 1 < S && !(W4P_EXP & 17)) transform((s + 1) & 1);
+      W4P_T(q1);
+      if (s + 2 < S && !(W4P_EXP & 17)) load_window(r2);
+      W4P_T(q4);
+      ring = r1;
+      __syncthreads();
+      W4P_T(q6);
+      W4P_ACC(0, q0, q1); W4P_ACC(3, q1, q4); W4P_ACC(5, q4, q6);
+    }
+#if W4P_TRACE
+    if (trace && lane == 0) for (int k = 0; k < 6; ++k) g_w4p_trace[8 + k] = tr[k];
+#endif
+    if (item + wk.step < wk.end) prefetch_item(item + wk.step);          // ... while the MFMA waves exchange and store
+#pragma unroll
+    for (int n = 0; n < NT; ++n) { __syncthreads(); __syncthreads(); }   // the MFMA waves' exchange rounds
+    __syncthreads();
+  }
+}
+
+template <int NT>
+__global__ void __launch_bounds__(768)
+conv_wino4p_kernel(const W4PParams p) {
+  extern __shared__ float4 smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (wave < W4P_NCONS) {
+    const int grp = wave >> 2, q = wave & 3;
+    if (q == 0) w4p_consumer<NT, 0>(p, smem, grp, lane, wave);
+    else if (q == 1) w4p_consumer<NT, 1>(p, smem, grp, lane, wave);
+    else if (q == 2) w4p_consumer<NT, 2>(p, smem, grp, lane, wave);
+    else w4p_consumer<NT, 3>(p, smem, grp, lane, wave);
+  } else {
+    const int pw = wave - W4P_NCONS;
+    if (pw & 1) w4p_producer<NT, 1>(p, smem, pw, lane);
+    else w4p_producer<NT, 0>(p, smem, pw, lane);
+  }
+}
+
+struct W4PLayout { int uoff, voff, xoff, totalF4; };
+bool w4p_geo(const ConvDesc& d, const ConvCfg& cfg, w4::Geo* g, W4PLayout* L) {
+  if (d.ks != 3 || d.stride != 1 || cfg.NT < 1 || cfg.NT > 3 || cfg.WM != 2 || cfg.WN != 4 || d.Cin % 16 || d.Cout % 16) return false;
+  if (!w4::geo(d, cfg, 32, g)) return false;
+  if (g->rawF4 > W4P_NCONS * W4P_MAXP * 64) return false;
+  const int uF4 = cfg.NT * W4P_UBLK, vF4 = 2 * W4P_UBLK;
+  L->uoff = 3 * g->rawF4;
+  L->voff = L->uoff + 3 * uF4;
+  const int end = L->voff + 2 * vF4;
+  // the exchange area overlays U ring slots 1, 2 and the V buffers (slot 0 and the raw ring may receive the next item's
+  // first fetches during the exchange rounds) and extends past them when they are smaller than 64 KiB (NT = 1)
+  L->xoff = L->uoff + uF4;
+  L->totalF4 = std::max(end, L->xoff + W4P_XCH);
+  return (size_t)L->totalF4 * sizeof(float4) <= 160 * 1024;
+}
+
+}  // namespace
+
+// packed fragments for ALG 8: [Cin/4][Cout16/16][9 pieces][64 lanes] float4; piece 2q+a (q = 0..3, a = 0..1): lane = g*16 + co_l holds
+// U[9q + 4a + j][co][4 c4 + g] * scale[co], j = 0..3; piece 8: float index q*64 + lane = U[9q + 8][co][4 c4 + g] * scale[co]
+size_t conv_wino4p_packed_floats(int Cin, int Cout16) { return (size_t)36 * Cin * Cout16; }
+void conv_wino4p_pack_weights(const float* w_oihw, const float* scale, int Cout, int Cin, int Cout16, float* dst) {
+  std::vector<double> u;
+  w4::u_transform(w_oihw, Cout, Cin, &u);
+  const int nC4 = Cin / 4, nT16 = Cout16 / 16;
+  auto val = [&](int pos, int co, int ci) -> float {
+    return co < Cout ? (float)(u[((size_t)pos * Cout + co) * Cin + ci] * (scale ? (double)scale[co] : 1.0)) : 0.f;
+  };
+  for (int c4 = 0; c4 < nC4; ++c4)
+    for (int nt = 0; nt < nT16; ++nt) {
+      float* blk = dst + ((size_t)c4 * nT16 + nt) * 9 * 256;
+      for (int lane = 0; lane < 64; ++lane) {
+        const int g = lane >> 4, co = nt * 16 + (lane & 15), ci = 4 * c4 + g;
+        for (int q = 0; q < 4; ++q) {
+          for (int a = 0; a < 2; ++a)
+            for (int j = 0; j < 4; ++j) blk[((2 * q + a) * 64 + lane) * 4 + j] = val(9 * q + 4 * a + j, co, ci);
+          blk[8 * 256 + q * 64 + lane] = val(9 * q + 8, co, ci);
+        }
+      }
+    }
+}
+
+// cfg: {MT = 1, NT (1..3), WM = 2 tile groups, WN = 4 position quarters, R = output rows per slab (multiple of 4), NI, ALG = 8}
+size_t conv_wino4p_lds_bytes(const ConvDesc& d, const ConvCfg& cfg) {
+  w4::Geo g;
+  W4PLayout L;
+  if (!w4p_geo(d, cfg, &g, &L)) return 0;
+  return (size_t)L.totalF4 * sizeof(float4);
+}
+
+int conv_wino4p_launch(const ConvDesc& d, const ConvCfg& cfg, hipStream_t stream) {
+  w4::Geo g;
+  W4PLayout L;
+  if (!w4p_geo(d, cfg, &g, &L) || !d.wfrag_wino4p) {
+    poco_set_error("conv(winograd 4x4, specialised waves): needs ks = 3, stride 1, NT 1..3, WM = 2, WN = 4, R % 4 == 0, "
+                   "NI*(R/4)*ceil(W/4) <= 32 tiles, a patch of <= 1024 slots and the ALG 8 weight fragments");
+    return POCO_ERR_ARG;
+  }
+  if (d.act == 3 || d.act == 2) { poco_set_error("conv(winograd 4x4): activation must be none or ReLU"); return POCO_ERR_ARG; }
+  W4PParams p{};
+  p.in = d.in + l16_chan_off(d.in_co, d.W);
+  p.res = d.res ? d.res + l16_chan_off(d.res_co, d.W) : nullptr;
+  p.out = d.out + l16_chan_off(d.out_co, d.W);
+  p.ufrag = reinterpret_cast<const float4*>(d.wfrag_wino4p); p.bias = d.bias;
+  p.B = d.B; p.H = d.H; p.W = d.W; p.nC4 = d.Cin / 4; p.nT16 = d.Cout / 16;
+  p.in_rs = d.in_cs * d.W; p.in_ss = d.W * 16; p.res_rs = d.res_cs * d.W; p.out_rs = d.out_cs * d.W; p.out_ss = d.W * 16;
+  p.R = g.R; p.NI = g.NI; p.S = g.S; p.nbands = g.nbands; p.TX = g.TX; p.PR = g.PR; p.PW = g.PW; p.npos = g.npos; p.rawF4 = g.rawF4;
+  p.tiles_per_slab = g.tps;
+  p.act = d.act; p.res_after_act = d.res_after_act;
+  p.uoff = L.uoff; p.voff = L.voff; p.xoff = L.xoff;
+  p.dPW = make_fastdiv(g.PW); p.dSlab = make_fastdiv(g.PR * g.PW); p.dBands = make_fastdiv(g.nbands);
+  p.dTX = make_fastdiv(g.TX); p.dTslab = make_fastdiv(g.tps);
+  p.nblocks_m = (g.S + g.NI - 1) / g.NI; p.nb_n = (p.nT16 + cfg.NT - 1) / cfg.NT;
+  // balanced persistent grid: every block walks the same number of items (one block per CU)
+  const long items = (long)p.nblocks_m * p.nb_n;
+  const long rounds = (items + 255) / 256;
+  long g4 = (items + rounds - 1) / rounds;
+  if (g4 > 8) g4 = std::min(256L, (g4 + 7) / 8 * 8);           // multiple of 8 for the XCD-aware walk
+  const size_t lds = (size_t)L.totalF4 * sizeof(float4);
+  auto fn = cfg.NT == 3 ? conv_wino4p_kernel<3> : cfg.NT == 2 ? conv_wino4p_kernel<2> : conv_wino4p_kernel<1>;
+  if (lds > 64 * 1024) {
+    static thread_local bool configured[4] = {false, false, false, false};
+    if (!configured[cfg.NT]) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (e != hipSuccess) { poco_set_error(std::string("hipFuncSetAttribute: ") + hipGetErrorString(e)); return POCO_ERR_HIP; }
+      configured[cfg.NT] = true;
+    }
+  }
+  hipLaunchKernelGGL(fn, dim3((unsigned)g4, 1), dim3(768), lds, stream, p);
+  POCO_HIP_CHECK(hipGetLastError());
+  return POCO_OK;
+}
+
+#if W4P_TRACE
+extern "C" int poco_w4p_trace(unsigned long long* host_out, int n) {
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_w4p_trace), sizeof(unsigned long long) * (size_t)std::min(n, 64)) == hipSuccess ? 0 : 1;
+}
+#endif

@@ -72,6 +72,7 @@ struct Op {
   float* wdev = nullptr;
   float* bdev = nullptr;
   float* wdev_wino = nullptr;   // 3x3 stride-1 convs: Winograd-transformed weights (ALG 3)
+  float* wdev_wino4p = nullptr; // the same in the LDS order of ALG 8
   float* wdev_wino4 = nullptr;  // 3x3 stride-1 convs on planes >= 28x28: F(4x4,3x3) fragments (ALG 7)
   float* wdev2 = nullptr;       // OP_CHAIN: the second 1x1 conv (next block's conv1)
   float* bdev2 = nullptr;
@@ -272,6 +273,8 @@ struct Builder {
           std::vector<float> pu4(conv_wino4_packed_floats(Cin, Cout16));
           conv_wino4_pack_weights(wp, scale.data(), Cout, Cin, Cout16, pu4.data());
           op.wdev_wino4 = upload(pu4);
+          conv_wino4p_pack_weights(wp, scale.data(), Cout, Cin, Cout16, pu4.data());     // same size, other order
+          op.wdev_wino4p = upload(pu4);
         }
       }
     }
@@ -1080,7 +1083,7 @@ int run_op(Engine& e, Op& op, int B, const IO& io, hipStream_t s) {
       d.in = aptr(e, op.in); d.in_cs = ai.C; d.in_co = 0;
       if (op.res.act >= 0) { d.res = aptr(e, op.res); d.res_cs = e.acts[op.res.act].C; }
       d.out = aptr(e, op.out); d.out_cs = ao.C; d.out_co = 0;
-      d.wfrag = op.wdev; d.bias = op.bdev; d.wfrag_wino = op.wdev_wino; d.wfrag_wino4 = op.wdev_wino4;
+      d.wfrag = op.wdev; d.bias = op.bdev; d.wfrag_wino = op.wdev_wino; d.wfrag_wino4 = op.wdev_wino4; d.wfrag_wino4p = op.wdev_wino4p;
       d.B = B; d.H = ai.H; d.W = ai.W; d.Cin = op.Cin; d.Cout = op.Cout; d.ks = op.ks; d.stride = op.stride;
       d.act = op.actfn; d.res_after_act = op.res_after; d.relu_from = op.relu_from;
       auto it = op.cfg.find(B);
@@ -1404,7 +1407,7 @@ extern "C" int poco_set_conv_cfg(poco_handle_t h, int op_index, int B, const int
   const size_t lds = conv_lds_bytes(d, c);
   if (B < 1 || lds == 0 || lds > 160 * 1024 || ((c.ALG == 3 || c.ALG == 4) && (op.wdev_wino == nullptr && e->finalized)) ||
       ((c.ALG == 3 || c.ALG == 4) && (op.actfn == 3 || op.actfn == 2)) ||
-      (c.ALG == 7 && ((op.wdev_wino4 == nullptr && e->finalized) || ai.H < 28 || ai.W < 28 || op.actfn >= 2))) {
+      ((c.ALG == 7 || c.ALG == 8) && ((op.wdev_wino4 == nullptr && e->finalized) || ai.H < 28 || ai.W < 28 || op.actfn >= 2))) {
     poco_set_error("poco_set_conv_cfg: configuration does not fit op '" + op.name + "' at this batch size");
     return POCO_ERR_ARG;
   }

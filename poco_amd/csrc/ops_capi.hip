@@ -44,7 +44,7 @@ static int conv_common(const float* d_in, int B, int H, int W, int Cin, const fl
   std::vector<float> shift(Cout16, 0.f);
   if (h_shift)
     for (int i = 0; i < Cout; ++i) shift[i] = h_shift[i];
-  DevBuf dw, db, dwu, dwu4;
+  DevBuf dw, db, dwu, dwu4, dwu4p;
   POCO_HIP_CHECK(dw.upload(packed));
   POCO_HIP_CHECK(db.upload(shift));
   ConvDesc d{};
@@ -59,6 +59,12 @@ static int conv_common(const float* d_in, int B, int H, int W, int Cin, const fl
       conv_wino4_pack_weights(h_w, h_scale, Cout, Cin, Cout16, pu4.data());
       POCO_HIP_CHECK(dwu4.upload(pu4));
       d.wfrag_wino4 = dwu4.p;
+    }
+    if (cfg7 && cfg7[6] == 8) {                   // the same fragments in the LDS order of the specialised-wave kernel
+      std::vector<float> pu4(conv_wino4p_packed_floats(Cin, Cout16));
+      conv_wino4p_pack_weights(h_w, h_scale, Cout, Cin, Cout16, pu4.data());
+      POCO_HIP_CHECK(dwu4p.upload(pu4));
+      d.wfrag_wino4p = dwu4p.p;
     }
   }
   d.in = d_in; d.in_cs = Cin; d.in_co = 0;
@@ -138,7 +144,7 @@ extern "C" int poco_tune_conv(int B, int H, int W, int Cin, int Cout, int ks, in
     for (auto& v : hu) v = rnd() * ws;
     POCO_HIP_CHECK(dwu.upload(hu));
     bool any7 = false;
-    for (int i = 0; i < ncfg; ++i) any7 = any7 || cfgs6[CONV_CFG_INTS * i + 6] == 7;
+    for (int i = 0; i < ncfg; ++i) any7 = any7 || cfgs6[CONV_CFG_INTS * i + 6] == 7 || cfgs6[CONV_CFG_INTS * i + 6] == 8;
     if (any7) {
       std::vector<float> hu4((size_t)36 * Cin * Cout);
       for (auto& v : hu4) v = rnd() * ws;
@@ -151,7 +157,7 @@ extern "C" int poco_tune_conv(int B, int H, int W, int Cin, int Cout, int ks, in
   POCO_HIP_CHECK(hipMalloc(&dout.p, nout * sizeof(float)));
   ConvDesc d{};
   d.in = din.p; d.in_cs = Cin; d.out = dout.p; d.out_cs = Cout; d.wfrag = dw.p; d.bias = db.p;
-  d.wfrag_wino = dwu.p; d.wfrag_wino4 = dwu4.p;
+  d.wfrag_wino = dwu.p; d.wfrag_wino4 = dwu4.p; d.wfrag_wino4p = dwu4.p;     // timing only: random fragments serve both orders
   d.B = B; d.H = H; d.W = W; d.Cin = Cin; d.Cout = Cout; d.ks = ks; d.stride = stride; d.act = 1;
   hipEvent_t e0, e1;
   POCO_HIP_CHECK(hipEventCreate(&e0));

@@ -125,6 +125,11 @@ def candidates(B, H, W, Cin, Cout, ks, stride, lds_cap=150 * 1024) -> List[Tuple
                     raw = (npos + npos // 8 + 1 + 63) // 64 * 64
                     if raw <= 1024 and 2 * max(2 * (raw + 9 * NT * 64), 4096) * 16 <= 160 * 1024:
                         out.add((1, NT, 2, 4, R, ni, 7))
+                    # ALG 8 (specialised waves): raw ring 3 deep (<= 1024 slots per slice), U ring 3 deep, V 2 deep, exchange overlay
+                    u, v = NT * 576, 2 * 576
+                    tot = max(3 * raw + 3 * u + 2 * v, 3 * raw + u + 4096)
+                    if raw <= 1024 and tot * 16 <= 160 * 1024:
+                        out.add((1, NT, 2, 4, R, ni, 8))
     return sorted(out)
 
 

@@ -245,8 +245,8 @@ WINO4 = [
 ]
 
 
-def _wino4_cfg(H, W, nt):
-    """(R, NI) of ALG 7 for a plane: as many 4-row tile bands as fit 32 tiles, whole images when several fit."""
+def _wino4_cfg(H, W, nt, alg=7):
+    """(R, NI) of ALG 7 / 8 for a plane: as many 4-row tile bands as fit 32 tiles, whole images when several fit."""
     TX, Hc = (W + 3) // 4, (H + 3) // 4 * 4
     R = Hc if (Hc // 4) * TX <= 32 else max(4, 32 // TX * 4)
     NI = max(1, min(32 // ((R // 4) * TX), 1024 // ((R + 2) * (4 * TX + 2)))) if R == Hc else 1
@@ -254,17 +254,19 @@ def _wino4_cfg(H, W, nt):
     lds = lambda ni: 4 * ((npos(ni) + npos(ni) // 8 + 1 + 63) // 64 * 64 + 9 * nt * 64) * 16     # 2 buffers x 2 slices, skewed slots
     while NI > 1 and (lds(NI) > 160 * 1024 or (npos(NI) + npos(NI) // 8 + 1 + 63) // 64 * 64 > 1024):
         NI -= 1
-    return (1, nt, 2, 4, R, NI, 7)
+    return (1, nt, 2, 4, R, NI, alg)
 
 
+@pytest.mark.parametrize("alg", [7, 8])
 @pytest.mark.parametrize("nt", [1, 2, 3])
 @pytest.mark.parametrize("case", WINO4, ids=lambda c: "x".join(map(str, c)))
-def test_conv_winograd_f4x4(case, nt, cuda):
-    """ALG 7: Winograd F(4x4,3x3) for the 3x3 stride-1 convs of hrnet.py:42-58.
+def test_conv_winograd_f4x4(case, nt, alg, cuda):
+    """ALG 7 / ALG 8 (specialised waves: 8 MFMA waves + 4 producer waves, V staged in LDS): Winograd F(4x4,3x3) for the
+    3x3 stride-1 convs of hrnet.py:42-58.
     Tolerance 2e-4 * max|ref|: the F(4x4) transforms (constants up to 8) amplify fp32 rounding ~10x over F(2x2)."""
     from poco_amd import ops
     B, H, W, Cin, Cout, has_res = case
-    cfg = _wino4_cfg(H, W, nt)
+    cfg = _wino4_cfg(H, W, nt, alg)
     rng = np.random.default_rng(B * 313 + Cin + Cout)
     x = rng.standard_normal((B, H, W, Cin)).astype(np.float32)
     w = (rng.standard_normal((Cout, Cin, 3, 3)) / np.sqrt(9 * Cin)).astype(np.float32)
@@ -310,7 +312,7 @@ def _conv_fp64_gpu(x, w, shift, stride, res, relu):
     return y.clamp_min(0) if relu else y
 
 
-ALG_TOL = {3: 1e-4, 4: 1e-4, 7: 2e-4}     # Winograd F(2x2): transforms amplify fp32 rounding ~5x, F(4x4) ~10x
+ALG_TOL = {3: 1e-4, 4: 1e-4, 7: 2e-4, 8: 2e-4}     # Winograd F(2x2): transforms amplify fp32 rounding ~5x, F(4x4) ~10x
 
 
 @pytest.mark.parametrize("batch", [32, 64, 128])

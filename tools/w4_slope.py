@@ -8,8 +8,9 @@ from poco_amd._lib import check, lib  # noqa: E402
 torch.cuda.set_device(0)
 L = lib()
 L.poco_tune_conv.argtypes = [C.c_int] * 7 + [C.POINTER(C.c_int), C.c_int, C.c_int, C.POINTER(C.c_float), C.c_void_p]
-CASES = [((64, 56, 56, 48), [(1, 3, 2, 4, 8, 1, 7), (1, 3, 4, 2, 4, 1, 4)]), ((64, 28, 28, 96), [(1, 3, 2, 4, 16, 1, 7), (1, 3, 4, 2, 8, 1, 4)]),
-         ((64, 14, 14, 192), [(1, 3, 2, 4, 16, 2, 7), (1, 3, 4, 2, 14, 1, 4)])]
+CASES = [((64, 56, 56, 48), [(1, 3, 2, 4, 8, 1, 8), (1, 3, 2, 4, 8, 1, 7), (1, 3, 4, 2, 4, 1, 4)]),
+         ((64, 28, 28, 96), [(1, 3, 2, 4, 16, 1, 8), (1, 3, 2, 4, 16, 1, 7), (1, 3, 4, 2, 8, 1, 4)]),
+         ((64, 14, 14, 192), [(1, 3, 2, 4, 16, 2, 8), (1, 3, 2, 4, 16, 2, 7), (1, 3, 4, 2, 14, 1, 4)])]
 for (B, H, W, Cout), cfgs in CASES:
     for cfg in cfgs:
         ts = []
