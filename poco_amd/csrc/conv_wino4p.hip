@@ -234,8 +234,6 @@ __device__ __forceinline__ void w4p_consumer(const W4PParams& p, float4* smem, i
       W4P_T(c0);
       const int r1 = ring == 2 ? 0 : ring + 1, r2 = r1 == 2 ? 0 : r1 + 1;
       int nvm = 0;
-      if (s + 2 < S && !(W4P_EXP & 2)) nvm += issue_u(s + 2, r2);           // slot of U(s-1): consumed before the barrier that ended iteration s-1
-      if (s + 4 < S && !(W4P_EXP & 2)) nvm += issue_raw(s + 4, r1);         // slot of raw(s+1): its window was read during iteration s-1
       const float4* U = smem + p.uoff + ring * uF4 + (2 * Q) * 64 + lane;
       const float4* V = smem + p.voff + (s & 1) * (2 * W4P_UBLK) + grp * W4P_UBLK + (2 * Q) * 64 + lane;
       const bool noread = (W4P_EXP & 8) != 0;
@@ -252,6 +250,14 @@ __device__ __forceinline__ void w4p_consumer(const W4PParams& p, float4* smem, i
           const float v = i < 4 ? f4c(vq0, i) : i < 8 ? f4c(vq1, i - 4) : vs;
           if (W4P_EXP & 4) acc[i][n][0] += a * v;
           else acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, v, acc[i][n], 0, 0, 0);
+        }
+        // The LDS-DMA of the coming slices goes out AFTER the first MFMAs of the slice are queued: a vector-memory instruction
+        // takes this wave ~60 clk to issue; behind queued MFMAs that is hidden, ahead of them the pipe would idle.
+        if (n == 0 && !(W4P_EXP & 64)) {
+          __builtin_amdgcn_sched_barrier(0);
+          if (s + 2 < S && !(W4P_EXP & 2)) nvm += issue_u(s + 2, r2);       // slot of U(s-1): consumed before the barrier that ended iteration s-1
+          if (s + 4 < S && !(W4P_EXP & 2)) nvm += issue_raw(s + 4, r1);     // slot of raw(s+1): its window was read during iteration s-1
+          __builtin_amdgcn_sched_barrier(0);
         }
       }
       wait_vm(nvm);                                         // what this wave issued BEFORE this iteration has landed: U(s+1), raw(s+3)
