@@ -1,28 +1,77 @@
-"""Aggregate rocprofv3 --pmc counter_collection CSVs per kernel family.
-usage: python tools/pmc_summary.py <dir with *_counter_collection.csv ...> [out.json]"""
+"""Aggregate rocprofv3 --pmc counter_collection CSVs PER KERNEL SYMBOL (template arguments kept, e.g. `conv_wino4p_kernel<3>`).
+usage: python tools/pmc_summary.py <dir with *_counter_collection.csv ...> <out.json> [forwards per PMC pass]
+
+Per symbol: the raw counter sums over all its dispatches, `dispatches`, and the derived ratios the design is steered by
+  mfma_busy  = SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x 256 CUs) / (GRBM_GUI_ACTIVE / 8 XCDs)   (fraction of the kernel's own
+               active time in which the MFMA pipe of a SIMD was busy, averaged over SIMDs)
+  mfma_gflop = SQ_INSTS_VALU_MFMA_MOPS_F32 x 512 / 1e9 (executed, not algorithmic)
+  hbm_bytes  = 2 x FETCH_SIZE KB (gfx950 correction for 16 B/lane streams, MI355X_MICROARCH.md) + WRITE_SIZE KB
+`_meta` records the kernel-source digest the profile was taken from (bench.py refuses a stale profile for roofline.traffic) and
+the number of forwards per pass; `_total` sums every kernel."""
 import csv
 import glob
+import hashlib
 import json
 import re
 import sys
 from collections import defaultdict
+from pathlib import Path
 
-root = sys.argv[1]
-agg = defaultdict(lambda: defaultdict(float))
-calls = defaultdict(lambda: defaultdict(int))
-for f in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
-    for r in csv.DictReader(open(f)):
-        name = r.get("Kernel_Name", "")
-        m = re.search(r"(conv_\w+_kernel|conv_wino_kernel|\w+_kernel)", name)
-        fam = m.group(1) if m else name[:40]
-        if "conv_" in fam:
-            fam = "conv(all MFMA variants)"
-        c = r["Counter_Name"]
-        agg[fam][c] += float(r["Counter_Value"])
-        calls[fam][c] += 1
-out = {}
-for fam, cs in agg.items():
-    d = {k: v for k, v in cs.items()}
-    d["dispatches"] = max(calls[fam].values())
-    out[fam] = d
-json.dump(out, open(sys.argv[2], "w") if len(sys.argv) > 2 else sys.stdout, indent=1)
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def csrc_digest() -> str:
+    h = hashlib.sha256()
+    for f in sorted((ROOT / "poco_amd" / "csrc").glob("*")):
+        if f.suffix in (".hip", ".h", ".cpp"):
+            h.update(f.name.encode())
+            h.update(f.read_bytes())
+    return h.hexdigest()[:16]
+
+
+def symbol(name: str) -> str:
+    name = re.sub(r"\(anonymous namespace\)::", "", name)
+    name = re.sub(r"^void\s+", "", name)
+    m = re.match(r"([A-Za-z_]\w*(?:<[^()]*?>)?)\s*\(", name)
+    s = m.group(1) if m else name.split("(")[0]
+    return s.strip()[:80]
+
+
+def main():
+    root, out = sys.argv[1], sys.argv[2]
+    forwards = int(sys.argv[3]) if len(sys.argv) > 3 else 5
+    agg = defaultdict(lambda: defaultdict(float))
+    calls = defaultdict(lambda: defaultdict(int))
+    for f in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            sym = symbol(r.get("Kernel_Name", ""))
+            c = r["Counter_Name"]
+            agg[sym][c] += float(r["Counter_Value"])
+            calls[sym][c] += 1
+    res = {}
+    tot = defaultdict(float)
+    for sym, cs in agg.items():
+        d = {k: v for k, v in cs.items()}
+        d["dispatches"] = max(calls[sym].values())
+        if d.get("GRBM_GUI_ACTIVE") and "SQ_VALU_MFMA_BUSY_CYCLES" in d:
+            d["mfma_busy"] = round(d["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0 / (d["GRBM_GUI_ACTIVE"] / 8.0), 4)
+        if "SQ_INSTS_VALU_MFMA_MOPS_F32" in d:
+            d["mfma_gflop"] = round(d["SQ_INSTS_VALU_MFMA_MOPS_F32"] * 512 / 1e9, 3)
+        if "FETCH_SIZE" in d or "WRITE_SIZE" in d:
+            d["hbm_bytes"] = round((2.0 * d.get("FETCH_SIZE", 0.0) + d.get("WRITE_SIZE", 0.0)) * 1024.0)
+        for k, v in cs.items():
+            tot[k] += v
+        res[sym] = d
+    t = dict(tot)
+    if t.get("GRBM_GUI_ACTIVE") and "SQ_VALU_MFMA_BUSY_CYCLES" in t:
+        t["mfma_busy"] = round(t["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0 / (t["GRBM_GUI_ACTIVE"] / 8.0), 4)
+    t["hbm_bytes_per_forward"] = round((2.0 * t.get("FETCH_SIZE", 0.0) + t.get("WRITE_SIZE", 0.0)) * 1024.0 / forwards)
+    res = dict(sorted(res.items(), key=lambda kv: -kv[1].get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0)))
+    res["_total"] = t
+    res["_meta"] = {"csrc_sha": csrc_digest(), "forwards": forwards,
+                    "note": "counter sums over all dispatches of the profiled command (warm-up + timed forwards)"}
+    json.dump(res, open(out, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()

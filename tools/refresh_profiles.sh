@@ -1,25 +1,37 @@
 #!/bin/bash
-# Round-end artifacts on the GPU box: bench lines of the three variants, rocprofv3 kernel stats
-# (single lane = non-overlapping kernel durations, and the default 4 lanes) and the PMC passes.
-# Usage (from the repo root on the box): tools/refresh_profiles.sh <tag>   -> gpurun_out/<tag>/
-TAG=${1:-r01}
+# Round-end artifacts on the GPU box: bench lines of the three variants, rocprofv3 kernel stats (single lane = non-overlapping
+# kernel durations, and the default 4 lanes) and the PMC passes (separate passes; never mixed with hip/hsa tracing).
+# Usage (from the repo root on the box): tools/refresh_profiles.sh <tag> [pmc]   -> gpurun_out/<tag>/ ; copy what is to be
+# judged into profiles/ (bench.py's roofline.traffic reads profiles/<tag>_pmc_*_summary.json and checks its kernel-source digest).
+TAG=${1:-r02}
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/$TAG
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-python $R/bench.py --steps 30 --warmup 5 2>$OUT/bench_w48.err | tail -1 > $OUT/${TAG}_bench_hrnet_w48_cls-cliff.json
-python $R/bench.py --steps 30 --warmup 5 --variant resnet50-cliff --batch 64 2>/dev/null | tail -1 > $OUT/${TAG}_bench_resnet50-cliff.json
-python $R/bench.py --steps 30 --warmup 5 --variant hrnet_w32-pare --batch 32 2>/dev/null | tail -1 > $OUT/${TAG}_bench_hrnet_w32-pare.json
-python $R/bench.py --steps 30 --warmup 5 --no-graph --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/${TAG}_bench_hrnet_w48_cls-cliff_nograph.json
-for L in 1 4; do
-  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ks_l$L -o bench -- \
-    python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-dominant --no-graph --lanes $L > $OUT/ks_l$L.log 2>&1
-  cp $OUT/ks_l$L/*/*kernel_stats.csv $OUT/${TAG}_bench_w48cliff_b64_lanes${L}_kernel_stats.csv 2>/dev/null || \
-    cp $OUT/ks_l$L/*kernel_stats.csv $OUT/${TAG}_bench_w48cliff_b64_lanes${L}_kernel_stats.csv
-  rm -rf $OUT/ks_l$L
-done
-if [ "$2" = "pmc" ]; then
-  BENCH_ARGS="--no-graph" bash $R/tools/run_pmc.sh > $OUT/pmc.log 2>&1
-  cp $R/gpurun_out/pmc_r1/summary.json $OUT/${TAG}_pmc_w48cliff_b64_summary.json
-fi
-cat $OUT/*.json | cut -c1-400
+python $R/bench.py 2>$OUT/bench_w48.err | tail -1 > $OUT/${TAG}_bench_hrnet_w48_cls-cliff.json
+python $R/bench.py --variant resnet50-cliff --batch 64 --no-stream 2>/dev/null | tail -1 > $OUT/${TAG}_bench_resnet50-cliff.json
+python $R/bench.py --variant hrnet_w32-pare --batch 32 --no-stream 2>/dev/null | tail -1 > $OUT/${TAG}_bench_hrnet_w32-pare.json
+python $R/bench.py --no-graph --no-cpu-baseline --no-stream 2>/dev/null | tail -1 > $OUT/${TAG}_bench_hrnet_w48_cls-cliff_nograph.json
+prof_variant() {   # variant batch short-tag
+  V=$1; B=$2; T=$3
+  ARGS="--variant $V --batch $B --no-cpu-baseline --no-stream --no-dominant --no-graph"
+  for L in 1 4; do
+    timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ks -o bench -- \
+      python $R/bench.py --steps 10 --warmup 3 --lanes $L $ARGS > $OUT/ks_${T}_l$L.log 2>&1
+    cp $(find $OUT/ks -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_${T}_b${B}_lanes${L}_kernel_stats.csv; rm -rf $OUT/ks
+    [ "$T" = "w48cliff" ] || break      # 4-lane statistics only for the headline variant
+  done
+  if [ "$4" = "pmc" ]; then
+    CMD="python $R/bench.py --steps 3 --warmup 2 $ARGS"
+    timeout 900 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_BUSY_CYCLES --output-format csv -d $OUT/p/p1 -o p1 -- $CMD > $OUT/p1.log 2>&1
+    timeout 900 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/p/p2 -o p2 -- $CMD > $OUT/p2.log 2>&1
+    timeout 900 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/p/p3 -o p3 -- $CMD > $OUT/p3.log 2>&1
+    timeout 900 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES --output-format csv -d $OUT/p/p4 -o p4 -- $CMD > $OUT/p4.log 2>&1
+    python $R/tools/pmc_summary.py $OUT/p $OUT/${TAG}_pmc_${T}_b${B}_summary.json 5
+    rm -rf $OUT/p
+  fi
+}
+prof_variant hrnet_w48_cls-cliff 64 w48cliff $2
+prof_variant resnet50-cliff 64 resnet50cliff $2
+prof_variant hrnet_w32-pare 32 w32pare $2
+ls $OUT; cat $OUT/*bench*.json | cut -c1-300
