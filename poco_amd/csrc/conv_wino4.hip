@@ -266,7 +266,7 @@ __device__ __forceinline__ void wino4_wave(const W4Params& p, float4* smem, int 
       constexpr int i = Q;
       const int oy = oyb + i;
       const bool oky = tvalid && oy < p.H;
-      const size_t orow = (size_t)b * p.H + min(oy, p.H - 1);
+      const size_t orow = (size_t)(tvalid ? b : 0u) * p.H + min(oy, p.H - 1);   // lanes without a tile: residual loads stay inside the tensor
       const size_t ooff = orow * p.out_rs + (size_t)(nt0 + n) * p.out_ss + g * 4;
       const size_t roff = orow * p.res_rs + (size_t)(nt0 + n) * p.out_ss + g * 4;
       float4 rr[4];

@@ -123,6 +123,9 @@ __device__ __forceinline__ Tile tile_of(const W4PParams& p, int item, int grp, i
   t.oy0 = band * p.R + 4 * (int)tyl;
   t.valid = sl < (uint32_t)p.NI && s < (uint32_t)p.S && t.oy0 < p.H;
   t.base = t.valid ? (int)((sl * (uint32_t)p.PR + 4 * tyl) * (uint32_t)p.PW) + 4 * t.tx : 0;
+  // a lane without a tile (beyond the block's slabs / the plane) computes along harmlessly and is masked at the store, but
+  // its unconditional residual loads must stay inside the tensor: park it on image 0, row 0
+  if (!t.valid) { t.b = 0; t.oy0 = 0; t.tx = 0; }
   return t;
 }
 
