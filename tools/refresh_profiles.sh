@@ -22,7 +22,9 @@ prof_variant() {   # variant batch short-tag
     [ "$T" = "w48cliff" ] || break      # 4-lane statistics only for the headline variant
   done
   if [ "$4" = "pmc" ]; then
-    CMD="python $R/bench.py --steps 3 --warmup 2 $ARGS"
+    # PMC passes on ONE lane: with 4 lanes kernels of different branches share the chip and a kernel's GRBM_GUI_ACTIVE
+    # (the time base of mfma_busy) counts the other kernels' time too
+    CMD="python $R/bench.py --steps 3 --warmup 2 --lanes 1 $ARGS"
     timeout 900 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_BUSY_CYCLES --output-format csv -d $OUT/p/p1 -o p1 -- $CMD > $OUT/p1.log 2>&1
     timeout 900 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/p/p2 -o p2 -- $CMD > $OUT/p2.log 2>&1
     timeout 900 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/p/p3 -o p3 -- $CMD > $OUT/p3.log 2>&1
