@@ -269,10 +269,12 @@ struct Builder {
         conv_wino_transform_weights(wp, Cout, Cin, &wt);
         conv_pack_weights(wt.data(), scale.data(), Cout, Cin, 4, Cout16, pu.data());
         op.wdev_wino = upload(pu);
-        if (ain.H >= 28 && ain.W >= 28) {          // F(4x4,3x3) only pays on the large planes (its 4x4 tiles waste 14x14 / 7x7)
+        if (ain.H >= 14 && ain.W >= 14) {          // F(4x4,3x3): 56x56 / 28x28 planes, and 14x14 (16 tiles per image, 31 % padding) with ALG 8
           std::vector<float> pu4(conv_wino4_packed_floats(Cin, Cout16));
-          conv_wino4_pack_weights(wp, scale.data(), Cout, Cin, Cout16, pu4.data());
-          op.wdev_wino4 = upload(pu4);
+          if (ain.H >= 28 && ain.W >= 28) {
+            conv_wino4_pack_weights(wp, scale.data(), Cout, Cin, Cout16, pu4.data());
+            op.wdev_wino4 = upload(pu4);
+          }
           conv_wino4p_pack_weights(wp, scale.data(), Cout, Cin, Cout16, pu4.data());     // same size, other order
           op.wdev_wino4p = upload(pu4);
         }
@@ -1407,7 +1409,8 @@ extern "C" int poco_set_conv_cfg(poco_handle_t h, int op_index, int B, const int
   const size_t lds = conv_lds_bytes(d, c);
   if (B < 1 || lds == 0 || lds > 160 * 1024 || ((c.ALG == 3 || c.ALG == 4) && (op.wdev_wino == nullptr && e->finalized)) ||
       ((c.ALG == 3 || c.ALG == 4) && (op.actfn == 3 || op.actfn == 2)) ||
-      ((c.ALG == 7 || c.ALG == 8) && ((op.wdev_wino4 == nullptr && e->finalized) || ai.H < 28 || ai.W < 28 || op.actfn >= 2))) {
+      (c.ALG == 7 && ((op.wdev_wino4 == nullptr && e->finalized) || ai.H < 28 || ai.W < 28 || op.actfn >= 2)) ||
+      (c.ALG == 8 && ((op.wdev_wino4p == nullptr && e->finalized) || ai.H < 14 || ai.W < 14 || op.actfn >= 2))) {
     poco_set_error("poco_set_conv_cfg: configuration does not fit op '" + op.name + "' at this batch size");
     return POCO_ERR_ARG;
   }
