@@ -99,3 +99,25 @@ def test_demo_video_two_ranks_matches_one_process(tmp_path, cuda):
         tol = 2e-2 if k.endswith("smpl_joints2d") else 1e-4            # 2-D joints in full-image pixels (values ~1e3)
         assert a[k].shape == b[k].shape and np.abs(a[k].astype(np.float64) - b[k]).max() <= tol, (k, np.abs(a[k] - b[k]).max())
     assert a["0/verts"].shape == (6, 6890, 3) and np.abs(a["0/pose"] - a["1/pose"][:1]).max() > 1e-2
+
+
+def test_bench_line_contract(cuda):
+    """The ONE JSON line bench.py prints: every field of the driver contract, roofline with a fresh (or explicitly stale) traffic
+    source, per-step event statistics, and the CPU baseline + streaming legs on request only."""
+    r = _run(["bench.py", "--steps", "5", "--warmup", "2", "--variant", "resnet50-cliff", "--no-stream", "--no-cpu-baseline"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _json_line(r.stdout)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "step_ms_events", "dist"):
+        assert k in d, k
+    assert d["unit"] == "crops/s" and d["dtype"] == "f32" and d["data"] == "synthetic" and d["vs_baseline"] is None
+    assert d["steps"] == 5 and d["warmup"] == 2 and d["n_gpus"] == 1 and d["higher_is_better"] is True
+    assert "workload" in d["config"] and "model" not in d["config"]
+    rf = d["roofline"]
+    assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and rf["peak"] == 157.3
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and 0.2 < rf["frac"] < 1.05
+    assert (rf["traffic"] is None) == ("stale" in rf["traffic_source"] or "no committed" in rf["traffic_source"])
+    assert abs(d["value"] - 64 * 5 / (d["ms_per_step"] * 5e-3)) / d["value"] < 1e-3            # value = crops of the job / its wall time
+    ev = d["step_ms_events"]
+    assert ev["min"] <= ev["median"] <= ev["max"] and abs(ev["mean"] - d["ms_per_step"]) / ev["mean"] < 0.05
+    assert "cpu_baseline" not in d and "streaming_cfg5" not in d
