@@ -32,7 +32,13 @@ struct G1Params {
   int nC16a, in2_rs, in2_ss, H2, stride2;
 };
 
-template <int MT, int NT, int D, bool HAS_RES, bool DUAL = false>
+// SCHED = 0 leaves the order of loads and MFMAs to hipcc, which sinks every load to just before its first use: the load
+// latency is then hidden only by the second wave of the SIMD.  SCHED > 0 pins the order: one operand load of the next
+// slice but D-2 per G = SCHED & 15 MFMAs, from the start of the slice or (SCHED & 16) ending with the slice (all of
+// them in front of the MFMAs would stall the wave at the vector-memory issue).  Which is fastest depends on the tile and
+// on how many waves a SIMD gets (measured: +20 % for the K = 1024 layers at 14x14 with one wave per SIMD, -15 % for
+// 56x56 tiles with two), so it is a tuned parameter (cfg.NI).
+template <int MT, int NT, int D, bool HAS_RES, bool DUAL = false, int SCHED = 0>
 __global__ void __launch_bounds__(512)
 gemm1x1_kernel(const G1Params p) {
   const int lane = threadIdx.x & 63;
@@ -81,20 +87,30 @@ gemm1x1_kernel(const G1Params p) {
     for (int n = 0; n < NT; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   float4 a[D][NT], b[D][MT];
-  auto load = [&](int s, int c) {                        // unconditional (c is clamped by the caller)
-#pragma unroll
-    for (int n = 0; n < NT; ++n) a[s][n] = wl[(size_t)c * wslice + woff[n]];
-    if constexpr (DUAL) {
-      const bool first = c < p.nC16a;                      // wave-uniform
-      const float* src = first ? p.in + (size_t)c * p.in_ss : p.in2 + (size_t)(c - p.nC16a) * p.in2_ss;
-#pragma unroll
-      for (int m = 0; m < MT; ++m) b[s][m] = *reinterpret_cast<const float4*>(src + (first ? boff[m] : boff2[m]));
+  // one operand load of slice c into stage s: pieces 0..NT-1 = weight fragments, NT..NT+MT-1 = pixel sub-tiles
+  auto load_piece = [&](int s, int c, int i) {           // unconditional (c is clamped by the caller)
+    if (i < NT) {
+      a[s][i] = wl[(size_t)c * wslice + woff[i]];
     } else {
-#pragma unroll
-      for (int m = 0; m < MT; ++m) b[s][m] = *reinterpret_cast<const float4*>(p.in + boff[m] + (size_t)c * p.in_ss);
+      const int m = i - NT;
+      if constexpr (DUAL) {
+        const bool first = c < p.nC16a;                      // wave-uniform
+        const float* src = first ? p.in + (size_t)c * p.in_ss : p.in2 + (size_t)(c - p.nC16a) * p.in2_ss;
+        b[s][m] = *reinterpret_cast<const float4*>(src + (first ? boff[m] : boff2[m]));
+      } else {
+        b[s][m] = *reinterpret_cast<const float4*>(p.in + boff[m] + (size_t)c * p.in_ss);
+      }
     }
   };
-  auto mma = [&](int s) {
+  auto load = [&](int s, int c) {
+#pragma unroll
+    for (int i = 0; i < NT + MT; ++i) load_piece(s, c, i);
+  };
+  // the MFMAs of stage s (SCHED > 0: with the loads of slice cn into stage sn pinned between them)
+  constexpr int G = SCHED & 15;                                        // MFMAs per load
+  constexpr int K0 = (SCHED & 16) ? 4 * MT * NT - G * (NT + MT) : 0;   // first MFMA with a load in front: early or late in the slice
+  auto mma = [&](int s, bool ld, int sn, int cn) {
+    int k = 0;
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -102,8 +118,19 @@ gemm1x1_kernel(const G1Params p) {
         const float wj = (j == 0) ? a[s][n].x : (j == 1) ? a[s][n].y : (j == 2) ? a[s][n].z : a[s][n].w;
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
+          if constexpr (SCHED > 0) {
+            const int kk = k - K0;
+            if (ld && kk >= 0 && kk % G == 0 && kk / G < NT + MT) {
+              load_piece(sn, cn, kk / G);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          }
           const float bj = (j == 0) ? b[s][m].x : (j == 1) ? b[s][m].y : (j == 2) ? b[s][m].z : b[s][m].w;
           acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wj, bj, acc[m][n], 0, 0, 0);
+          if constexpr (SCHED > 0) {
+            if (ld && k >= K0 - 1 && k < K0 + G * (NT + MT)) __builtin_amdgcn_sched_barrier(0);
+          }
+          ++k;
         }
       }
   };
@@ -114,13 +141,13 @@ gemm1x1_kernel(const G1Params p) {
   for (int c0 = 0; c0 < nfull; c0 += D) {
 #pragma unroll
     for (int u = 0; u < D; ++u) {                        // slice c0 + u lives in stage u (c0 is a multiple of D)
-      load((u + D - 1) % D, min(c0 + u + D - 1, last));
-      mma(u);
+      if constexpr (SCHED == 0) load((u + D - 1) % D, min(c0 + u + D - 1, last));
+      mma(u, true, (u + D - 1) % D, min(c0 + u + D - 1, last));
     }
   }
 #pragma unroll
   for (int u = 0; u < D - 1; ++u) {                      // tail: nC16 % D slices, already (being) loaded
-    if (nfull + u < p.nC16) mma(u);
+    if (nfull + u < p.nC16) mma(u, false, 0, 0);
   }
 
   // ---- epilogue: shift (+ residual) (activation) -> L16 channel slice --------------------------------------
@@ -170,15 +197,27 @@ gemm1x1_kernel(const G1Params p) {
   }
 }
 
-template <int MT, int NT>
-int launch_d(int D, const G1Params& p, dim3 grid, int nthreads, hipStream_t stream) {
+template <int MT, int NT, int SCHED>
+int launch_s(int D, const G1Params& p, dim3 grid, int nthreads, hipStream_t stream) {
   const bool r = p.res != nullptr;
-  if (D == 2 && r) hipLaunchKernelGGL((gemm1x1_kernel<MT, NT, 2, true>), grid, dim3(nthreads), 0, stream, p);
-  else if (D == 2) hipLaunchKernelGGL((gemm1x1_kernel<MT, NT, 2, false>), grid, dim3(nthreads), 0, stream, p);
-  else if (r) hipLaunchKernelGGL((gemm1x1_kernel<MT, NT, 3, true>), grid, dim3(nthreads), 0, stream, p);
-  else hipLaunchKernelGGL((gemm1x1_kernel<MT, NT, 3, false>), grid, dim3(nthreads), 0, stream, p);
+  if (D == 2 && r) hipLaunchKernelGGL((gemm1x1_kernel<MT, NT, 2, true, false, SCHED>), grid, dim3(nthreads), 0, stream, p);
+  else if (D == 2) hipLaunchKernelGGL((gemm1x1_kernel<MT, NT, 2, false, false, SCHED>), grid, dim3(nthreads), 0, stream, p);
+  else if (r) hipLaunchKernelGGL((gemm1x1_kernel<MT, NT, 3, true, false, SCHED>), grid, dim3(nthreads), 0, stream, p);
+  else hipLaunchKernelGGL((gemm1x1_kernel<MT, NT, 3, false, false, SCHED>), grid, dim3(nthreads), 0, stream, p);
   POCO_HIP_CHECK(hipGetLastError());
   return POCO_OK;
+}
+
+// cfg.NI: 1 = hipcc's order; 2, 3, 4 = a load per 2, 4, 8 MFMAs from the start of the slice; 5, 6 = per 2, 4 at its end
+constexpr int g1_sched(int NI) { return NI == 2 ? 2 : NI == 3 ? 4 : NI == 4 ? 8 : NI == 5 ? 16 + 2 : NI == 6 ? 16 + 4 : 0; }
+template <int MT, int NT>
+int launch_d(int D, int NI, const G1Params& p, dim3 grid, int nthreads, hipStream_t stream) {
+  if (NI == 2) return launch_s<MT, NT, g1_sched(2)>(D, p, grid, nthreads, stream);
+  if (NI == 3) return launch_s<MT, NT, g1_sched(3)>(D, p, grid, nthreads, stream);
+  if (NI == 4) return launch_s<MT, NT, g1_sched(4)>(D, p, grid, nthreads, stream);
+  if (NI == 5) return launch_s<MT, NT, g1_sched(5)>(D, p, grid, nthreads, stream);
+  if (NI == 6) return launch_s<MT, NT, g1_sched(6)>(D, p, grid, nthreads, stream);
+  return launch_s<MT, NT, 0>(D, p, grid, nthreads, stream);
 }
 
 bool tile_ok(int MT, int NT) {
@@ -187,17 +226,17 @@ bool tile_ok(int MT, int NT) {
 
 }  // namespace
 
-// cfg: {MT, NT, WM, WN, R = prefetch depth D (2|3), NI = 1, ALG = 6}
+// cfg: {MT, NT, WM, WN, R = prefetch depth D (2|3), NI = load schedule (g1_sched), ALG = 6}
 bool gemm1x1_cfg_valid(const ConvDesc& d, const ConvCfg& cfg) {
   const long P = (long)d.B * ((d.H - 1) / d.stride + 1) * ((d.W - 1) / d.stride + 1);
   return d.ks == 1 && (d.stride == 1 || d.stride == 2) && d.Cin % 16 == 0 && d.Cout % 16 == 0 && tile_ok(cfg.MT, cfg.NT) &&
-         cfg.WM >= 1 && cfg.WN >= 1 && cfg.WM * cfg.WN <= 8 && (cfg.R == 2 || cfg.R == 3) && cfg.NI == 1 && P < (1L << 27) &&
+         cfg.WM >= 1 && cfg.WN >= 1 && cfg.WM * cfg.WN <= 8 && (cfg.R == 2 || cfg.R == 3) && cfg.NI >= 1 && cfg.NI <= 6 && (g1_sched(cfg.NI) & 15) * (cfg.MT + cfg.NT) <= 4 * cfg.MT * cfg.NT && P < (1L << 27) &&
          (long)d.B * d.H * d.in_cs * d.W < (1L << 31) && P * std::max(d.out_cs, d.res_cs) < (1L << 31);
 }
 
 int gemm1x1_launch(const ConvDesc& d, const ConvCfg& cfg, hipStream_t stream) {
   if (!gemm1x1_cfg_valid(d, cfg)) {
-    poco_set_error("gemm1x1: ALG 6 needs ks = 1, stride 1|2, (MT,NT) in {(2,4),(4,2),(4,4),(7,2),(7,4),(8,2)}, WM*WN <= 8, R (depth) 2|3, NI = 1");
+    poco_set_error("gemm1x1: ALG 6 needs ks = 1, stride 1|2, (MT,NT) in {(2,4),(4,2),(4,4),(7,2),(7,4),(8,2)}, WM*WN <= 8, R (depth) 2|3, NI (load schedule) 1..6 with room for its loads in a slice");
     return POCO_ERR_ARG;
   }
   if ((d.in_cs | d.in_co | d.out_cs | d.out_co | d.res_cs | d.res_co) & 3) {
@@ -220,7 +259,7 @@ int gemm1x1_launch(const ConvDesc& d, const ConvCfg& cfg, hipStream_t stream) {
   const int mtiles = (p.P + 15) / 16;
   const dim3 grid((mtiles + cfg.WM * cfg.MT - 1) / (cfg.WM * cfg.MT), (p.nT16 + cfg.WN * cfg.NT - 1) / (cfg.WN * cfg.NT));
   const int nthreads = cfg.WM * cfg.WN * 64;
-#define G1_CASE(mt, nt) if (cfg.MT == mt && cfg.NT == nt) return launch_d<mt, nt>(cfg.R, p, grid, nthreads, stream);
+#define G1_CASE(mt, nt) if (cfg.MT == mt && cfg.NT == nt) return launch_d<mt, nt>(cfg.R, cfg.NI, p, grid, nthreads, stream);
   G1_CASE(2, 4) G1_CASE(4, 2) G1_CASE(4, 4) G1_CASE(7, 2) G1_CASE(7, 4) G1_CASE(8, 2)
 #undef G1_CASE
   poco_set_error("gemm1x1: unsupported tile");

@@ -31,6 +31,9 @@ def load_table() -> Dict[str, List[int]]:
     return {}
 
 
+G1_SCHED_G = (0, 0, 2, 4, 8, 2, 4)   # ALG 6: MFMAs per pinned operand load for NI = 2..6 (gemm1x1.hip g1_sched)
+
+
 def candidates(B, H, W, Cin, Cout, ks, stride, lds_cap=150 * 1024) -> List[Tuple[int, ...]]:
     pad = (ks - 1) // 2
     Ho = (H + 2 * pad - ks) // stride + 1
@@ -41,10 +44,10 @@ def candidates(B, H, W, Cin, Cout, ks, stride, lds_cap=150 * 1024) -> List[Tuple
         return [(1, 1, wm, 1, 1, 1, 5) for wm in (1, 2, 4, 8, 16)] + [(4, 1, 1, 1, 1, min(B, 64), 1)]
     if ks == 1 and stride == 1:          # split-K GEMM straight from global memory (small planes / few pixels)
         out.update((1, 1, wm, 1, 1, 1, 5) for wm in (1, 2, 4, 8))
-    if ks == 1:                          # register-direct GEMM, no LDS (ALG 6); R = operand prefetch depth
-        for (MT, NT), (WM, WN), D in itertools.product(((2, 4), (4, 2), (4, 4), (7, 2), (7, 4), (8, 2)),
-                                                       ((1, 1), (1, 2), (2, 1), (1, 4), (2, 2), (4, 1), (1, 8), (2, 4), (4, 2), (8, 1)),
-                                                       (2, 3)):
+    if ks == 1:                          # register-direct GEMM, no LDS (ALG 6); R = operand prefetch depth; NI = load
+        for (MT, NT), (WM, WN), D in itertools.product(                   # schedule: 1 here, 2..6 tried by tune_shape
+                ((2, 4), (4, 2), (4, 4), (7, 2), (7, 4), (8, 2)),
+                ((1, 1), (1, 2), (2, 1), (1, 4), (2, 2), (4, 1), (1, 8), (2, 4), (4, 2), (8, 1)), (2, 3)):
             if WN > 1 and (WN - 1) * NT >= nT:       # a whole wave column beyond Cout
                 continue
             out.add((MT, NT, WM, WN, D, 1, 6))
@@ -133,14 +136,31 @@ def candidates(B, H, W, Cin, Cout, ks, stride, lds_cap=150 * 1024) -> List[Tuple
     return sorted(out)
 
 
-def tune_shape(L, B, H, W, Cin, Cout, ks, stride, iters=8):
-    cands = [(0, 0, 0, 0, 0, 0, 0)] + candidates(B, H, W, Cin, Cout, ks, stride)
+def solo_times(L, B, H, W, Cin, Cout, ks, stride, iters=8, with_default=False):
+    """[(ms, cfg)] of every candidate of one shape, each timed on its own (cfg all-zero = the built-in heuristic)."""
+    from ._lib import check
+    cands = ([(0, 0, 0, 0, 0, 0, 0)] if with_default else []) + candidates(B, H, W, Cin, Cout, ks, stride)
     flat = (C.c_int * (7 * len(cands)))(*[v for c in cands for v in c])
     ms = (C.c_float * len(cands))()
-    from ._lib import check
     check(L.poco_tune_conv(B, H, W, Cin, Cout, ks, stride, flat, len(cands), iters, ms, None), "poco_tune_conv")
-    res = [(ms[i], cands[i]) for i in range(len(cands)) if ms[i] > 0]
-    base = ms[0]
+    res = [(ms[i], cands[i]) for i in range(len(cands))]
+    # ALG 6 load schedules (NI 2..6) only for its best few tilings under hipcc's schedule (NI = 1)
+    g6 = [c for _, c in sorted(r for r in res if r[0] > 0 and r[1][6] == 6 and r[1][5] == 1)[:8]]
+    cands6 = [c[:5] + (ni, 6) for c in g6 for ni in range(2, 7) if G1_SCHED_G[ni] * (c[0] + c[1]) <= 4 * c[0] * c[1]]
+    if cands6:
+        flat6 = (C.c_int * (7 * len(cands6)))(*[v for c in cands6 for v in c])
+        ms6 = (C.c_float * len(cands6))()
+        check(L.poco_tune_conv(B, H, W, Cin, Cout, ks, stride, flat6, len(cands6), iters, ms6, None), "poco_tune_conv")
+        res += [(ms6[i], cands6[i]) for i in range(len(cands6))]
+    return res
+
+
+def tune_shape(L, B, H, W, Cin, Cout, ks, stride, iters=8):
+    from ._lib import check
+    timed = solo_times(L, B, H, W, Cin, Cout, ks, stride, iters, with_default=True)
+    base = timed[0][0]
+    cands = [c for _, c in timed]
+    res = [r for r in timed if r[0] > 0]
     # re-time the top few with more iterations to reduce noise
     top = sorted(res)[:6]
     cands2 = [c for _, c in top]
@@ -257,11 +277,7 @@ def tune_in_context(variant: str, B: int, top_shapes: int = 12, top_cands: int =
     for k in sorted(cost, key=lambda kk: -cost[kk])[:top_shapes]:
         idxs = shapes[k]
         H, W, Cin, Cout, ks, stride = m.conv_desc(idxs[0])[:6]
-        cands = candidates(B, H, W, Cin, Cout, ks, stride)
-        flat = (C.c_int * (7 * len(cands)))(*[v for c in cands for v in c])
-        ms = (C.c_float * len(cands))()
-        L.poco_tune_conv(B, H, W, Cin, Cout, ks, stride, flat, len(cands), 8, ms, None)
-        solo = sorted((ms[i], cands[i]) for i in range(len(cands)) if ms[i] > 0)[:top_cands]
+        solo = sorted(r for r in solo_times(L, B, H, W, Cin, Cout, ks, stride) if r[0] > 0)[:top_cands]
         cur = tuple(m.conv_cfg(idxs[0], B))
         trial = [cur] + [c for _, c in solo if tuple(c) != cur]
         best_cfg, best_t = cur, None
