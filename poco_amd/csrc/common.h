@@ -45,7 +45,9 @@ struct ConvCfg {
                // 8: ALG 7's arithmetic and geometry with specialised waves (conv_wino4p.hip): 8 MFMA waves + 4 producer
                //    waves (LDS-DMA + input transform, V staged in LDS); same cfg fields as ALG 7
                // 6: 1x1 conv (stride 1|2) as a register-direct GEMM, no LDS / barriers (gemm1x1.hip):
-               //    (MT,NT) in {(2,4),(4,2),(4,4),(7,2),(7,4),(8,2)}, R = operand prefetch depth (2|3), NI = 1
+               //    (MT,NT) in {(2,4),(4,2),(4,4),(7,2),(7,4),(8,2)}, R = operand prefetch depth (2|3), NI = load schedule 1..6
+               // 9: ALG 6 with coalesced global traffic: pixel / output tiles turned into the MFMA lane order through
+               //    wave-private LDS (gemm1x1t.hip): (MT,NT) in {(4,4),(7,2),(7,4),(8,2)}, R = NI = 1
 };
 constexpr int CONV_CFG_INTS = 7;   // ints per configuration in the C ABI / tuning table
 inline ConvCfg conv_cfg_from(const int* c) { return ConvCfg{c[0], c[1], c[2], c[3], c[4], c[5], c[6]}; }
@@ -94,6 +96,10 @@ int linear_launch(const ConvDesc& d, const ConvCfg& cfg, hipStream_t stream);
 // ---- 1x1 convs as a register-direct GEMM (gemm1x1.hip), ALG 6 ---------------------------------------
 bool gemm1x1_cfg_valid(const ConvDesc& d, const ConvCfg& cfg);
 int gemm1x1_launch(const ConvDesc& d, const ConvCfg& cfg, hipStream_t stream);
+// ---- the same with coalesced global traffic and an LDS transposition (gemm1x1t.hip), ALG 9 -----------------
+bool gemm1x1t_cfg_valid(const ConvDesc& d, const ConvCfg& cfg);
+size_t gemm1x1t_lds_bytes(const ConvDesc& d, const ConvCfg& cfg);
+int gemm1x1t_launch(const ConvDesc& d, const ConvCfg& cfg, hipStream_t stream);
 
 #include <vector>
 // ---- Winograd F(4x4,3x3) (conv_wino4.hip), ALG 7 -------------------------------------------

@@ -12,6 +12,8 @@
 // Operand roles as in the other kernels: packed weight fragments (conv_pack_weights, ks = 1) = A operand, pixels =
 // B operand, so a lane ends up with 4 consecutive output channels of one pixel -> 16-B stores.
 #include "conv_mfma_types.h"
+#include <cstdio>
+#include <cstdlib>
 
 namespace {
 
@@ -286,8 +288,20 @@ int launch_gemm1x1_dual(const float* a, int a_cs, int Ca, const float* b, int b_
   p.act = act; p.res_after_act = 0; p.relu_from = 0;
   p.dWo = make_fastdiv(Wo); p.dHo = make_fastdiv(Ho);
   const int mtiles = (p.P + 15) / 16;
-  const dim3 grid((mtiles + 6) / 7, p.nT16 / 4);
-  hipLaunchKernelGGL((gemm1x1_kernel<7, 4, 2, false, true>), grid, dim3(64), 0, stream, p);
+  // tile 7x4, depth 2; wave layout and load schedule by the pixel count (measured per ResNet-50 stage, B = 64)
+  int WM = 1, WN = 1, NI = 1;
+  static const char* ov = getenv("POCO_G1_DUAL");         // "WM,WN,NI": timing probe
+  if (ov) sscanf(ov, "%d,%d,%d", &WM, &WN, &NI);
+  p.WM = WM; p.WN = WN;
+  const dim3 grid((mtiles + 7 * WM - 1) / (7 * WM), (p.nT16 / 4 + WN - 1) / WN);
+  const dim3 block(WM * WN * 64);
+  switch (NI) {
+    case 3: hipLaunchKernelGGL((gemm1x1_kernel<7, 4, 2, false, true, g1_sched(3)>), grid, block, 0, stream, p); break;
+    case 4: hipLaunchKernelGGL((gemm1x1_kernel<7, 4, 2, false, true, g1_sched(4)>), grid, block, 0, stream, p); break;
+    case 5: hipLaunchKernelGGL((gemm1x1_kernel<7, 4, 2, false, true, g1_sched(5)>), grid, block, 0, stream, p); break;
+    case 6: hipLaunchKernelGGL((gemm1x1_kernel<7, 4, 2, false, true, g1_sched(6)>), grid, block, 0, stream, p); break;
+    default: hipLaunchKernelGGL((gemm1x1_kernel<7, 4, 2, false, true>), grid, block, 0, stream, p);
+  }
   POCO_HIP_CHECK(hipGetLastError());
   return POCO_OK;
 }

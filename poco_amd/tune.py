@@ -51,6 +51,8 @@ def candidates(B, H, W, Cin, Cout, ks, stride, lds_cap=150 * 1024) -> List[Tuple
             if WN > 1 and (WN - 1) * NT >= nT:       # a whole wave column beyond Cout
                 continue
             out.add((MT, NT, WM, WN, D, 1, 6))
+            if D == 2 and (MT, NT) in ((4, 4), (7, 2), (7, 4), (8, 2)):   # the same through the LDS transposition (ALG 9)
+                out.add((MT, NT, WM, WN, 1, 1, 9))
     for MT, NT, WM, WN in itertools.product((4, 7, 13), (1, 2, 3, 4), (1, 2, 4, 8), (1, 2, 3, 4, 6, 8)):
         if WM * WN > 8 or (MT == 13 and NT > (2 if ks == 3 else 3)) or nT % NT:
             continue

@@ -199,7 +199,13 @@ GEMM1X1 = [
     (2, 28, 28, 80, 144, 1, True),      # K = 5 slices: exercises the depth-2 and depth-3 tails
 ]
 GEMM1X1_CFG = [(2, 4, 2, 2, 2, 1, 6), (4, 2, 4, 2, 3, 1, 6), (4, 4, 1, 4, 2, 1, 6), (4, 4, 2, 2, 3, 1, 6), (7, 2, 2, 4, 3, 1, 6),
-               (7, 4, 1, 2, 2, 1, 6), (7, 4, 2, 2, 3, 1, 6), (8, 2, 8, 1, 2, 1, 6), (8, 2, 1, 1, 3, 1, 6)]
+               (7, 4, 1, 2, 2, 1, 6), (7, 4, 2, 2, 3, 1, 6), (8, 2, 8, 1, 2, 1, 6), (8, 2, 1, 1, 3, 1, 6),
+               # pinned load schedules (NI 2..6): early / late in the slice, both prefetch depths
+               (7, 2, 2, 2, 2, 2, 6), (7, 2, 1, 1, 3, 3, 6), (7, 4, 1, 1, 2, 4, 6), (7, 4, 2, 2, 3, 5, 6), (4, 2, 1, 2, 2, 6, 6),
+               (2, 4, 1, 1, 3, 5, 6), (8, 2, 2, 2, 2, 3, 6), (4, 4, 2, 1, 2, 4, 6),
+               # ALG 9: the same GEMM with coalesced global traffic through a wave-private LDS transposition (csrc/gemm1x1t.hip)
+               (7, 4, 1, 1, 1, 1, 9), (7, 4, 2, 2, 1, 1, 9), (7, 2, 2, 4, 1, 1, 9), (4, 4, 1, 4, 1, 1, 9), (8, 2, 8, 1, 1, 1, 9),
+               (8, 2, 1, 1, 1, 1, 9)]
 
 
 @pytest.mark.parametrize("cfg", GEMM1X1_CFG, ids=lambda c: "-".join(map(str, c)))

@@ -14,7 +14,9 @@ BASE = [((64, 14, 14, 1024, 256, 1, 1), [(7, 2, 1, 1, 3), (7, 2, 2, 2, 2), (7, 4
         ((64, 14, 14, 256, 1024, 1, 1), [(7, 4, 1, 1, 2), (7, 4, 2, 2, 2), (7, 2, 2, 2, 3)]),
         ((64, 28, 28, 512, 256, 1, 1), [(7, 4, 2, 2, 2), (7, 4, 1, 1, 2), (7, 2, 2, 2, 2)]),
         ((64, 56, 56, 256, 256, 1, 1), [(7, 4, 2, 2, 2), (7, 4, 1, 1, 2), (7, 4, 1, 1, 3), (7, 2, 2, 2, 2)])]
-CASES = [(sh, [c + (ni, 6) for c in cf for ni in NIS]) for sh, cf in BASE]
+CASES = [(sh, [c + (ni, 6) for c in cf for ni in NIS] +
+          [(mt, nt, wm, wn, 1, 1, 9) for (mt, nt) in ((7, 4), (7, 2), (8, 2), (4, 4)) for (wm, wn) in ((1, 1), (2, 2), (1, 4), (2, 1), (4, 1), (4, 2), (2, 4))])
+         for sh, cf in BASE]
 for shape, cfgs in CASES:
     B, H, W, Cin, Cout, ks, st = shape
     flat = (C.c_int * (7 * len(cfgs)))(*[v for c in cfgs for v in c])
