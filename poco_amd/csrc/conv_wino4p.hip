@@ -56,6 +56,12 @@ struct W4PParams {
 #define W4P_EXP 0     // timing probes (tools/build_exp.sh conv_wino4p.hip W4P_EXP n; results are then garbage): 1 producers skip the
 #endif                // transform, 2 no LDS-DMA inside the K loop, 4 MFMA waves skip the MFMAs, 8 ... skip their operand reads,
                       // 16 no per-slice barrier work at all in the producers (neither DMA nor transform)
+#ifndef W4P_RAWP
+#define W4P_RAWP 0     // 1: the producers (not the MFMA waves) issue the raw-patch LDS-DMA inside the K loop
+#endif
+#ifndef W4P_SCHED
+#define W4P_SCHED 0
+#endif
 #ifndef W4P_TRACE
 #define W4P_TRACE 0   // 1: block 0 accumulates s_memtime phase sums of MFMA wave 0 and producer wave 8 (tools/w4p_trace.py)
 #endif
@@ -131,6 +137,32 @@ __device__ __forceinline__ Tile tile_of(const W4PParams& p, int item, int grp, i
 
 __device__ __forceinline__ float f4c(const float4& v, int j) { return j == 0 ? v.x : j == 1 ? v.y : j == 2 ? v.z : v.w; }
 
+// V slot of (tile t, channel g of the slice) inside a 64-slot operand vector.  The producers work in the lane order g + 4 t (a
+// 32-lane half = 8 tiles x 4 channels: their window reads hit 32 different banks; with the MFMA operand order t + 16 g a half
+// is 16 tiles x 2 channels = 2-way conflicts on every read) and store to slot sigma; the MFMA waves (lane = t + 16 g) read slot
+// sigma.  sigma = 4 t + ((g + f(t / 4)) & 3), f = (0, 0, 2, 2): contiguous for 8 consecutive producer lanes (ds_write_b128) and
+// conflict-free for the four 16-lane groups of the MFMA waves' ds_read_b128 and the halves of their ds_read_b32.
+__device__ __forceinline__ int w4p_sigma(int t, int g) { return 4 * t + ((g + ((t >> 2) & 2)) & 3); }
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, float k, f32x2 c) { return __builtin_elementwise_fma(a, (f32x2){k, k}, c); }
+__device__ __forceinline__ f32x2 pk_fma2(f32x2 a, f32x2 k, f32x2 c) { return __builtin_elementwise_fma(a, k, c); }
+
+// Which Winograd position (xi, nu) sits in slot i (0..3 = first quad, 4..7 = second quad, 8 = the single) of MFMA wave q.
+// Wave q owns nine positions of transform rows RA(q) = (0, 1, 3, 4)[q] and RA(q) + 1, as in ALG 7, but INSIDE a wave the slots
+// follow the register pairs the packed-fp32 input transform produces per row - (nu0, nu5), (nu1, nu3), (nu2, nu4) - so that
+// the producers write their v_pk_* results to LDS without a single v_mov.  Rows r = 0, 1, 2 of a producer (xi = 3 RH + r):
+//   even q = 2 RH    : [r0: nu 0 5 1 3] [r0: nu 2 4 | r1: nu 0 5] (r1: nu 1)
+//   odd  q = 2 RH + 1: [r1: nu 2 4 | r2: nu 0 5] [r2: nu 1 3 2 4] (r1: nu 3)
+__host__ __device__ constexpr int w4p_ra(int q) { return (9 * q) / 6; }
+__host__ __device__ constexpr int w4p_row(int q, int i) {                     // 0 / 1: transform row RA(q) + that
+  return (q & 1) ? ((i < 2 || i == 8) ? 0 : 1) : (i < 6 ? 0 : 1);
+}
+__host__ __device__ constexpr int w4p_nu(int q, int i) {
+  constexpr int E[9] = {0, 5, 1, 3, 2, 4, 0, 5, 1}, O[9] = {2, 4, 0, 5, 1, 3, 2, 4, 3};
+  return (q & 1) ? O[i] : E[i];
+}
+
 
 // ---- staging (LDS-DMA) shared by whoever issues it: `nw` waves take pieces w, w + nw, ... -------------------------------
 // global float offsets of this wave's raw-patch pieces (lane = slot inside the piece), -1 = padding / beyond the patch
@@ -165,9 +197,9 @@ __device__ __forceinline__ void raw_piece_offsets(const W4PParams& p, int item, 
 // ---------------------------------------------------------------------------------------------------------------------
 template <int NT, int Q>
 __device__ __forceinline__ void w4p_consumer(const W4PParams& p, float4* smem, int grp, int lane, int wave) {
-  constexpr int P0 = 9 * Q;                 // first position of this wave
-  constexpr int RA = P0 / 6;                // its two position rows: RA (from column P0 % 6 on) and RA + 1
+  // this wave's nine positions: w4p_row / w4p_nu (transform rows RA(Q) and RA(Q) + 1)
   const int idx = lane & 15, g = lane >> 4;
+  const int vlane = w4p_sigma(idx, g);      // this lane's slot in the V operand vectors
   const int uF4 = NT * W4P_UBLK;
   const int rawF4 = p.rawF4;
   const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) float4*)smem;
@@ -222,14 +254,14 @@ __device__ __forceinline__ void w4p_consumer(const W4PParams& p, float4* smem, i
       for (int n = 0; n < NT; ++n) acc[i][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
 #if W4P_TRACE
-    const bool trace = blockIdx.x == 0 && wave == 0 && item == wk.first;
-    unsigned long long tr[4] = {0, 0, 0, 0};
+    const bool trace = blockIdx.x == 0 && item == wk.first;
+    unsigned long long tr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
     W4P_T(c_a);
     // (the producers fetched raw(0..2), U(0) during the previous item's exchange rounds and U(1) just now)
     __syncthreads();                                        // B0: the first fetches have landed (and the padding slots are zero)
     __syncthreads();                                        // B1: V(0) is written; the windows of slices 0 and 1 are in the producers' registers
-    if (S > 3) issue_raw(3, 0);
+    if (S > 3 && !W4P_RAWP) issue_raw(3, 0);
     W4P_T(c_b);
     W4P_ACC(0, c_a, c_b);
     int ring = 0;                                           // s % 3
@@ -238,10 +270,39 @@ __device__ __forceinline__ void w4p_consumer(const W4PParams& p, float4* smem, i
       const int r1 = ring == 2 ? 0 : ring + 1, r2 = r1 == 2 ? 0 : r1 + 1;
       int nvm = 0;
       const float4* U = smem + p.uoff + ring * uF4 + (2 * Q) * 64 + lane;
-      const float4* V = smem + p.voff + (s & 1) * (2 * W4P_UBLK) + grp * W4P_UBLK + (2 * Q) * 64 + lane;
+      const float4* V = smem + p.voff + (s & 1) * (2 * W4P_UBLK) + grp * W4P_UBLK + (2 * Q) * 64 + vlane;
       const bool noread = (W4P_EXP & 8) != 0;
       const float4 vq0 = noread ? make_float4(1.f, 2.f, 3.f, (float)s) : V[0], vq1 = noread ? make_float4(1.f, 2.f, 3.f, 4.f) : V[64];
-      const float vs = noread ? 2.f : reinterpret_cast<const float*>(V - (2 * Q) * 64 - lane + 512)[Q * 64 + lane];
+      const float vs = noread ? 2.f : reinterpret_cast<const float*>(V - (2 * Q) * 64 - vlane + 512)[Q * 64 + vlane];
+#if W4P_SCHED == 1
+      // U double-buffered in registers: the three operand reads of n-tile n + 1 are issued BEFORE the nine MFMAs of n-tile n
+      // (the scheduler otherwise sinks them next to their first use and every s_waitcnt lgkmcnt(0) exposes an LDS round trip)
+      float4 uq0[2], uq1[2];
+      float us[2];
+      auto ld_u = [&](int n, int b) __attribute__((always_inline)) {
+        uq0[b] = U[n * W4P_UBLK];
+        uq1[b] = U[n * W4P_UBLK + 64];
+        us[b] = reinterpret_cast<const float*>(U - (2 * Q) * 64 - lane + n * W4P_UBLK + 512)[Q * 64 + lane];
+      };
+      ld_u(0, 0);
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        if (n + 1 < NT) ld_u(n + 1, (n + 1) & 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+          const float a = i < 4 ? f4c(uq0[n & 1], i) : i < 8 ? f4c(uq1[n & 1], i - 4) : us[n & 1];
+          const float v = i < 4 ? f4c(vq0, i) : i < 8 ? f4c(vq1, i - 4) : vs;
+          acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, v, acc[i][n], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (n == 0) {
+          if (s + 2 < S) nvm += issue_u(s + 2, r2);
+          if (s + 4 < S && !W4P_RAWP) nvm += issue_raw(s + 4, r1);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+#else
 #pragma unroll
       for (int n = 0; n < NT; ++n) {                        // U of one n-tile at a time: 9 operand registers live, not 27
         const float4 uq0 = noread ? make_float4(1.f, 2.f + n, 3.f, (float)s) : U[n * W4P_UBLK];
@@ -259,16 +320,18 @@ __device__ __forceinline__ void w4p_consumer(const W4PParams& p, float4* smem, i
         if (n == 0 && !(W4P_EXP & 64)) {
           __builtin_amdgcn_sched_barrier(0);
           if (s + 2 < S && !(W4P_EXP & 2)) nvm += issue_u(s + 2, r2);       // slot of U(s-1): consumed before the barrier that ended iteration s-1
-          if (s + 4 < S && !(W4P_EXP & 2)) nvm += issue_raw(s + 4, r1);     // slot of raw(s+1): its window was read during iteration s-1
+          if (s + 4 < S && !(W4P_EXP & 2) && !W4P_RAWP) nvm += issue_raw(s + 4, r1);     // slot of raw(s+1): its window was read during iteration s-1
           __builtin_amdgcn_sched_barrier(0);
         }
       }
+#endif
+      W4P_T(c05);
       wait_vm(nvm);                                         // what this wave issued BEFORE this iteration has landed: U(s+1), raw(s+3)
       ring = r1;
       W4P_T(c1);
       __syncthreads();                                      // everybody is done with slice s; V(s+1), U(s+1), raw(s+2) are in place
       W4P_T(c2);
-      W4P_ACC(1, c0, c1); W4P_ACC(2, c1, c2);
+      W4P_ACC(1, c0, c1); W4P_ACC(2, c1, c2); W4P_ACC(4, c05, c1);
     }
     W4P_T(c_e0);
 
@@ -286,8 +349,8 @@ __device__ __forceinline__ void w4p_consumer(const W4PParams& p, float4* smem, i
           f32x4 z = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int i = 0; i < 9; ++i) {
-            const int pos = P0 + i, xi = pos / 6, nu = pos - xi * 6;
-            if (xi - RA == r && at_c(j, nu) != 0.f) z += at_c(j, nu) * acc[i][n];
+            const int nu = w4p_nu(Q, i);
+            if (w4p_row(Q, i) == r && at_c(j, nu) != 0.f) z += at_c(j, nu) * acc[i][n];
           }
           xch[((wave * 2 + r) * 4 + j) * 64 + lane] = make_float4(z[0], z[1], z[2], z[3]);
         }
@@ -339,7 +402,10 @@ __device__ __forceinline__ void w4p_consumer(const W4PParams& p, float4* smem, i
 #if W4P_TRACE
     W4P_T(c_e1);
     W4P_ACC(3, c_e0, c_e1);
-    if (trace && lane == 0) { for (int k = 0; k < 4; ++k) g_w4p_trace[k] = tr[k]; g_w4p_trace[4] = (unsigned long long)p.nC4; }
+    if (trace && lane == 0) {
+      if (wave == 0) { for (int k = 0; k < 4; ++k) g_w4p_trace[k] = tr[k]; g_w4p_trace[4] = (unsigned long long)p.nC4; }
+      g_w4p_trace[16 + 2 * wave] = tr[1]; g_w4p_trace[17 + 2 * wave] = tr[2]; g_w4p_trace[48 + wave] = tr[4];
+    }
 #endif
   }
 }
@@ -350,7 +416,8 @@ __device__ __forceinline__ void w4p_consumer(const W4PParams& p, float4* smem, i
 template <int NT, int RH>
 __device__ __forceinline__ void w4p_producer(const W4PParams& p, float4* smem, int pw, int lane) {
   const int grp = pw >> 1;
-  const int idx = lane & 15, g = lane >> 4;
+  const int idx = lane >> 2, g = lane & 3;   // transform lane order: 8 tiles x 4 channels per 32-lane half (see w4p_sigma)
+  const int vlane = w4p_sigma(idx, g);
   const int rawF4 = p.rawF4;
   const int uF4 = NT * W4P_UBLK;
   const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) float4*)smem;
@@ -412,64 +479,109 @@ __device__ __forceinline__ void w4p_producer(const W4PParams& p, float4* smem, i
     const int nt0 = (item / p.nblocks_m) * NT;
     // ---- this lane's (tile, channel) pair: float offsets of its 36 window elements in a raw slot -----------------------
     const Tile tl = tile_of(p, item, grp, idx);
-    int woff[6][6];
+    // pos(k, 0) is even (patch width and tile origins are even), so the columns (2c, 2c + 1) of a window row never straddle a
+    // multiple of 8 in the skewed slot order: their slots are neighbours (16 B apart) and ONE ds_read2_b32 fetches the pair
+    // into a 64-bit register pair = one operand of the packed-fp32 transform below.  18 addresses / reads instead of 36.
+    int woff[6][3];
 #pragma unroll
     for (int k = 0; k < 6; ++k)
 #pragma unroll
-      for (int sc = 0; sc < 6; ++sc) {
-        const int pos = tl.base + k * p.PW + sc;
-        woff[k][sc] = (pos + (pos >> 3)) * 4 + g;
+      for (int c = 0; c < 3; ++c) {
+        const int pos = tl.base + k * p.PW + 2 * c;
+        woff[k][c] = (pos + (pos >> 3)) * 4 + g;
       }
-    float d[6][6];                                            // the window of the slice that is transformed next
+    f32x2 d[6][3];                                            // the window of the slice that is transformed next (column pairs)
     auto load_window = [&](int rslot) {
       const float* rawf = reinterpret_cast<const float*>(smem + rslot * rawF4);
 #pragma unroll
       for (int k = 0; k < 6; ++k)
 #pragma unroll
-        for (int sc = 0; sc < 6; ++sc) d[k][sc] = rawf[woff[k][sc]];
+        for (int c = 0; c < 3; ++c) {
+          const float* w = rawf + woff[k][c];
+          d[k][c] = (f32x2){w[0], w[4]};
+        }
     };
+    // V = B^T d B in packed fp32 (v_pk_fma_f32 / v_pk_add_f32: half the issue slots of scalar VALU, and fp32 MFMAs share the
+    // vector ALUs with it).  Stage 1 (down the window columns) works on the column pairs as they were read; stage 2 (along a
+    // row) produces the pairs (nu0, nu5), (nu1, nu3), (nu2, nu4): 18 + 21 packed instructions for this wave's 18 positions.
     auto transform = [&](int vbuf) {                          // d -> rows 3 RH .. 3 RH + 2 of V (18 positions) of group grp
-      float t[3][6];
+      f32x2 t[3][3];
 #pragma unroll
-      for (int sc = 0; sc < 6; ++sc) {
-        t[0][sc] = bt_row<3 * RH + 0>(d[0][sc], d[1][sc], d[2][sc], d[3][sc], d[4][sc], d[5][sc]);
-        t[1][sc] = bt_row<3 * RH + 1>(d[0][sc], d[1][sc], d[2][sc], d[3][sc], d[4][sc], d[5][sc]);
-        t[2][sc] = bt_row<3 * RH + 2>(d[0][sc], d[1][sc], d[2][sc], d[3][sc], d[4][sc], d[5][sc]);
+      for (int c = 0; c < 3; ++c) {
+        const f32x2 d0 = d[0][c], d1 = d[1][c], d2 = d[2][c], d3 = d[3][c], d4 = d[4][c], d5 = d[5][c];
+        if constexpr (RH == 0) {
+          t[0][c] = pk_fma(d0, 4.f, pk_fma(d2, -5.f, d4));                       // 4 d0 - 5 d2 + d4
+          const f32x2 a = pk_fma(d2, -4.f, d4), cc = pk_fma(d1, 4.f, -d3);       // rows 1, 2 = (d4 - 4 d2) -+ (4 d1 - d3)
+          t[1][c] = a - cc;
+          t[2][c] = a + cc;
+        } else {
+          const f32x2 b = d4 - d2, e = d1 - d3;                                  // rows 3, 4 = (d4 - d2) -+ 2 (d1 - d3)
+          t[0][c] = pk_fma(e, -2.f, b);
+          t[1][c] = pk_fma(e, 2.f, b);
+          t[2][c] = pk_fma(d1, 4.f, pk_fma(d3, -5.f, d5));                       // 4 d1 - 5 d3 + d5
+        }
       }
-      float v[18];                                           // position 18 RH + j, j = 6 r + nu
+      f32x2 A[3], Bp[3], Cp[3];                               // per row: (v0, v5), (v1, v3), (v2, v4)
 #pragma unroll
       for (int r = 0; r < 3; ++r) {
-        const float* tr = t[r];
-        v[6 * r + 0] = bt_row<0>(tr[0], tr[1], tr[2], tr[3], tr[4], tr[5]);
-        v[6 * r + 1] = bt_row<1>(tr[0], tr[1], tr[2], tr[3], tr[4], tr[5]);
-        v[6 * r + 2] = bt_row<2>(tr[0], tr[1], tr[2], tr[3], tr[4], tr[5]);
-        v[6 * r + 3] = bt_row<3>(tr[0], tr[1], tr[2], tr[3], tr[4], tr[5]);
-        v[6 * r + 4] = bt_row<4>(tr[0], tr[1], tr[2], tr[3], tr[4], tr[5]);
-        v[6 * r + 5] = bt_row<5>(tr[0], tr[1], tr[2], tr[3], tr[4], tr[5]);
+        const f32x2 T0 = t[r][0], T1 = t[r][1], T2 = t[r][2];
+        A[r] = pk_fma(T0, 4.f, pk_fma(T1, -5.f, T2));                            // 4 t0 - 5 t2 + t4 | 4 t1 - 5 t3 + t5
+        const f32x2 ab = pk_fma2(T1.xx, (f32x2){-4.f, -1.f}, T2.xx);             // t4 - 4 t2 | t4 - t2
+        const f32x2 cf = pk_fma2(T0.yy, (f32x2){4.f, 2.f}, T1.yy * (f32x2){-1.f, -2.f});   // 4 t1 - t3 | 2 t1 - 2 t3
+        Bp[r] = ab - cf;
+        Cp[r] = ab + cf;
       }
-      // positions 18 RH .. 18 RH + 17 = the 9-position sets of MFMA waves q = 2 RH and 2 RH + 1 (two quads + one single each)
+      // slot order of the MFMA waves q = 2 RH and 2 RH + 1: see w4p_nu
       float4* Vg = smem + p.voff + vbuf * (2 * W4P_UBLK) + grp * W4P_UBLK;
       float* Vs = reinterpret_cast<float*>(Vg + 512);
-#pragma unroll
-      for (int ql = 0; ql < 2; ++ql) {
-        const int q = 2 * RH + ql;
-        Vg[(2 * q) * 64 + lane] = make_float4(v[9 * ql + 0], v[9 * ql + 1], v[9 * ql + 2], v[9 * ql + 3]);
-        Vg[(2 * q + 1) * 64 + lane] = make_float4(v[9 * ql + 4], v[9 * ql + 5], v[9 * ql + 6], v[9 * ql + 7]);
-        Vs[q * 64 + lane] = v[9 * ql + 8];
-      }
+      constexpr int qa = 2 * RH, qb = 2 * RH + 1;
+      if ((W4P_EXP & 256) && p.B < 100000) return;          // probe: transform without the V stores
+      Vg[(2 * qa) * 64 + vlane] = make_float4(A[0].x, A[0].y, Bp[0].x, Bp[0].y);
+      Vg[(2 * qa + 1) * 64 + vlane] = make_float4(Cp[0].x, Cp[0].y, A[1].x, A[1].y);
+      Vs[qa * 64 + vlane] = Bp[1].x;
+      Vs[qb * 64 + vlane] = Bp[1].y;
+      Vg[(2 * qb) * 64 + vlane] = make_float4(Cp[1].x, Cp[1].y, A[2].x, A[2].y);
+      Vg[(2 * qb + 1) * 64 + vlane] = make_float4(Bp[2].x, Bp[2].y, Cp[2].x, Cp[2].y);
     };
 
     const int S = p.nC4;
     if (S > 1) issue_u1(item);
+#if W4P_RAWP
+    // raw pieces pw, pw + 4, ... of this item (the patch comes from HBM / MALL: its latency is the long one, and vmcnt counts in
+    // order - on an MFMA wave a late patch piece would also hold up the wait for the U pieces issued after it)
+    int goffp[4];
+    raw_piece_offsets<4>(p, item, pw, W4P_NPROD, lane, goffp);
+    bool livep[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) livep[k] = __ballot(goffp[k] >= 0) != 0ull;
+    auto issue_raw = [&](int c4, int slot) __attribute__((always_inline)) -> int {
+      int cnt = 0;
+      const float* sbase = p.in + (size_t)(c4 >> 2) * p.in_ss + (c4 & 3) * 4;
+      const unsigned sb = lds_base + (unsigned)(slot * rawF4) * 16u;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int piece = pw + W4P_NPROD * k;
+        if (piece < npieces_raw && livep[k]) {
+          if (goffp[k] >= 0)
+            w4::dma16_sv(sbase, (unsigned)goffp[k] * 4u, (unsigned)__builtin_amdgcn_readfirstlane((int)(sb + (unsigned)piece * 1024u)));
+          ++cnt;
+        }
+      }
+      return cnt;
+    };
+#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                                        // B0: raw(0..2), U(0..1) have landed
     load_window(0);
     transform(0);
     if (S > 1) load_window(1);
     __syncthreads();                                        // B1 (the compiler waits for this wave's LDS accesses before a barrier)
+#if W4P_RAWP
+    if (S > 3) issue_raw(3, 0);
+#endif
     int ring = 0;                                           // s % 3
 #if W4P_TRACE
-    const bool trace = blockIdx.x == 0 && pw == 0 && item == wk.first;
+    const bool trace = blockIdx.x == 0 && item == wk.first;
     unsigned long long tr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
     for (int s = 0; s < S; ++s) {
@@ -477,17 +589,27 @@ __device__ __forceinline__ void w4p_producer(const W4PParams& p, float4* smem, i
       W4P_T(q0);
       // V(s+1) from the window fetched during the previous iteration, then the window of slice s+2 (raw(s+2) landed before the
       // barrier that ended iteration s-1)
+#if W4P_RAWP
+      int nvm = 0;
+      if (s + 4 < S) nvm = issue_raw(s + 4, r1);            // slot of raw(s+1): its window was read during iteration s-1
+#endif
       if (s + 1 < S && !(W4P_EXP & 17)) transform((s + 1) & 1);
       W4P_T(q1);
-      if (s + 2 < S && !(W4P_EXP & 17)) load_window(r2);
+      if (s + 2 < S && !(W4P_EXP & (17 | 128))) load_window(r2);
       W4P_T(q4);
       ring = r1;
+#if W4P_RAWP
+      wait_vm(nvm);                                         // raw(s+3), issued one iteration ago, has landed
+#endif
       __syncthreads();
       W4P_T(q6);
       W4P_ACC(0, q0, q1); W4P_ACC(3, q1, q4); W4P_ACC(5, q4, q6);
     }
 #if W4P_TRACE
-    if (trace && lane == 0) for (int k = 0; k < 6; ++k) g_w4p_trace[8 + k] = tr[k];
+    if (trace && lane == 0) {
+      if (pw == 0) for (int k = 0; k < 6; ++k) g_w4p_trace[8 + k] = tr[k];
+      g_w4p_trace[32 + 4 * pw] = tr[0]; g_w4p_trace[33 + 4 * pw] = tr[3]; g_w4p_trace[34 + 4 * pw] = tr[5];
+    }
 #endif
     if (item + wk.step < wk.end) prefetch_item(item + wk.step);          // ... while the MFMA waves exchange and store
 #pragma unroll
@@ -534,7 +656,8 @@ bool w4p_geo(const ConvDesc& d, const ConvCfg& cfg, w4::Geo* g, W4PLayout* L) {
 }  // namespace
 
 // packed fragments for ALG 8: [Cin/4][Cout16/16][9 pieces][64 lanes] float4; piece 2q+a (q = 0..3, a = 0..1): lane = g*16 + co_l holds
-// U[9q + 4a + j][co][4 c4 + g] * scale[co], j = 0..3; piece 8: float index q*64 + lane = U[9q + 8][co][4 c4 + g] * scale[co]
+// U[pos(q, 4a + j)][co][4 c4 + g] * scale[co], j = 0..3; piece 8: float index q*64 + lane = U[pos(q, 8)][co][4 c4 + g] * scale[co];
+// pos(q, i) = 6 (RA(q) + w4p_row(q, i)) + w4p_nu(q, i) (the slot order of the packed input transform, see w4p_nu)
 size_t conv_wino4p_packed_floats(int Cin, int Cout16) { return (size_t)36 * Cin * Cout16; }
 void conv_wino4p_pack_weights(const float* w_oihw, const float* scale, int Cout, int Cin, int Cout16, float* dst) {
   std::vector<double> u;
@@ -549,9 +672,10 @@ void conv_wino4p_pack_weights(const float* w_oihw, const float* scale, int Cout,
       for (int lane = 0; lane < 64; ++lane) {
         const int g = lane >> 4, co = nt * 16 + (lane & 15), ci = 4 * c4 + g;
         for (int q = 0; q < 4; ++q) {
+          auto pos = [&](int i) { return 6 * (w4p_ra(q) + w4p_row(q, i)) + w4p_nu(q, i); };
           for (int a = 0; a < 2; ++a)
-            for (int j = 0; j < 4; ++j) blk[((2 * q + a) * 64 + lane) * 4 + j] = val(9 * q + 4 * a + j, co, ci);
-          blk[8 * 256 + q * 64 + lane] = val(9 * q + 8, co, ci);
+            for (int j = 0; j < 4; ++j) blk[((2 * q + a) * 64 + lane) * 4 + j] = val(pos(4 * a + j), co, ci);
+          blk[8 * 256 + q * 64 + lane] = val(pos(8), co, ci);
         }
       }
     }

@@ -20,3 +20,5 @@ for (B, H, W, Cin, Cout), cfg in [((64, 56, 56, 48, 48), (1, 3, 2, 4, 8, 1, 8)),
     print(f"  MFMA wave 0: prologue wait {buf[0]} clk | per slice: work {buf[1]/S:.0f} clk, barrier wait {buf[2]/S:.0f} clk | epilogue {buf[3]} clk")
     names = ["transform burst", "store U (+wait loads)", "load U + raw DMA issue", "window reads (issue)", "wait_vm", "barrier wait"]
     print("  producer 0 per slice: " + " | ".join(f"{n} {buf[8+k]/S:.0f}" for k, n in enumerate(names)))
+    print("  all MFMA waves (work / barrier wait per slice): " + "  ".join(f"w{w}: {buf[16+2*w]/S:.0f}({buf[48+w]/S:.0f} in wait_vm)/{buf[17+2*w]/S:.0f}" for w in range(8)))
+    print("  all producers (transform+V store / window reads / barrier wait per slice): " + "  ".join(f"p{w}: {buf[32+4*w]/S:.0f}/{buf[33+4*w]/S:.0f}/{buf[34+4*w]/S:.0f}" for w in range(4)))
