@@ -31,6 +31,7 @@
 // in LDS order: [q = 0..3][2 quads][64 lanes] float4 (positions 9q..9q+7), then [q][64 lanes] float (position 9q+8);
 // lane = (co & 15) + 16 (ci & 3).  One block = nine 1 KiB LDS-DMA pieces.
 #include "conv_wino4_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -713,10 +714,16 @@ int conv_wino4p_launch(const ConvDesc& d, const ConvCfg& cfg, hipStream_t stream
   p.dTX = make_fastdiv(g.TX); p.dTslab = make_fastdiv(g.tps);
   p.nblocks_m = (g.S + g.NI - 1) / g.NI; p.nb_n = (p.nT16 + cfg.NT - 1) / cfg.NT;
   // balanced persistent grid: every block walks the same number of items (one block per CU)
+  // cfg.MT = CU share divisor: the grid is sized for 256 / MT CUs.  A block needs a whole CU (LDS), all blocks of a launch run
+  // their K loops (MFMA-bound, HBM nearly idle) and their store phases (HBM-write-bound, MFMA idle) in lockstep; two launches
+  // of different lanes on half of the CUs each run out of phase and overlap one's stores with the other's MFMAs.
+  static const int mt_env = [] { const char* e = getenv("POCO_W4P_MT"); return e ? atoi(e) : 0; }();
+  const int mt = std::max(1, mt_env > 0 ? mt_env : cfg.MT);
+  const long cus = std::max(8, 256 / mt);
   const long items = (long)p.nblocks_m * p.nb_n;
-  const long rounds = (items + 255) / 256;
+  const long rounds = (items + cus - 1) / cus;
   long g4 = (items + rounds - 1) / rounds;
-  if (g4 > 8) g4 = std::min(256L, (g4 + 7) / 8 * 8);           // multiple of 8 for the XCD-aware walk
+  if (g4 > 8) g4 = std::min(cus, (g4 + 7) / 8 * 8);            // multiple of 8 for the XCD-aware walk
   const size_t lds = (size_t)L.totalF4 * sizeof(float4);
   auto fn = cfg.NT == 3 ? conv_wino4p_kernel<3> : cfg.NT == 2 ? conv_wino4p_kernel<2> : conv_wino4p_kernel<1>;
   if (lds > 64 * 1024) {
