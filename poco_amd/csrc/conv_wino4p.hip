@@ -56,15 +56,14 @@ struct W4PParams {
 #ifndef W4P_EXP
 #define W4P_EXP 0     // timing probes (tools/build_exp.sh conv_wino4p.hip W4P_EXP n; results are then garbage): 1 producers skip the
 #endif                // transform, 2 no LDS-DMA inside the K loop, 4 MFMA waves skip the MFMAs, 8 ... skip their operand reads,
-                      // 16 no per-slice barrier work at all in the producers (neither DMA nor transform)
-#ifndef W4P_RAWP
-#define W4P_RAWP 0     // 1: the producers (not the MFMA waves) issue the raw-patch LDS-DMA inside the K loop
-#endif
-#ifndef W4P_SCHED
-#define W4P_SCHED 0
-#endif
+                      // 16 no per-slice barrier work at all in the producers (neither DMA nor transform), 128 producers skip the window
+                      // reads only, 512 / 1024 no U / no patch LDS-DMA inside the K loop
 #ifndef W4P_TRACE
-#define W4P_TRACE 0   // 1: block 0 accumulates s_memtime phase sums of MFMA wave 0 and producer wave 8 (tools/w4p_trace.py)
+#define W4P_TRACE 0   // 1: block 0 accumulates s_memtime phase sums of its 8 MFMA waves and 4 producer waves (tools/w4p_trace.py; reading the
+                      // counter drains lgkmcnt, so a phase that ends with LDS reads in flight includes their latency)
+#endif
+#ifndef W4P_TRACE_ITEM
+#define W4P_TRACE_ITEM 0   // which item of block 0's walk is traced (0 = the first, cold one)
 #endif
 #if W4P_TRACE
 __device__ unsigned long long g_w4p_trace[64];
@@ -255,14 +254,14 @@ __device__ __forceinline__ void w4p_consumer(const W4PParams& p, float4* smem, i
       for (int n = 0; n < NT; ++n) acc[i][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
 #if W4P_TRACE
-    const bool trace = blockIdx.x == 0 && item == wk.first;
+    const bool trace = blockIdx.x == 0 && item == wk.first + W4P_TRACE_ITEM * wk.step;
     unsigned long long tr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
     W4P_T(c_a);
     // (the producers fetched raw(0..2), U(0) during the previous item's exchange rounds and U(1) just now)
     __syncthreads();                                        // B0: the first fetches have landed (and the padding slots are zero)
     __syncthreads();                                        // B1: V(0) is written; the windows of slices 0 and 1 are in the producers' registers
-    if (S > 3 && !W4P_RAWP) issue_raw(3, 0);
+    if (S > 3) issue_raw(3, 0);
     W4P_T(c_b);
     W4P_ACC(0, c_a, c_b);
     int ring = 0;                                           // s % 3
@@ -275,35 +274,6 @@ __device__ __forceinline__ void w4p_consumer(const W4PParams& p, float4* smem, i
       const bool noread = (W4P_EXP & 8) != 0;
       const float4 vq0 = noread ? make_float4(1.f, 2.f, 3.f, (float)s) : V[0], vq1 = noread ? make_float4(1.f, 2.f, 3.f, 4.f) : V[64];
       const float vs = noread ? 2.f : reinterpret_cast<const float*>(V - (2 * Q) * 64 - vlane + 512)[Q * 64 + vlane];
-#if W4P_SCHED == 1
-      // U double-buffered in registers: the three operand reads of n-tile n + 1 are issued BEFORE the nine MFMAs of n-tile n
-      // (the scheduler otherwise sinks them next to their first use and every s_waitcnt lgkmcnt(0) exposes an LDS round trip)
-      float4 uq0[2], uq1[2];
-      float us[2];
-      auto ld_u = [&](int n, int b) __attribute__((always_inline)) {
-        uq0[b] = U[n * W4P_UBLK];
-        uq1[b] = U[n * W4P_UBLK + 64];
-        us[b] = reinterpret_cast<const float*>(U - (2 * Q) * 64 - lane + n * W4P_UBLK + 512)[Q * 64 + lane];
-      };
-      ld_u(0, 0);
-#pragma unroll
-      for (int n = 0; n < NT; ++n) {
-        if (n + 1 < NT) ld_u(n + 1, (n + 1) & 1);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < 9; ++i) {
-          const float a = i < 4 ? f4c(uq0[n & 1], i) : i < 8 ? f4c(uq1[n & 1], i - 4) : us[n & 1];
-          const float v = i < 4 ? f4c(vq0, i) : i < 8 ? f4c(vq1, i - 4) : vs;
-          acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, v, acc[i][n], 0, 0, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        if (n == 0) {
-          if (s + 2 < S) nvm += issue_u(s + 2, r2);
-          if (s + 4 < S && !W4P_RAWP) nvm += issue_raw(s + 4, r1);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
-#else
 #pragma unroll
       for (int n = 0; n < NT; ++n) {                        // U of one n-tile at a time: 9 operand registers live, not 27
         const float4 uq0 = noread ? make_float4(1.f, 2.f + n, 3.f, (float)s) : U[n * W4P_UBLK];
@@ -320,12 +290,11 @@ __device__ __forceinline__ void w4p_consumer(const W4PParams& p, float4* smem, i
         // takes this wave ~60 clk to issue; behind queued MFMAs that is hidden, ahead of them the pipe would idle.
         if (n == 0 && !(W4P_EXP & 64)) {
           __builtin_amdgcn_sched_barrier(0);
-          if (s + 2 < S && !(W4P_EXP & 2)) nvm += issue_u(s + 2, r2);       // slot of U(s-1): consumed before the barrier that ended iteration s-1
-          if (s + 4 < S && !(W4P_EXP & 2) && !W4P_RAWP) nvm += issue_raw(s + 4, r1);     // slot of raw(s+1): its window was read during iteration s-1
+          if (s + 2 < S && !(W4P_EXP & (2 | 512))) nvm += issue_u(s + 2, r2);       // slot of U(s-1): consumed before the barrier that ended iteration s-1
+          if (s + 4 < S && !(W4P_EXP & (2 | 1024))) nvm += issue_raw(s + 4, r1);     // slot of raw(s+1): its window was read during iteration s-1
           __builtin_amdgcn_sched_barrier(0);
         }
       }
-#endif
       W4P_T(c05);
       wait_vm(nvm);                                         // what this wave issued BEFORE this iteration has landed: U(s+1), raw(s+3)
       ring = r1;
@@ -536,7 +505,6 @@ __device__ __forceinline__ void w4p_producer(const W4PParams& p, float4* smem, i
       float4* Vg = smem + p.voff + vbuf * (2 * W4P_UBLK) + grp * W4P_UBLK;
       float* Vs = reinterpret_cast<float*>(Vg + 512);
       constexpr int qa = 2 * RH, qb = 2 * RH + 1;
-      if ((W4P_EXP & 256) && p.B < 100000) return;          // probe: transform without the V stores
       Vg[(2 * qa) * 64 + vlane] = make_float4(A[0].x, A[0].y, Bp[0].x, Bp[0].y);
       Vg[(2 * qa + 1) * 64 + vlane] = make_float4(Cp[0].x, Cp[0].y, A[1].x, A[1].y);
       Vs[qa * 64 + vlane] = Bp[1].x;
@@ -547,42 +515,15 @@ __device__ __forceinline__ void w4p_producer(const W4PParams& p, float4* smem, i
 
     const int S = p.nC4;
     if (S > 1) issue_u1(item);
-#if W4P_RAWP
-    // raw pieces pw, pw + 4, ... of this item (the patch comes from HBM / MALL: its latency is the long one, and vmcnt counts in
-    // order - on an MFMA wave a late patch piece would also hold up the wait for the U pieces issued after it)
-    int goffp[4];
-    raw_piece_offsets<4>(p, item, pw, W4P_NPROD, lane, goffp);
-    bool livep[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) livep[k] = __ballot(goffp[k] >= 0) != 0ull;
-    auto issue_raw = [&](int c4, int slot) __attribute__((always_inline)) -> int {
-      int cnt = 0;
-      const float* sbase = p.in + (size_t)(c4 >> 2) * p.in_ss + (c4 & 3) * 4;
-      const unsigned sb = lds_base + (unsigned)(slot * rawF4) * 16u;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int piece = pw + W4P_NPROD * k;
-        if (piece < npieces_raw && livep[k]) {
-          if (goffp[k] >= 0)
-            w4::dma16_sv(sbase, (unsigned)goffp[k] * 4u, (unsigned)__builtin_amdgcn_readfirstlane((int)(sb + (unsigned)piece * 1024u)));
-          ++cnt;
-        }
-      }
-      return cnt;
-    };
-#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                                        // B0: raw(0..2), U(0..1) have landed
     load_window(0);
     transform(0);
     if (S > 1) load_window(1);
     __syncthreads();                                        // B1 (the compiler waits for this wave's LDS accesses before a barrier)
-#if W4P_RAWP
-    if (S > 3) issue_raw(3, 0);
-#endif
     int ring = 0;                                           // s % 3
 #if W4P_TRACE
-    const bool trace = blockIdx.x == 0 && item == wk.first;
+    const bool trace = blockIdx.x == 0 && item == wk.first + W4P_TRACE_ITEM * wk.step;
     unsigned long long tr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
     for (int s = 0; s < S; ++s) {
@@ -590,18 +531,11 @@ __device__ __forceinline__ void w4p_producer(const W4PParams& p, float4* smem, i
       W4P_T(q0);
       // V(s+1) from the window fetched during the previous iteration, then the window of slice s+2 (raw(s+2) landed before the
       // barrier that ended iteration s-1)
-#if W4P_RAWP
-      int nvm = 0;
-      if (s + 4 < S) nvm = issue_raw(s + 4, r1);            // slot of raw(s+1): its window was read during iteration s-1
-#endif
       if (s + 1 < S && !(W4P_EXP & 17)) transform((s + 1) & 1);
       W4P_T(q1);
       if (s + 2 < S && !(W4P_EXP & (17 | 128))) load_window(r2);
       W4P_T(q4);
       ring = r1;
-#if W4P_RAWP
-      wait_vm(nvm);                                         // raw(s+3), issued one iteration ago, has landed
-#endif
       __syncthreads();
       W4P_T(q6);
       W4P_ACC(0, q0, q1); W4P_ACC(3, q1, q4); W4P_ACC(5, q4, q6);
