@@ -282,6 +282,9 @@ def tune_in_context(variant: str, B: int, top_shapes: int = 12, top_cands: int =
         solo = sorted(r for r in solo_times(L, B, H, W, Cin, Cout, ks, stride) if r[0] > 0)[:top_cands]
         cur = tuple(m.conv_cfg(idxs[0], B))
         trial = [cur] + [c for _, c in solo if tuple(c) != cur]
+        # ALG 8 on half of the CUs (cfg.MT = 2): always slower alone, but two such launches of different lanes then run out of
+        # phase (one's HBM-write-bound store rounds under the other's MFMA-bound K loops)
+        trial += [(2,) + tuple(c[1:]) for c in trial[:3] if c[6] == 8 and c[0] == 1]
         best_cfg, best_t = cur, None
         for cfg in trial:
             try:
