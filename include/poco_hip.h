@@ -134,6 +134,20 @@ int poco_bench_conv2d(const float* d_in, int B, int H, int W, int Cin, const flo
                       int ks, int stride, float* d_out, const int* cfg7, int iters, float* ms_out,
                       int* cfg_used6, void* stream);
 
+/* Part-attention pooling == pocolib/models/layers/keypoint_attention.py:34-48 (KeypointAttention.forward with
+ * use_conv = False, softmax over the pixels) as pare_head.py:794-796 calls it (heat-map channel 0 = background is skipped):
+ *   out[b, c, j] = sum_p softmax_p(heat[b, p, 1 + j]) * feat[b, p, c],  j = 0..23.
+ * d_heat [B,H,heat_cs/16,W,16] (L16, heat_cs >= 32: channels 1..24 are the parts), d_feat [B,H,C/16,W,16] (L16, C a multiple of
+ * 16, <= 128), d_out [B, C, 24]. */
+int poco_op_part_attention(const float* d_heat, int heat_cs, const float* d_feat, int C, int B, int H, int W,
+                           float* d_out, void* stream);
+/* LocallyConnected2d(128 -> 6, output_size [24,1], kernel 1, no bias) == pocolib/models/layers/locallyconnected2d.py:27-37
+ * as pare_head.py builds its pose_mlp: pose6d[b, j, o] = sum_c x[b, c, j] * w[o, c, j].
+ * d_x [B,128,24], d_w [6,128,24], d_pose6d [B,24,6]. */
+int poco_op_lc2d_pose(const float* d_x, const float* d_w, float* d_pose6d, int B, void* stream);
+/* rot6d_to_rotmat == pocolib/utils/geometry.py:247-261: d_in [B,24,3,2] (144 floats per crop) -> d_rotmat [B,24,3,3]. */
+int poco_op_rot6d(const float* d_in, float* d_rotmat, int B, void* stream);
+
 /* GPU-side crop + normalise: replaces the per-detection CPU loop cv2.warpAffine(INTER_LINEAR,
  * BORDER_CONSTANT) -> ToTensor -> Normalize + per-crop H2D copy of pocolib/core/tester.py:182-203 and
  * pocolib/utils/vibe_image_utils.py:94-107,233-266,343-351.

@@ -195,3 +195,37 @@ extern "C" int poco_crop_normalize(const unsigned char* d_frame, int H, int W, c
   if (e != hipSuccess) { poco_set_error(std::string("poco_crop_normalize: ") + hipGetErrorString(e)); return POCO_ERR_HIP; }
   return POCO_OK;
 }
+
+// ---- head operators on their own (parity tests against vectors made by the reference's modules) --------------------------
+#include "kernels.h"
+
+extern "C" int poco_op_part_attention(const float* d_heat, int heat_cs, const float* d_feat, int C, int B, int H, int W,
+                                      float* d_out, void* stream) {
+  if (!d_heat || !d_feat || !d_out) { poco_set_error("part_attention: null pointer"); return POCO_ERR_ARG; }
+  if (heat_cs < 32 || (heat_cs & 15) || C < 16 || C > 128 || (C & 15) || B < 1 || H < 1 || W < 1) {
+    poco_set_error("part_attention: needs heat_cs >= 32 and C <= 128, both multiples of 16 (L16 layout)");
+    return POCO_ERR_ARG;
+  }
+  float* scratch = nullptr;
+  POCO_HIP_CHECK(hipMalloc(&scratch, part_attention_scratch_floats(B, C) * sizeof(float)));
+  launch_part_attention_pool_ws(d_heat, heat_cs, d_feat, C, d_out, C * 24, B, H, W, scratch, (hipStream_t)stream);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+  (void)hipFree(scratch);
+  POCO_HIP_CHECK(e);
+  return POCO_OK;
+}
+
+extern "C" int poco_op_lc2d_pose(const float* d_x, const float* d_w, float* d_pose6d, int B, void* stream) {
+  if (!d_x || !d_w || !d_pose6d || B < 1) { poco_set_error("lc2d_pose: bad argument"); return POCO_ERR_ARG; }
+  launch_lc2d_pose(d_x, 128 * 24, d_w, d_pose6d, B, (hipStream_t)stream);
+  POCO_HIP_CHECK(hipGetLastError());
+  return POCO_OK;
+}
+
+extern "C" int poco_op_rot6d(const float* d_in, float* d_rotmat, int B, void* stream) {
+  if (!d_in || !d_rotmat || B < 1) { poco_set_error("rot6d: bad argument"); return POCO_ERR_ARG; }
+  launch_rot6d(d_in, 144, d_rotmat, 216, nullptr, 0, B, (hipStream_t)stream);
+  POCO_HIP_CHECK(hipGetLastError());
+  return POCO_OK;
+}

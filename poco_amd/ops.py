@@ -71,3 +71,38 @@ def bench_conv2d(x: torch.Tensor, weight: np.ndarray, stride=1, cfg=None, iters=
     check(rc, "poco_bench_conv2d")
     flops = 2.0 * B * Ho * Wo * Cout * Cin * ks * ks
     return ms.value, flops / (ms.value * 1e-3) / 1e12, tuple(used)
+
+
+def part_attention(feat_nchw: torch.Tensor, heat_nchw: torch.Tensor) -> torch.Tensor:
+    """KeypointAttention as the PARE head uses it: feat [B,C,H,W], heat [B,24,H,W] (the 24 part maps, no background channel)
+    -> [B,C,24].  Channels are padded to the library's L16 layout here (tests only; the engine never leaves L16)."""
+    B, Cc, H, W = feat_nchw.shape
+    assert heat_nchw.shape == (B, 24, H, W) and feat_nchw.is_cuda
+    C16 = (Cc + 15) // 16 * 16
+    f = torch.zeros((B, H, W, C16), device=feat_nchw.device)
+    f[..., :Cc] = feat_nchw.permute(0, 2, 3, 1)
+    h = torch.zeros((B, H, W, 32), device=feat_nchw.device)
+    h[..., 1:25] = heat_nchw.permute(0, 2, 3, 1)            # channel 0 = background, skipped by the kernel
+    fl, hl = to_l16(f), to_l16(h)
+    out = torch.empty((B, C16, 24), device=feat_nchw.device)
+    check(lib().poco_op_part_attention(fptr(hl), 32, fptr(fl), C16, B, H, W, fptr(out), current_stream()),
+          "poco_op_part_attention")
+    return out[:, :Cc]
+
+
+def lc2d_pose(x: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
+    """x [B,128,24] , w [6,128,24] -> [B,24,6] (LocallyConnected2d 128 -> 6 per joint)."""
+    B = x.shape[0]
+    assert x.shape[1:] == (128, 24) and w.shape == (6, 128, 24) and x.is_cuda
+    out = torch.empty((B, 24, 6), device=x.device)
+    check(lib().poco_op_lc2d_pose(fptr(x.contiguous()), fptr(w.contiguous()), fptr(out), B, current_stream()), "poco_op_lc2d_pose")
+    return out
+
+
+def rot6d(x: torch.Tensor) -> torch.Tensor:
+    """x [B,24,6] (each row = a 3x2 matrix, row-major as in the reference) -> rotation matrices [B,24,3,3]."""
+    B = x.shape[0]
+    assert x.shape[1:] == (24, 6) and x.is_cuda
+    out = torch.empty((B, 24, 3, 3), device=x.device)
+    check(lib().poco_op_rot6d(fptr(x.contiguous()), fptr(out), B, current_stream()), "poco_op_rot6d")
+    return out
