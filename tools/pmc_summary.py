@@ -23,7 +23,7 @@ ROOT = Path(__file__).resolve().parent.parent
 def csrc_digest() -> str:
     h = hashlib.sha256()
     for f in sorted((ROOT / "poco_amd" / "csrc").glob("*")):
-        if f.suffix in (".hip", ".h", ".cpp"):
+        if f.suffix in (".hip", ".h", ".cpp") and f.name != "ops_capi.hip":   # (the stand-alone operators' C wrappers are not on the forward path)
             h.update(f.name.encode())
             h.update(f.read_bytes())
     return h.hexdigest()[:16]
