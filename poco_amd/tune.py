@@ -116,7 +116,8 @@ def candidates(B, H, W, Cin, Cout, ks, stride, lds_cap=150 * 1024) -> List[Tuple
     if ks == 3 and stride == 1 and H >= 14 and W >= 14:      # Winograd F(4x4,3x3): ALG 7 (planes >= 28x28) / ALG 8 (>= 14x14); 2 tile groups x 4 position quarters
         TX4, Hc = (W + 3) // 4, (H + 3) // 4 * 4
         for NT in (1, 2, 3):
-            if nT % NT and nT > NT:
+            ragged = nT % NT and nT > NT       # last n-tile group partly empty: ALG 8 handles it (clamped U fetch, masked stores)
+            if ragged and not (NT == 3 and nT % 3 == 2 and nT >= 8):      # worth it only when one of >= 9 slots idles
                 continue
             for R in range(4, Hc + 1, 4):
                 tps = (R // 4) * TX4
@@ -128,7 +129,7 @@ def candidates(B, H, W, Cin, Cout, ks, stride, lds_cap=150 * 1024) -> List[Tuple
                         continue
                     npos = ni * (R + 2) * (4 * TX4 + 2)
                     raw = (npos + npos // 8 + 1 + 63) // 64 * 64
-                    if H >= 28 and W >= 28 and raw <= 1024 and 2 * max(2 * (raw + 9 * NT * 64), 4096) * 16 <= 160 * 1024:
+                    if not ragged and H >= 28 and W >= 28 and raw <= 1024 and 2 * max(2 * (raw + 9 * NT * 64), 4096) * 16 <= 160 * 1024:
                         out.add((1, NT, 2, 4, R, ni, 7))
                     # ALG 8 (specialised waves): raw ring 3 deep (<= 1024 slots per slice), U ring 3 deep, V 2 deep, exchange overlay
                     u, v = NT * 576, 2 * 576
