@@ -17,8 +17,10 @@
 //     address arithmetic: ~50 instructions per 27 MFMAs instead of ~190.
 //   * waves 8-11, the producers (group = (wave-8) >> 1, transform rows 3h..3h+2 for h = (wave-8) & 1): they stream the
 //     raw patch and the U fragments of the coming slices into LDS rings with LDS-DMA (global_load_lds_dwordx4), and
-//     compute V = B^T d B of the NEXT slice for their group ONCE (a lane = one (tile, channel) pair: 36 window reads,
-//     18 + 18 row transforms, 4 ds_write_b128 + 2 ds_write_b32) while the MFMA waves work on the current one.  Their
+//     compute V = B^T d B of the NEXT slice for their group ONCE (a lane = one (tile, channel) pair in the order channel + 4 tile:
+//     15 ds_read2_b32 fetch the window as column pairs, 18 + 21 packed-fp32 instructions transform it, 4 ds_write_b128 + 2
+//     ds_write_b32 store the 18 positions in the pair order of the results, see w4p_nu / w4p_sigma) while the MFMA waves work
+//     on the current one.  Their
 //     VALU / LDS / VMEM instructions issue in the slots the MFMA pipe leaves free on their SIMD (one MFMA occupies the
 //     pipe for 8 issue slots).  In ALG 7 the four waves of a group each read the whole window (144 reads per pair).
 //   * one s_barrier per slice hands V(s+1), U(s+1) and raw(s+2) over; raw ring 3 deep (LDS-DMA issued four slices ahead,

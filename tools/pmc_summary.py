@@ -25,7 +25,9 @@ def csrc_digest() -> str:
     for f in sorted((ROOT / "poco_amd" / "csrc").glob("*")):
         if f.suffix in (".hip", ".h", ".cpp") and f.name != "ops_capi.hip":   # (the stand-alone operators' C wrappers are not on the forward path)
             h.update(f.name.encode())
-            h.update(f.read_bytes())
+            # code only: // comments and blank lines do not invalidate a profile
+            code = [ln.split("//")[0].rstrip() for ln in f.read_text().splitlines()]
+            h.update("\n".join(ln for ln in code if ln.strip()).encode())
     return h.hexdigest()[:16]
 
 
