@@ -79,7 +79,12 @@ def pmc_traffic(variant, B):
                       f"{csrc_digest()} (re-run tools/refresh_profiles.sh on the GPU box)")
     fw = float(meta.get("forwards", 5))
     tot = sum((2.0 * v.get("FETCH_SIZE", 0.0) + v.get("WRITE_SIZE", 0.0)) for k, v in d.items() if not k.startswith("_"))
+    global _PMC_MFMA_BUSY_PER_SIMD
+    _PMC_MFMA_BUSY_PER_SIMD = sum(v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) for k, v in d.items() if not k.startswith("_")) / fw / 1024.0
     return round(tot * 1024.0 / fw), f"{cands[-1].name} (same kernel sources, {int(fw)} forwards per PMC pass)"
+
+
+_PMC_MFMA_BUSY_PER_SIMD = None    # MFMA-pipe busy cycles per SIMD and forward from the same committed PMC pass (set by pmc_traffic)
 
 
 # ------------------------------------------------------------------------------------------------------------
@@ -390,6 +395,13 @@ def main():
                                  "of the kernel time, profiles/); `dominant` = the kernel symbol with the most time, "
                                  "algorithmic flops of its launches / their HIP-event time on one stream"},
         }
+        if _PMC_MFMA_BUSY_PER_SIMD:
+            # north_star asks for the MFMA utilisation next to the roofline fraction: executed MFMA time (Winograd executes 2.2x
+            # fewer MFMAs than the algorithmic count) over this run's forward time at the nominal 2.4 GHz
+            line["roofline"]["mfma_pipe_busy"] = {
+                "frac_at_2.4GHz": round(_PMC_MFMA_BUSY_PER_SIMD / (ev_ms * 1e-3 * 2.4e9), 4),
+                "busy_cycles_per_simd_per_forward": round(_PMC_MFMA_BUSY_PER_SIMD),
+                "source": "SQ_VALU_MFMA_BUSY_CYCLES of the committed PMC pass (single lane) / 1024 SIMDs / (this run's mean forward time x 2.4 GHz)"}
         if gather_check is not None:
             line["dist"]["gather_check"] = ("ok: all gathered rows bitwise equal to the per-rank forwards" if gather_check
                                             else "FAILED")
