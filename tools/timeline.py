@@ -39,3 +39,20 @@ for s, e, n, q in fw:
     a[0] += 1; a[1] += e - s
 for n, (c, d) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:8]:
     print(f"  {n:42s} n={c:4d} sum {d / 1e3:8.0f} us avg {d / c / 1e3:7.1f} us")
+
+# which kernels run ALONE (concurrency 1): wall time attributed to the single resident kernel, by symbol
+solo = defaultdict(float)
+active = []
+pts = sorted([(s, 0, i) for i, (s, e, n, q) in enumerate(fw)] + [(e, 1, i) for i, (s, e, n, q) in enumerate(fw)])
+live, last = set(), t0
+for t, kind, i in pts:
+    if len(live) == 1:
+        solo[fw[next(iter(live))][2][:70]] += t - last
+    if kind == 0:
+        live.add(i)
+    else:
+        live.discard(i)
+    last = t
+print("wall time with exactly one kernel resident, by kernel:")
+for n, v in sorted(solo.items(), key=lambda kv: -kv[1])[:14]:
+    print(f"  {v / 1e3:8.1f} us  {n}")
