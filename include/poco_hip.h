@@ -64,6 +64,8 @@ typedef struct {
   float* uncert_feat;        /* [B,3072] pare / [B,2048] cliff                           */
   float* pred_segm_mask;     /* [B,25,56,56] NCHW, pare only                             */
   float* body_feat2;         /* [B,1024] cliff only                                      */
+  float* backbone_feat;      /* [B,480,56,56] NCHW, hrnet_w32 only: the backbone's output map  */
+                             /* (hrnet.py:515-519), for parity checks; NULL in production      */
 } poco_outputs_t;
 
 /* variant = "<backbone>-<head>" exactly as POCO.BACKBONE in the yaml (poco.py:41):

@@ -43,7 +43,7 @@ enum OpType {
 // external buffer slots (inputs / outputs of poco_forward)
 enum Ext {
   X_NONE = 0, X_IMG, X_BBOX, X_FOCAL, X_SCALE, X_CENTER, X_ORIG,
-  Y_POSE, Y_POSE6D, Y_SHAPE, Y_CAM, Y_CAM_T, Y_FULL_CAM_T, Y_VERTS, Y_J3D, Y_J2D, Y_VAR, Y_UFEAT, Y_SEGM,
+  Y_POSE, Y_POSE6D, Y_SHAPE, Y_CAM, Y_CAM_T, Y_FULL_CAM_T, Y_VERTS, Y_J3D, Y_J2D, Y_VAR, Y_UFEAT, Y_SEGM, Y_BBFEAT,
   Y_BODY2
 };
 
@@ -754,6 +754,9 @@ bool build_graph(Engine& e, bool declare) {
                    lastt ? Builder::R(feat480, offs[br]) : Ref());
       }
     }
+    // optional copy of the 480-channel map for parity checks (skipped when the caller passes no pointer)
+    { Op op; op.type = OP_NCHW_OUT; op.name = "out.backbone_feat"; op.in = Builder::R(feat480); op.out = Builder::X(Y_BBFEAT);
+      op.C = 480; b.push(std::move(op)); }
     // present in reference checkpoints, unused by forward (hrnet.py:326-332)
     b.P(bp + "final_layer.weight", {24, 32, 1, 1}, 0);
     b.P(bp + "final_layer.bias", {24}, 0);
@@ -1058,6 +1061,7 @@ float* ext_out(const IO& io, int slot) {
     case Y_UFEAT: return io.out->uncert_feat;
     case Y_SEGM: return io.out->pred_segm_mask;
     case Y_BODY2: return io.out->body_feat2;
+    case Y_BBFEAT: return io.out->backbone_feat;
     default: return nullptr;
   }
 }

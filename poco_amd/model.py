@@ -29,7 +29,7 @@ class _Inputs(C.Structure):
 class _Outputs(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in (
         "pred_pose", "pred_pose6d", "pred_shape", "pred_cam", "pred_cam_t", "pred_fullimg_cam_t", "smpl_vertices",
-        "smpl_joints3d", "smpl_joints2d", "var_pose", "uncert_feat", "pred_segm_mask", "body_feat2")]
+        "smpl_joints3d", "smpl_joints2d", "var_pose", "uncert_feat", "pred_segm_mask", "body_feat2", "backbone_feat")]
 
 
 def _bind():
@@ -198,7 +198,7 @@ class POCO:
             tune.apply_table(self, B, table)
 
     # ---- forward ---------------------------------------------------------------------------------
-    def _alloc_outputs(self, B: int, want_segm: bool) -> Dict[str, torch.Tensor]:
+    def _alloc_outputs(self, B: int, want_segm: bool, want_backbone_feat: bool = False) -> Dict[str, torch.Tensor]:
         d = self.device
         f = torch.float32
         ufd = self._L.poco_uncert_feat_dim(self._h)
@@ -221,6 +221,8 @@ class POCO:
             o["pred_pose6d"] = torch.empty(B, 24, 6, device=d, dtype=f)
             if want_segm:
                 o["pred_segm_mask"] = torch.empty(B, 25, 56, 56, device=d, dtype=f)
+            if want_backbone_feat:      # parity checks only: the HRNet-W32 output map (hrnet.py:515-519)
+                o["backbone_feat"] = torch.empty(B, 480, 56, 56, device=d, dtype=f)
         return o
 
     def _pack_io(self, batch, out):
@@ -248,7 +250,7 @@ class POCO:
         outs = _Outputs(dp(g("pred_pose")), dp(g("pred_pose6d", g("pred_pose_6d"))), dp(g("pred_shape")), dp(g("pred_cam")),
                         dp(g("pred_cam_t")), dp(g("pred_fullimg_cam_t")), dp(g("smpl_vertices")), dp(g("smpl_joints3d")),
                         dp(g("smpl_joints2d")), dp(g("var_pose")), dp(g("uncert_feat")), dp(g("pred_segm_mask")),
-                        dp(g("body_feat2")))
+                        dp(g("body_feat2")), dp(g("backbone_feat")))
         return B, ins, outs, keep
 
     @torch.no_grad()

@@ -56,6 +56,25 @@ def test_golden_b2(variant, profile, cuda):
     assert out["log_phi"] is None and out["gt_pose_cond_idx"] == []
 
 
+@pytest.mark.parametrize("profile", ["default", "stress"])
+def test_golden_backbone_map_w32(profile, cuda):
+    """HRNet-W32's 480-channel output map itself (hrnet.py:515-519: trunk + bilinear x2 chains + concat) against the samples, sum and
+    mean magnitude the REFERENCE's backbone produced (tests/golden/model_hrnet_w32-pare*.npz: feat_*).  VERDICT r1 row a2: the map was
+    only checked through what the head makes of it.  The engine copies it out on request (poco_outputs_t.backbone_feat)."""
+    g = dict(np.load(util.GOLD / ("model_hrnet_w32-pare.npz" if profile == "default" else "model_hrnet_w32-pare_stress.npz")))
+    m = util.make_engine("hrnet_w32-pare", max_batch=4, profile=profile)
+    out = m._alloc_outputs(2, want_segm=False, want_backbone_feat=True)
+    m(util.cuda_batch(synth.synth_batch(2, 1234, profile=profile), cuda), out=out)
+    torch.cuda.synchronize()
+    f = _np(out["backbone_feat"]).reshape(2, -1)
+    assert f.shape[1] == 480 * 56 * 56
+    scale = max(1.0, float(np.abs(g["feat_samples"]).max()))
+    assert np.abs(f[:, g["feat_idx"]] - g["feat_samples"]).max() < TOL * scale
+    assert np.abs(np.abs(f).mean(1) - g["feat_abs_mean"]).max() < TOL * scale
+    assert np.abs(f.astype(np.float64).sum(1) - g["feat_sum"]).max() < TOL * scale * 1e3     # 1.5e6 terms per crop
+    assert float(np.abs(g["feat_samples"][0] - g["feat_samples"][1]).max()) > 10 * TOL          # the two crops do differ
+
+
 @pytest.mark.parametrize("variant,B", [("hrnet_w32-pare", 5), ("hrnet_w48_cls-cliff", 7), ("resnet50-cliff", 9),
                                        ("resnet50-cliff", 1)])
 def test_oracle_other_batches(variant, B, cuda):
