@@ -10,10 +10,12 @@ from tests import util  # noqa: E402
 key = sys.argv[1]
 cfgB = tuple(int(x) for x in sys.argv[2].split(","))
 period = int(sys.argv[3]) if len(sys.argv) > 3 else 8
+lanes = int(sys.argv[4]) if len(sys.argv) > 4 else 4
 B = int(key.split("x")[0])
 m = util.make_engine("hrnet_w48_cls-cliff", max_batch=B)
 batch = util.cuda_batch(synth.synth_batch(B, 1), torch.device("cuda:0"))
 out = m._alloc_outputs(B, False)
+m.set_num_lanes(lanes)
 idxs = [i for i in range(len(m.ops())) if m.conv_desc(i) is not None and tune.shape_key(B, *m.conv_desc(i)[:6]) == key]
 cfgA = tuple(m.conv_cfg(idxs[0], B))
 print(len(idxs), "ops of", key, "A =", cfgA, "B =", cfgB)
