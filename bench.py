@@ -146,12 +146,14 @@ def cpu_baseline(variant, B=64, passes=3, inst_threads=32):
             ts.append(time.time() - t0)
         runs.append({"instances": 1, "threads_per_instance": th, "crops_per_pass": B, "passes": max(npass, 1),
                      "crops_per_s": round(B / float(np.median(ts)), 2)})
-    T = inst_threads
-    P = max(1, phys // T)
-    if P > 1:
+    legs = []
+    for T in sorted({inst_threads, 16}, reverse=True):       # 4 x 32 and 8 x 16 on a 128-core host
+        P = max(1, phys // T)
+        if P < 2:
+            continue
         per = max(4, B // P)                     # the B crops are shared out: P instances x B/P crops at the same time
         procs = [subprocess.Popen([sys.executable, str(Path(__file__).resolve()), "--cpu-worker", variant, str(i), str(T),
-                                   str(per), "1", str(i * T)], stdin=subprocess.PIPE, stdout=subprocess.PIPE,
+                                   str(per), "2", str(i * T)], stdin=subprocess.PIPE, stdout=subprocess.PIPE,
                                   stderr=subprocess.DEVNULL, text=True, env=dict(os.environ, OMP_NUM_THREADS=str(T)))
                  for i in range(P)]
         ok = all(p.stdout.readline().strip() == "READY" for p in procs)
@@ -163,17 +165,21 @@ def cpu_baseline(variant, B=64, passes=3, inst_threads=32):
             wall = time.time() - t0
             ok = all(d.startswith("DONE") for d in done)
         for p in procs:
-            p.wait(timeout=60)
+            try:
+                p.wait(timeout=60)
+            except subprocess.TimeoutExpired:
+                p.kill()
         if ok:
-            runs.append({"instances": P, "threads_per_instance": T, "crops_per_pass": per * P, "passes": 1,
+            legs.append(f"{P} pinned instances x {T} threads")
+            runs.append({"instances": P, "threads_per_instance": T, "crops_per_pass": per * P, "passes": 2,
                          "pinned": f"instance i on cpus [{T}i, {T}i+{T})",
-                         "crops_per_s": round(per * P / wall, 2)})
+                         "crops_per_s": round(2 * per * P / wall, 2)})
     best = max(runs, key=lambda r: r["crops_per_s"])
     return {"value": best["crops_per_s"], "unit": "crops/s", "cores": best["instances"] * best["threads_per_instance"],
             "kind": "port", "host": {"physical_cores": phys, "logical_cpus": logical}, "runs": runs,
             "sample": f"oracle/poco_ref.py (torch CPU fp32) on {B} crops of {variant} per pass, 1 warm-up + up to {passes} timed "
-                      f"passes (median); best of: 1 instance x 8 / 16 / 32 / {phys} threads, {P} pinned instances x {T} threads "
-                      f"sharing the {B} crops"}
+                      f"passes (median); `value` = the best of: 1 instance x 8 / 16 / 32 / {phys} threads, "
+                      f"{' and '.join(legs) if legs else 'no multi-instance leg'} sharing the {B} crops (2 passes)"}
 
 
 def streaming_leg(variant, device, batch=128, people=4, batches=20):
@@ -216,6 +222,129 @@ def streaming_leg(variant, device, batch=128, people=4, batches=20):
             "ms_per_batch": round(dt / batches * 1e3, 2), "pcie_in_MB_per_batch": round(fpb * H * W * 3 / 1e6, 1)}
 
 
+HBM_PEAK_TBS = 8.0      # MI355X_MICROARCH.md: HBM3E ~8 TB/s (about 6.3 achievable with a streaming kernel)
+
+
+def _time_launches(fn, iters=50, warm=5):
+    """mean microseconds of `fn()` (which only enqueues kernels on torch's current stream) over `iters` back-to-back calls."""
+    for _ in range(warm):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    st = torch.cuda.current_stream()
+    e0.record(st)
+    for _ in range(iters):
+        fn()
+    e1.record(st)
+    e1.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e3
+
+
+def side_kernels(device):
+    """the HBM/latency-bound side kernels are reported in GB/s against their ALGORITHMIC bytes (the minimal HBM
+    traffic of the operation: every input and parameter read once, every output written once), at the BASELINE sizes
+    (VERDICT r2 next #4): part-attention pool (config #2: B = 32, 56x56, C = 128 and 64), SMPL-LBS (B = 64), the GPU crop
+    (config #5: 128 crops of one 1080p frame) and the RealNVP flow (config #3: N = B*24 = 1536 and 3072 rows, 2 and 6 coupling
+    layers, log_prob and forward_p, with a per-row context and with the reference's per-crop context repeated 24x).  Each
+    entry: mean microseconds per call over back-to-back launches between two HIP events on the launch stream."""
+    import ctypes as C
+    from poco_amd import synth
+    from poco_amd._lib import check, current_stream, fptr, lib
+    from poco_amd.model import POCO
+    from poco_amd.tester import crop_normalize
+    L = lib()
+    out = {}
+
+    def entry(us, nbytes, note):
+        gbs = nbytes / (us * 1e-6) / 1e9
+        return {"us": round(us, 2), "algorithmic_MB": round(nbytes / 1e6, 3), "GB_per_s": round(gbs, 1),
+                "frac_of_hbm_peak": round(gbs / (HBM_PEAK_TBS * 1e3), 4), "note": note}
+
+    # -- part-attention pool (keypoint_attention.py:34-48 as pare_head.py:794-796 calls it) ----------------------------
+    B, H, W = 32, 56, 56
+    g = torch.Generator(device=device).manual_seed(1)
+    heat = torch.randn((B, H, 2, W, 16), device=device, generator=g)
+    L.poco_bench_part_attention.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                            C.c_int, C.POINTER(C.c_float), C.c_void_p]
+    for Cc in (128, 64):
+        feat = torch.randn((B, H, Cc // 16, W, 16), device=device, generator=g)
+        dst = torch.empty((B, Cc, 24), device=device)
+        ms = C.c_float(0)
+        check(L.poco_bench_part_attention(fptr(heat), 32, fptr(feat), Cc, B, H, W, fptr(dst), 50, C.byref(ms), current_stream()),
+              "poco_bench_part_attention")
+        out[f"part_attention_B{B}_C{Cc}"] = entry(ms.value * 1e3, B * (H * W * (32 + Cc) + Cc * 24) * 4,
+                                                  f"{B} crops x 56x56 x ({Cc} features + 32 heat-map channels) read once, [B,{Cc},24] written")
+    del heat
+
+    # -- engine-bound operators: SMPL-LBS and the flow (resnet50-cliff shell, 3 flow blocks = 6 coupling layers) ------
+    def shell(nfl):
+        m = POCO(backbone="resnet50-cliff", num_flow_layers=nfl, max_batch=64, smpl=synth.synth_smpl(7), device=device)
+        spec = [(n, shp) for n, shp, _ in m.expected_tensors() if not n.startswith("smpl.")]
+        w = synth.synth_state_dict(spec, 0)
+        m.load_state_dict({k: v for k, v in w.items() if v.dtype != np.int64}, strict=True)
+        return m.finalize()
+
+    m6 = shell(3)
+    Bl = 64
+    r = np.random.default_rng(5)
+    betas = torch.from_numpy(r.standard_normal((Bl, 10)).astype(np.float32)).to(device)
+    R = torch.linalg.qr(torch.randn(Bl * 24, 3, 3, generator=torch.Generator().manual_seed(2)))[0].reshape(Bl, 24, 3, 3).to(device)
+    verts = torch.empty(Bl, 6890, 3, device=device)
+    j49 = torch.empty(Bl, 49, 3, device=device)
+    L.poco_smpl_lbs.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 5
+
+    def lbs():
+        check(L.poco_smpl_lbs(m6._h, Bl, betas.data_ptr(), R.data_ptr(), verts.data_ptr(), j49.data_ptr(), current_stream()), "poco_smpl_lbs")
+
+    V = 6890
+    model_bytes = (207 * V * 3 + 10 * V * 3 + V * 3 + V * 24) * 4
+    out[f"smpl_lbs_B{Bl}"] = entry(_time_launches(lbs), model_bytes + Bl * (V * 3 + 49 * 3 + 216 + 10) * 4,
+                                   f"body model ({model_bytes/1e6:.1f} MB: posedirs, shapedirs, template, skinning weights) read once + "
+                                   f"{Bl} x (6890x3 vertices + 49 joints) written")
+
+    # -- GPU crop + normalise (vibe_image_utils.py:94-107,233-266) ---------------------------------------------------
+    Hf, Wf, Nc = 1080, 1920, 128
+    frame = torch.from_numpy(r.integers(0, 256, (Hf, Wf, 3), dtype=np.uint8)).to(device)
+    side = r.uniform(150, 600, Nc)
+    boxes = torch.from_numpy(np.stack([r.uniform(0.2, 0.8, Nc) * Wf, r.uniform(0.3, 0.7, Nc) * Hf, side, side], 1).astype(np.float32)).to(device)
+    crops = torch.empty(Nc, 3, 224, 224, device=device)
+    L.poco_crop_normalize.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_void_p, C.c_void_p]
+
+    def crop():
+        check(L.poco_crop_normalize(frame.data_ptr(), Hf, Wf, boxes.data_ptr(), Nc, 1.0, 224, crops.data_ptr(), current_stream()), "poco_crop_normalize")
+
+    out[f"crop_normalize_{Nc}x1080p"] = entry(_time_launches(crop), Hf * Wf * 3 + Nc * 3 * 224 * 224 * 4,
+                                               f"one 1080p uint8 frame read once + {Nc} x [3,224,224] fp32 crops written "
+                                               "(byte-exact cv2 fixed-point warpAffine)")
+    del frame, crops
+
+    # -- RealNVP (real_nvp.py:25-65; nf_head.py:93-110: N = B*24 rows, context of a crop repeated for its 24 joints) --
+    L.poco_realnvp_rep.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+    m2 = shell(1)
+    for tag, m, layers in (("L2", m2, 2), ("L6", m6, 6)):
+        wbytes = layers * 2 * (521 * 64 + 64 + 64 * 64 + 64 + 9 * 64 + 9) * 4
+        for N in (1536, 3072):
+            x = torch.from_numpy(np.abs(r.standard_normal((N, 9))).astype(np.float32)).to(device)
+            crop_ctx = torch.from_numpy(r.standard_normal((N // 24, 512)).astype(np.float32)).to(device)
+            row_ctx = crop_ctx.repeat_interleave(24, 0).contiguous()
+            for rep, cx, rtag in ((24, crop_ctx, "ctx_per_crop"), (1, row_ctx, "ctx_per_row")):
+                for fwd, nm, ow in ((0, "log_prob", 1), (1, "forward_p", 9)):
+                    o = torch.empty(N * ow, device=device)
+
+                    def flow(m=m, x=x, cx=cx, o=o, fwd=fwd, N=N, rep=rep):
+                        check(L.poco_realnvp_rep(m._h, N, x.data_ptr(), cx.data_ptr(), rep, o.data_ptr(), fwd, current_stream()), "poco_realnvp")
+
+                    nb = N * (9 + ow) * 4 + (N // rep) * 512 * 4 + wbytes
+                    gf = 2.0 * (N // rep) * 512 * layers * 128 + 2.0 * N * layers * 2 * (16 * 64 + 64 * 64 + 64 * 16)
+                    e = entry(_time_launches(flow), nb,
+                              f"{N} rows x 9 + {N // rep} context rows x 512 read, {layers} coupling layers' weights ({wbytes/1e3:.0f} KB) "
+                              f"read once, {ow} float(s) per row written; 2 launches (context GEMM + MFMA coupling kernel)")
+                    e["gflop"] = round(gf / 1e9, 3)
+                    e["tflops_f32_mfma"] = round(gf / (e["us"] * 1e-6) / 1e12, 2)
+                    out[f"realnvp_{nm}_{tag}_N{N}_{rtag}"] = e
+    del m2, m6
+    return out
+
+
 def spawn_ranks(args) -> int:
     """`python bench.py --gpus N` without a launcher: start N ranks of this same script, one per GPU."""
     import socket
@@ -244,6 +373,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stream", action="store_true", help="skip the config-#5 streaming leg (`streaming_cfg5`)")
     ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--no-side", action="store_true", help="skip the `side_kernels` block (HBM/latency-bound kernels in GB/s)")
     ap.add_argument("--lanes", type=int, default=4, help="HIP streams for independent branches (1 = single stream)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay of the forward")
     ap.add_argument("--no-dominant", action="store_true",
@@ -408,6 +538,8 @@ def main():
         if dominant is not None:
             dominant["frac"] = round(dominant["tflops"] / PEAK_F32_MFMA_TFLOPS, 4)
             line["roofline"]["dominant"] = dominant
+        if world == 1 and not args.no_side:
+            line["side_kernels"] = side_kernels(device)
         if world == 1 and not args.no_stream:
             line["streaming_cfg5"] = streaming_leg(args.variant, device)
         if world == 1 and not args.no_cpu_baseline:

@@ -113,9 +113,17 @@ int poco_smpl_lbs(poco_handle_t h, int B, const float* d_betas, const float* d_r
                   float* d_joints49, void* stream);
 /* RealNVP with the engine's flow_head.flow.* weights (pocolib/models/layers/real_nvp.py):
  * forward=0: log_prob(x[N,9] | ctx[N,512]) -> out[N]   (:55-65)
- * forward=1: forward_p(z[N,9], ctx)        -> out[N,9] (:25-38) */
+ * forward=1: forward_p(z[N,9], ctx)        -> out[N,9] (:25-38)
+ * Two launches: one GEMM for the context part of the first Linear of all 2L s/t MLPs, one fp32-MFMA kernel for the coupling
+ * recursion (csrc/kernels_flow.hip).  The GEMM's scratch is owned by the engine and grows on demand: the first call at a
+ * larger N allocates (synchronising), later calls only enqueue. */
 int poco_realnvp(poco_handle_t h, int N, const float* d_x, const float* d_ctx, float* d_out, int forward,
                  void* stream);
+/* The same with the context as the reference's flow_head actually has it (pocolib/models/head/nf_head.py:93-110): one
+ * 512-vector per CROP, used by `rep` consecutive rows (rep = 24 joints) - torch.repeat_interleave(context, rep) is never
+ * materialised.  d_ctx [ceil(N/rep), 512]; row r uses d_ctx[r / rep].  rep = 1 is poco_realnvp. */
+int poco_realnvp_rep(poco_handle_t h, int N, const float* d_x, const float* d_ctx, int rep, float* d_out, int forward,
+                     void* stream);
 
 /* ---- stand-alone operators (parity tests, tuner, micro-benchmarks) -------------------------- */
 
@@ -143,6 +151,10 @@ int poco_bench_conv2d(const float* d_in, int B, int H, int W, int Cin, const flo
  * 16, <= 128), d_out [B, C, 24]. */
 int poco_op_part_attention(const float* d_heat, int heat_cs, const float* d_feat, int C, int B, int H, int W,
                            float* d_out, void* stream);
+/* Timing of the same pool: `iters` back-to-back launches between two HIP events on `stream`; ms_out = mean ms per launch
+ * (both kernels of the split-pixel softmax pool).  bench.py's `side_kernels` line. */
+int poco_bench_part_attention(const float* d_heat, int heat_cs, const float* d_feat, int C, int B, int H, int W,
+                              float* d_out, int iters, float* ms_out, void* stream);
 /* LocallyConnected2d(128 -> 6, output_size [24,1], kernel 1, no bias) == pocolib/models/layers/locallyconnected2d.py:27-37
  * as pare_head.py builds its pose_mlp: pose6d[b, j, o] = sum_c x[b, c, j] * w[o, c, j].
  * d_x [B,128,24], d_w [6,128,24], d_pose6d [B,24,6]. */
@@ -150,12 +162,18 @@ int poco_op_lc2d_pose(const float* d_x, const float* d_w, float* d_pose6d, int B
 /* rot6d_to_rotmat == pocolib/utils/geometry.py:247-261: d_in [B,24,3,2] (144 floats per crop) -> d_rotmat [B,24,3,3]. */
 int poco_op_rot6d(const float* d_in, float* d_rotmat, int B, void* stream);
 
-/* GPU-side crop + normalise: replaces the per-detection CPU loop cv2.warpAffine(INTER_LINEAR,
+/* GPU-side crop + normalise: replaces the per-detection CPU loop cv2.getAffineTransform -> cv2.warpAffine(INTER_LINEAR,
  * BORDER_CONSTANT) -> ToTensor -> Normalize + per-crop H2D copy of pocolib/core/tester.py:182-203 and
- * pocolib/utils/vibe_image_utils.py:94-107,233-266,343-351.
- * d_frame uint8 [H,W,3] RGB, d_boxes [N,4] (cx,cy,w,h) px, d_out [N,3,res,res] fp32 NCHW. */
-int poco_crop_normalize(const unsigned char* d_frame, int H, int W, const float* d_boxes, int N, float bbox_scale,
+ * pocolib/utils/vibe_image_utils.py:58-107,233-266,343-351.  The uint8 crop underneath is BYTE-exact with OpenCV 4.5.5's
+ * fixed-point algorithm for that call (requirements.txt:4; restated in oracle/crop_np.py): 6x6 LU solve + inversion in
+ * double, 10-bit fixed-point coordinates, 1/32-px fractions, int16 weights, rounded 15-bit shift.
+ * d_frame uint8 [H,W,3] RGB, d_boxes [N,4] (cx,cy,w,h) px (float32, or float64 for the _f64 entry: the reference's
+ * detections / smoothed tracks may be either), bbox_scale = the Python float `scale` of get_single_image_crop_demo,
+ * d_out [N,3,res,res] fp32 NCHW. */
+int poco_crop_normalize(const unsigned char* d_frame, int H, int W, const float* d_boxes, int N, double bbox_scale,
                         int res, float* d_out, void* stream);
+int poco_crop_normalize_f64(const unsigned char* d_frame, int H, int W, const double* d_boxes, int N, double bbox_scale,
+                            int res, float* d_out, void* stream);
 
 /* Time `ncfg` tile configurations (6 ints each; MT<=0 = heuristic) for one conv shape on random
  * data; ms_out[i] < 0 = configuration invalid for this shape.  Used by poco_amd/tune.py. */

@@ -297,6 +297,33 @@ def run_ops():
     o["joint_map"] = np.array([C.JOINT_MAP[n] for n in C.JOINT_NAMES], np.int32)       # smpl_head.py:17
     assert np.array_equal(o["joint_map"], synth.JOINT_MAP_49)
     o["img_norm_mean"], o["img_norm_std"] = np.array(C.IMG_NORM_MEAN), np.array(C.IMG_NORM_STD)
+    # crop: the float32 point triples the reference's gen_trans_from_patch_cv hands to cv2.getAffineTransform
+    # (vibe_image_utils.py:58-92; cv2 replaced by a recorder).  float64 boxes: independent of the numpy version's
+    # scalar promotion (the reference pins numpy 1.18 where float32 * Python float is float64 anyway).
+    import importlib
+    vi = importlib.import_module("pocolib.utils.vibe_image_utils")
+    seen = {}
+
+    def _record(src, dst):
+        seen["src"], seen["dst"] = np.array(src), np.array(dst)
+        return np.zeros((2, 3))
+
+    vi.cv2.getAffineTransform = _record
+    rc = np.random.default_rng(4242)
+    cb = np.stack([rc.uniform(-50, 2000, 12), rc.uniform(-50, 1100, 12), rc.uniform(8, 900, 12), rc.uniform(8, 900, 12)], 1)
+    cb[0] = (112, 112, 224, 224)
+    cb[1] = np.float32([100.5, 77.25, 33.3, 51.7]).astype(np.float64)
+    csc = np.array([1.0, 1.0, 1.1, 1.2] * 3)
+    srcs, dsts = [], []
+    for (cx_, cy_, w_, h_), sc_ in zip(cb, csc):
+        vi.gen_trans_from_patch_cv(cx_, cy_, w_, h_, 224, 224, float(sc_), 0, inv=False)
+        assert seen["src"].dtype == np.float32 and seen["dst"].dtype == np.float32
+        srcs.append(seen["src"]); dsts.append(seen["dst"])
+    o["crop_boxes"], o["crop_scale"], o["crop_src"], o["crop_dst"] = cb, csc, np.stack(srcs), np.stack(dsts)
+    from oracle import crop_np
+    for bx, sc_, s_, d_ in zip(cb, csc, srcs, dsts):
+        ps, pd = crop_np.patch_points(*bx, 224, sc_)
+        assert np.array_equal(ps, s_) and np.array_equal(pd, d_)
     np.savez_compressed(GOLD / "ops.npz", **o)
     # pin the oracle's small functions
     assert np.abs(poco_ref.rot6d_to_rotmat(torch.from_numpy(x6)).numpy() - o["rot6d_out"]).max() < 1e-6

@@ -108,6 +108,8 @@ struct Engine {
   Ref smpl_betas, smpl_rot, cam_ref;
   FlowDev flow{};
   bool has_flow = false;
+  float* flow_scratch = nullptr;          // step A of the flow (context GEMM), grown on demand by poco_realnvp
+  size_t flow_scratch_floats = 0;
   int uncert_feat_dim = 0;
   std::string err;
 
@@ -119,6 +121,7 @@ struct Engine {
     if (ev_fork) (void)hipEventDestroy(ev_fork);
     for (void* p : dev_allocs) (void)hipFree(p);
     if (ws) (void)hipFree(ws);
+    if (flow_scratch) (void)hipFree(flow_scratch);
   }
 };
 
@@ -675,7 +678,9 @@ void build_flow(Builder& b, int in_ctx) {
   b.P("flow_head.cond_layer.weight", {ctx, in_ctx}, 0);
   b.P("flow_head.cond_layer.bias", {ctx}, 0);
   const HostParam* mask = b.P("flow_head.flow.mask", {L, D}, 0);
-  std::vector<float> w0[2], b0[2], w1[2], b1[2], w2[2], b2[2];
+  const int NM = L * 2;                                   // MLPs: index li*2 + net (net 0 = s, 1 = t)
+  std::vector<float> wpack((size_t)NM * 24 * 256), b1((size_t)NM * H), b2((size_t)NM * 16, 0.f), wctx((size_t)NM * H * ctx),
+      bctx((size_t)NM * H);
   bool all = mask != nullptr;
   for (int net = 0; net < 2; ++net) {
     const std::string nn = net == 0 ? "s" : "t";
@@ -689,22 +694,33 @@ void build_flow(Builder& b, int in_ctx) {
       const HostParam* B2 = b.P(q + ".4.bias", {D}, 0);
       if (b.declare) continue;
       if (!W0 || !B0 || !W1 || !B1 || !W2 || !B2) { all = false; continue; }
-      for (int i = 0; i < K0; ++i) for (int h = 0; h < H; ++h) w0[net].push_back(W0->data[(size_t)h * K0 + i]);
-      for (int k = 0; k < H; ++k) for (int h = 0; h < H; ++h) w1[net].push_back(W1->data[(size_t)h * H + k]);
-      w2[net].insert(w2[net].end(), W2->data.begin(), W2->data.end());
-      b0[net].insert(b0[net].end(), B0->data.begin(), B0->data.end());
-      b1[net].insert(b1[net].end(), B1->data.begin(), B1->data.end());
-      b2[net].insert(b2[net].end(), B2->data.begin(), B2->data.end());
+      const int m = l * 2 + net;
+      // first Linear: the 9 state columns (K padded to 16) feed the coupling kernel, the 512 context columns step A
+      std::vector<float> w0z((size_t)H * 16, 0.f);
+      for (int h = 0; h < H; ++h) {
+        for (int i = 0; i < D; ++i) w0z[(size_t)h * 16 + i] = W0->data[(size_t)h * K0 + i];
+        for (int k = 0; k < ctx; ++k) wctx[((size_t)m * H + h) * ctx + k] = W0->data[(size_t)h * K0 + D + k];
+        bctx[(size_t)m * H + h] = B0->data[h];
+        b1[(size_t)m * H + h] = B1->data[h];
+      }
+      for (int i = 0; i < D; ++i) b2[(size_t)m * 16 + i] = B2->data[i];
+      float* wp = wpack.data() + (size_t)m * 24 * 256;
+      conv_pack_weights(w0z.data(), nullptr, H, 16, 1, H, wp);                       // 4 quads
+      conv_pack_weights(W1->data.data(), nullptr, H, H, 1, H, wp + 4 * 256);          // 16 quads [k slice][n-tile]
+      conv_pack_weights(W2->data.data(), nullptr, D, H, 1, 16, wp + 20 * 256);        // 4 quads, rows 9..15 zero
     }
   }
   if (b.declare || !all) return;
+  std::vector<float> mask16((size_t)L * 16, 0.f);
+  for (int l = 0; l < L; ++l)
+    for (int i = 0; i < D; ++i) mask16[(size_t)l * 16 + i] = mask->data[(size_t)l * D + i];
+  std::vector<float> wcf(conv_packed_weight_floats(ctx, NM * H, 1));
+  conv_pack_weights(wctx.data(), nullptr, NM * H, ctx, 1, NM * H, wcf.data());
   e.flow.L = L; e.flow.ctx = ctx;
-  e.flow.mask = b.upload(mask->data);
-  for (int net = 0; net < 2; ++net) {
-    e.flow.w0t[net] = b.upload(w0[net]); e.flow.b0[net] = b.upload(b0[net]);
-    e.flow.w1t[net] = b.upload(w1[net]); e.flow.b1[net] = b.upload(b1[net]);
-    e.flow.w2[net] = b.upload(w2[net]);  e.flow.b2[net] = b.upload(b2[net]);
-  }
+  e.flow.mask16 = b.upload(mask16);
+  e.flow.wpack = reinterpret_cast<const float4*>(b.upload(wpack));
+  e.flow.b1 = b.upload(b1); e.flow.b2 = b.upload(b2);
+  e.flow.wctx_frag = b.upload(wcf); e.flow.bctx = b.upload(bctx);
   e.has_flow = true;
 }
 
@@ -1474,11 +1490,25 @@ extern "C" int poco_smpl_lbs(poco_handle_t h, int B, const float* d_betas, const
   return POCO_OK;
 }
 
-extern "C" int poco_realnvp(poco_handle_t h, int N, const float* d_x, const float* d_ctx, float* d_out, int forward,
-                            void* stream) {
+extern "C" int poco_realnvp_rep(poco_handle_t h, int N, const float* d_x, const float* d_ctx, int rep, float* d_out,
+                                int forward, void* stream) {
   Engine* e = H(h);
   if (!e || !e->finalized || !e->has_flow) { poco_set_error("poco_realnvp: flow_head.flow.* tensors were not loaded"); return POCO_ERR_STATE; }
-  if (!d_x || !d_ctx || !d_out || N < 1) { poco_set_error("poco_realnvp: bad arguments"); return POCO_ERR_ARG; }
-  launch_realnvp(e->flow, d_x, d_ctx, d_out, N, forward, (hipStream_t)stream);
-  return POCO_OK;
+  if (!d_x || !d_ctx || !d_out || N < 1 || rep < 1) { poco_set_error("poco_realnvp: bad arguments"); return POCO_ERR_ARG; }
+  const size_t need = realnvp_scratch_floats(e->flow, (N + rep - 1) / rep);
+  if (need > e->flow_scratch_floats) {          // grow-only; the first call at a new size allocates (and synchronises)
+    if (e->flow_scratch) {
+      POCO_HIP_CHECK(hipDeviceSynchronize());
+      (void)hipFree(e->flow_scratch);
+      e->flow_scratch = nullptr; e->flow_scratch_floats = 0;
+    }
+    POCO_HIP_CHECK(hipMalloc(&e->flow_scratch, need * sizeof(float)));
+    e->flow_scratch_floats = need;
+  }
+  return launch_realnvp(e->flow, d_x, d_ctx, rep, d_out, N, forward, e->flow_scratch, (hipStream_t)stream);
+}
+
+extern "C" int poco_realnvp(poco_handle_t h, int N, const float* d_x, const float* d_ctx, float* d_out, int forward,
+                            void* stream) {
+  return poco_realnvp_rep(h, N, d_x, d_ctx, 1, d_out, forward, stream);
 }

@@ -99,19 +99,29 @@ void launch_camera(const CamArgs& a, int B, hipStream_t s);
 
 // ---- RealNVP (kernels_flow.hip) -----------------------------------------------------------------------
 struct FlowDev {
-  int L;               // number of coupling layers (rows of mask)
+  int L;               // number of coupling layers (rows of mask; even: nf_head.py:20-21 builds mask pairs)
   int ctx;             // context dim (512)
-  const float* mask;   // [L,9]
-  // per layer, nets s and t: W0t [521][64] (input-major), b0[64], W1t [64][64], b1[64], W2 [9][64], b2[9]
-  const float* w0t[2]; const float* b0[2]; const float* w1t[2]; const float* b1[2];
-  const float* w2[2];  const float* b2[2];
+  const float* mask16; // [L][16]: mask rows zero-padded from 9 to 16
+  // per (layer, net s|t): 24 x 64 float4 MFMA A-operand fragments = conv_pack_weights(ks = 1) of
+  //   W0[:, :9] (K padded to 16) [4 quads] | W1 [16 quads: k slice major] | W2 (rows padded to 16) [4 quads]
+  const float4* wpack;
+  const float* b1;     // [L][2][64]
+  const float* b2;     // [L][2][16] (zero padded)
+  // step A (context GEMM): W0[:, 9:] of all 2L MLPs stacked to [L*2*64][512] in conv_pack_weights(ks = 1) order, bias = b0
+  const float* wctx_frag;
+  const float* bctx;   // [L*2*64]
 };
-// log_prob (backward_p + N(0,I) prior, layers/real_nvp.py:40-65) or forward_p (:25-38).
-void launch_realnvp(const FlowDev& f, const float* x, const float* ctx, float* out, int N, int forward,
-                    hipStream_t s);
+// log_prob (backward_p + N(0,I) prior, layers/real_nvp.py:40-65; forward = 0) or forward_p (:25-38; forward = 1) of N rows.
+// ctx: [ceil(N/rep)][512], row r uses context row r / rep (rep = 1: one context per row; rep = 24: nf_head.py:105-110's
+// repeat_interleave without materialising it).  scratch: realnvp_scratch_floats(f, ceil(N/rep)) floats.
+size_t realnvp_scratch_floats(const FlowDev& f, int ctx_rows);
+int launch_realnvp(const FlowDev& f, const float* x, const float* ctx, int rep, float* out, int N, int forward, float* scratch,
+                   hipStream_t s);
 
 // ---- preprocessing (kernels_misc.hip) --------------------------------------------------------------------
-// frame: uint8 [H,W,3] RGB (device); boxes: [N,4] = (cx, cy, w, h) in pixels; out: [N,3,res,res] fp32 NCHW,
-// bilinear affine crop of box*scale -> uint8 rounding -> /255 -> ImageNet mean/std.
-void launch_crop_normalize(const unsigned char* frame, int H, int W, const float* boxes, float bbox_scale, float* out,
+// frame: uint8 [H,W,3] RGB (device); boxes: [N,4] = (cx, cy, w, h) in pixels (float32 or float64); out: [N,3,res,res] fp32
+// NCHW = ToTensor + Normalize of the uint8 crop cv2.warpAffine(getAffineTransform(box * scale -> res x res)) makes, byte-exact.
+void launch_crop_normalize(const unsigned char* frame, int H, int W, const float* boxes, double bbox_scale, float* out,
                            int N, int res, hipStream_t s);
+void launch_crop_normalize_f64(const unsigned char* frame, int H, int W, const double* boxes, double bbox_scale, float* out,
+                               int N, int res, hipStream_t s);

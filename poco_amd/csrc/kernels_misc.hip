@@ -269,41 +269,175 @@ void launch_avgpool(const float* in, float* dst, int B, int H, int W, int C, int
 }
 
 // ---- GPU-side crop + normalise ---------------------------------------------------
-// Replaces the per-crop CPU loop  cv2.warpAffine(bilinear, BORDER_CONSTANT) -> ToTensor -> Normalize
-// + per-crop H2D copy of pocolib/core/tester.py:182-203 / utils/vibe_image_utils.py:94-107,233-266,
-// 343-351.  One thread per output pixel, frame read once from HBM (uint8 HWC RGB), output NCHW fp32.
+// Replaces the per-crop CPU loop  cv2.getAffineTransform -> cv2.warpAffine(INTER_LINEAR, BORDER_CONSTANT) on uint8 ->
+// ToTensor -> Normalize + per-crop H2D copy of pocolib/core/tester.py:182-203 / utils/vibe_image_utils.py:58-107,
+// 233-266,343-351.  BYTE-exact with OpenCV 4.5.5's algorithm for that call (restated step by step in oracle/crop_np.py,
+// which documents every constant): the 6x6 LU solve and the matrix inversion in IEEE double WITHOUT fma contraction,
+// 10-bit fixed-point coordinates with round_delta 16, 5-bit sub-pixel fractions, int16 weights summing to 2^15 and a
+// rounded 15-bit shift.  A block owns CROP_ROWS rows of one crop; its first wave solves the box's affine system once
+// (~1 us), every thread then produces pixels x = t, t + 256, ... of those rows for the three channels (stores
+// coalesced along x in NCHW; the uint8 frame is read through L2, 12 bytes per output pixel).
 namespace {
-__global__ void crop_normalize_kernel(const unsigned char* __restrict__ frame, int H, int W,
-                                      const float* __restrict__ boxes, float bbox_scale, float* __restrict__ out,
-                                      int N, int res) {
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (long)N * res * res) return;
-  const int x = (int)(i % res), y = (int)((i / res) % res), n = (int)(i / ((long)res * res));
-  const float cx = boxes[n * 4], cy = boxes[n * 4 + 1], bw = boxes[n * 4 + 2], bh = boxes[n * 4 + 3];
-  // gen_trans_from_patch_cv (rot = 0): src = centre + (dst - res/2) * (bbox * scale / res)
-  const float sx = cx + ((float)x - 0.5f * res) * (bw * bbox_scale / res);
-  const float sy = cy + ((float)y - 0.5f * res) * (bh * bbox_scale / res);
-  const int x0 = (int)floorf(sx), y0 = (int)floorf(sy);
-  const float fx = sx - x0, fy = sy - y0;
-  const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};
+constexpr int CROP_ROWS = 8;
+
+// cv::hal::LU64f (LUImpl<double>, opencv/modules/core/src/matrix_decomp.cpp) for the 6x6 system of getAffineTransform.
+__device__ __forceinline__ void lu_solve6(double (&A)[6][6], double (&b)[6]) {
+#pragma clang fp contract(off)
+  // fully unrolled with static indices (the pivot row is swapped in through selects) so that A lives in registers
+  bool singular = false;
 #pragma unroll
-  for (int c = 0; c < 3; ++c) {
-    float v[4];
+  for (int i = 0; i < 6; ++i) {
+    int k = i;
+    double best = fabs(A[i][i]);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int xx = x0 + (k & 1), yy = y0 + (k >> 1);
-      v[k] = ((unsigned)xx < (unsigned)W && (unsigned)yy < (unsigned)H) ? (float)frame[((size_t)yy * W + xx) * 3 + c] : 0.f;
+    for (int j = i + 1; j < 6; ++j)
+      if (fabs(A[j][i]) > best) { best = fabs(A[j][i]); k = j; }
+    singular = singular || best < 2.220446049250313e-16 * 100;      // cv::solve returns false and leaves zeros
+#pragma unroll
+    for (int j = i + 1; j < 6; ++j) {
+      const bool sw = k == j;
+#pragma unroll
+      for (int c = i; c < 6; ++c) {
+        const double t = A[i][c];
+        A[i][c] = sw ? A[j][c] : t;
+        A[j][c] = sw ? t : A[j][c];
+      }
+      const double t = b[i];
+      b[i] = sw ? b[j] : t;
+      b[j] = sw ? t : b[j];
     }
-    float p = (1.f - fy) * ((1.f - fx) * v[0] + fx * v[1]) + fy * ((1.f - fx) * v[2] + fx * v[3]);
-    p = fminf(fmaxf(rintf(p), 0.f), 255.f);                 // cv2 stores the warped crop as uint8
-    out[(((size_t)n * 3 + c) * res + y) * res + x] = (p / 255.f - mean[c]) / stdv[c];
+    const double d = -1.0 / A[i][i];
+#pragma unroll
+    for (int j = i + 1; j < 6; ++j) {
+      const double alpha = A[j][i] * d;
+#pragma unroll
+      for (int c = i + 1; c < 6; ++c) A[j][c] = A[j][c] + alpha * A[i][c];
+      b[j] = b[j] + alpha * b[i];
+    }
+  }
+#pragma unroll
+  for (int i = 5; i >= 0; --i) {
+    double s = b[i];
+#pragma unroll
+    for (int c = i + 1; c < 6; ++c) s = s - A[i][c] * b[c];
+    b[i] = s / A[i][i];
+  }
+  if (singular) {
+#pragma unroll
+    for (int j = 0; j < 6; ++j) b[j] = 0.0;
+  }
+}
+
+// gen_trans_from_patch_cv(rot = 0) -> getAffineTransform(src, dst) -> the inversion cv::warpAffine applies: Mi[6].
+__device__ __forceinline__ void crop_inverse_affine(double cx, double cy, double bw, double bh, double scale, int res, double (&Mi)[6]) {
+#pragma clang fp contract(off)
+  const float down = (float)(bh * scale * 0.5), right = (float)(bw * scale * 0.5);
+  const float sx[3] = {(float)cx, (float)(cx + (double)0.0f), (float)(cx + (double)right)};
+  const float sy[3] = {(float)cy, (float)(cy + (double)down), (float)(cy + (double)0.0f)};
+  const float half = (float)(res * 0.5);
+  const float dx[3] = {half, half, half + half}, dy[3] = {half, half + half, half};
+  double A[6][6], b[6];
+  for (int i = 0; i < 6; ++i)
+    for (int j = 0; j < 6; ++j) A[i][j] = 0.0;
+  for (int i = 0; i < 3; ++i) {
+    A[2 * i][0] = A[2 * i + 1][3] = sx[i];
+    A[2 * i][1] = A[2 * i + 1][4] = sy[i];
+    A[2 * i][2] = A[2 * i + 1][5] = 1.0;
+    b[2 * i] = dx[i];
+    b[2 * i + 1] = dy[i];
+  }
+  lu_solve6(A, b);
+  double D = b[0] * b[4] - b[1] * b[3];
+  D = D != 0.0 ? 1.0 / D : 0.0;
+  const double A11 = b[4] * D, A22 = b[0] * D;
+  Mi[0] = A11;
+  Mi[1] = b[1] * -D;
+  Mi[3] = b[3] * -D;
+  Mi[4] = A22;
+  Mi[2] = -Mi[0] * b[2] - Mi[1] * b[5];
+  Mi[5] = -Mi[3] * b[2] - Mi[4] * b[5];
+}
+
+__device__ __forceinline__ int cv_round(double v) { return __double2int_rn(v); }      // cvRound: round half to even
+
+template <typename BoxT>
+__global__ void __launch_bounds__(256)
+crop_normalize_kernel(const unsigned char* __restrict__ frame, int H, int W, const BoxT* __restrict__ boxes,
+                      double bbox_scale, float* __restrict__ out, int res) {
+#pragma clang fp contract(off)
+  __shared__ double sM[6];
+  const int n = blockIdx.y, row0 = blockIdx.x * CROP_ROWS;
+  if (threadIdx.x < 64) {                    // the whole first wave solves the same system (no divergence, no broadcast)
+    double Mi[6];
+    crop_inverse_affine((double)boxes[n * 4], (double)boxes[n * 4 + 1], (double)boxes[n * 4 + 2], (double)boxes[n * 4 + 3],
+                        bbox_scale, res, Mi);
+    if (threadIdx.x < 6) sM[threadIdx.x] = Mi[threadIdx.x];
+  }
+  __syncthreads();
+  const double M0 = sM[0], M1 = sM[1], M2 = sM[2], M3 = sM[3], M4 = sM[4], M5 = sM[5];
+  const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};
+  const int rows = min(CROP_ROWS, res - row0);
+  for (int i = threadIdx.x; i < rows * res; i += 256) {
+    const int x = i % res, y = row0 + i / res;
+    const int adelta = cv_round(M0 * x * 1024.0), bdelta = cv_round(M3 * x * 1024.0);
+    const int X0 = cv_round((M1 * y + M2) * 1024.0) + 16, Y0 = cv_round((M4 * y + M5) * 1024.0) + 16;
+    const int X = (X0 + adelta) >> 5, Y = (Y0 + bdelta) >> 5;
+    const int sx = max(-32768, min(32767, X >> 5)), sy = max(-32768, min(32767, Y >> 5));
+    const int fx = X & 31, fy = Y & 31;
+    // BilinearTab_i: saturate_short((1-fy|fy)/32 * (1-fx|fx)/32 * 2^15) = exact integers; (0,0) saturates to 32767 and the
+    // table's sum correction puts the missing 1 on the last weight (tests/test_host_cpu.py checks this formula == the table)
+    int w00 = (32 - fy) * (32 - fx) * 32, w01 = (32 - fy) * fx * 32, w10 = fy * (32 - fx) * 32, w11 = fy * fx * 32;
+    if ((fx | fy) == 0) { w00 = 32767; w11 = 1; }
+    float* o = out + (((size_t)n * 3) * res + y) * res + x;
+    const size_t cs = (size_t)res * res;
+    if (sx >= 0 && sy >= 0 && sx <= W - 3 && sy + 1 < H) {
+      // interior (the common case): the 2 x 2 x RGB neighbourhood is bytes 0..5 of two 8-byte windows (unaligned 64-bit
+      // loads: 2 memory instructions per pixel instead of 12 byte loads; the window never leaves the frame since sx <= W - 3)
+      typedef unsigned long long __attribute__((aligned(1))) u64u;
+      const unsigned char* p00 = frame + ((size_t)sy * W + sx) * 3;
+      const unsigned long long r0 = *reinterpret_cast<const u64u*>(p00);
+      const unsigned long long r1 = *reinterpret_cast<const u64u*>(p00 + (size_t)W * 3);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const int v00 = (int)((r0 >> (8 * c)) & 255), v01 = (int)((r0 >> (8 * (3 + c))) & 255);
+        const int v10 = (int)((r1 >> (8 * c)) & 255), v11 = (int)((r1 >> (8 * (3 + c))) & 255);
+        const int p = min(255, max(0, (w00 * v00 + w01 * v01 + w10 * v10 + w11 * v11 + (1 << 14)) >> 15));
+        // ToTensor (uint8 -> float32 / 255) -> Normalize ((t - mean) / std), float32 like torchvision on the CPU
+        o[c * cs] = ((float)p / 255.f - mean[c]) / stdv[c];
+      }
+    } else {
+      const bool x0ok = (unsigned)sx < (unsigned)W, x1ok = (unsigned)(sx + 1) < (unsigned)W;
+      const bool y0ok = (unsigned)sy < (unsigned)H, y1ok = (unsigned)(sy + 1) < (unsigned)H;
+      const unsigned char* p00 = frame + ((long)sy * W + sx) * 3;      // only dereferenced where the *ok flags allow
+      const unsigned char* p10 = p00 + (long)W * 3;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const int v00 = (x0ok && y0ok) ? p00[c] : 0, v01 = (x1ok && y0ok) ? p00[3 + c] : 0;
+        const int v10 = (x0ok && y1ok) ? p10[c] : 0, v11 = (x1ok && y1ok) ? p10[3 + c] : 0;
+        const int p = min(255, max(0, (w00 * v00 + w01 * v01 + w10 * v10 + w11 * v11 + (1 << 14)) >> 15));
+        o[c * cs] = ((float)p / 255.f - mean[c]) / stdv[c];
+      }
+    }
   }
 }
 }  // namespace
 
-void launch_crop_normalize(const unsigned char* frame, int H, int W, const float* boxes, float bbox_scale, float* out,
+template <typename BoxT>
+static void launch_crop_t(const unsigned char* frame, int H, int W, const BoxT* boxes, double bbox_scale, float* out, int N,
+                          int res, hipStream_t s) {
+  for (int n0 = 0; n0 < N; n0 += 65535) {             // gridDim.y limit
+    const int nn = N - n0 < 65535 ? N - n0 : 65535;
+    hipLaunchKernelGGL(crop_normalize_kernel<BoxT>, dim3((res + CROP_ROWS - 1) / CROP_ROWS, nn), dim3(256), 0, s, frame, H, W,
+                       boxes + (size_t)n0 * 4, bbox_scale, out + (size_t)n0 * 3 * res * res, res);
+  }
+}
+
+void launch_crop_normalize(const unsigned char* frame, int H, int W, const float* boxes, double bbox_scale, float* out,
                            int N, int res, hipStream_t s) {
-  const long n = (long)N * res * res;
-  hipLaunchKernelGGL(crop_normalize_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, frame, H, W, boxes,
-                     bbox_scale, out, N, res);
+  launch_crop_t<float>(frame, H, W, boxes, bbox_scale, out, N, res, s);
+}
+
+void launch_crop_normalize_f64(const unsigned char* frame, int H, int W, const double* boxes, double bbox_scale, float* out,
+                               int N, int res, hipStream_t s) {
+  launch_crop_t<double>(frame, H, W, boxes, bbox_scale, out, N, res, s);
 }

@@ -183,17 +183,28 @@ extern "C" int poco_tune_conv(int B, int H, int W, int Cin, int Cout, int ks, in
 }
 
 #include "kernels.h"
-extern "C" int poco_crop_normalize(const unsigned char* d_frame, int H, int W, const float* d_boxes, int N,
-                                   float bbox_scale, int res, float* d_out, void* stream) {
-  if (!d_frame || !d_boxes || !d_out || N < 0 || H < 1 || W < 1 || res < 1) {
-    poco_set_error("poco_crop_normalize: bad arguments");
+static int crop_common(const unsigned char* d_frame, int H, int W, const void* d_boxes, int f64, int N, double bbox_scale,
+                       int res, float* d_out, void* stream) {
+  if (!d_frame || !d_boxes || !d_out || N < 0 || H < 1 || W < 1 || res < 1 || H > 32767 || W > 32767) {
+    poco_set_error("poco_crop_normalize: bad arguments (frame up to 32767 x 32767: cv2.warpAffine's int16 coordinate maps)");
     return POCO_ERR_ARG;
   }
   if (N == 0) return POCO_OK;
-  launch_crop_normalize(d_frame, H, W, d_boxes, bbox_scale, d_out, N, res, (hipStream_t)stream);
+  if (f64) launch_crop_normalize_f64(d_frame, H, W, (const double*)d_boxes, bbox_scale, d_out, N, res, (hipStream_t)stream);
+  else launch_crop_normalize(d_frame, H, W, (const float*)d_boxes, bbox_scale, d_out, N, res, (hipStream_t)stream);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { poco_set_error(std::string("poco_crop_normalize: ") + hipGetErrorString(e)); return POCO_ERR_HIP; }
   return POCO_OK;
+}
+
+extern "C" int poco_crop_normalize(const unsigned char* d_frame, int H, int W, const float* d_boxes, int N,
+                                   double bbox_scale, int res, float* d_out, void* stream) {
+  return crop_common(d_frame, H, W, d_boxes, 0, N, bbox_scale, res, d_out, stream);
+}
+
+extern "C" int poco_crop_normalize_f64(const unsigned char* d_frame, int H, int W, const double* d_boxes, int N,
+                                       double bbox_scale, int res, float* d_out, void* stream) {
+  return crop_common(d_frame, H, W, d_boxes, 1, N, bbox_scale, res, d_out, stream);
 }
 
 // ---- head operators on their own (parity tests against vectors made by the reference's modules) --------------------------
@@ -213,6 +224,35 @@ extern "C" int poco_op_part_attention(const float* d_heat, int heat_cs, const fl
   if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
   (void)hipFree(scratch);
   POCO_HIP_CHECK(e);
+  return POCO_OK;
+}
+
+// `iters` back-to-back launches of the pool between two HIP events on `stream` (scratch allocated once, outside the events).
+extern "C" int poco_bench_part_attention(const float* d_heat, int heat_cs, const float* d_feat, int C, int B, int H, int W,
+                                         float* d_out, int iters, float* ms_out, void* stream) {
+  if (!d_heat || !d_feat || !d_out || !ms_out || iters < 1) { poco_set_error("bench_part_attention: bad argument"); return POCO_ERR_ARG; }
+  if (heat_cs < 32 || (heat_cs & 15) || C < 16 || C > 128 || (C & 15) || B < 1 || H < 1 || W < 1) {
+    poco_set_error("bench_part_attention: needs heat_cs >= 32 and C <= 128, both multiples of 16 (L16 layout)");
+    return POCO_ERR_ARG;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  float* scratch = nullptr;
+  POCO_HIP_CHECK(hipMalloc(&scratch, part_attention_scratch_floats(B, C) * sizeof(float)));
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0);
+  (void)hipEventCreate(&e1);
+  launch_part_attention_pool_ws(d_heat, heat_cs, d_feat, C, d_out, C * 24, B, H, W, scratch, s);
+  (void)hipEventRecord(e0, s);
+  for (int i = 0; i < iters; ++i) launch_part_attention_pool_ws(d_heat, heat_cs, d_feat, C, d_out, C * 24, B, H, W, scratch, s);
+  (void)hipEventRecord(e1, s);
+  hipError_t e = hipEventSynchronize(e1);
+  float ms = 0.f;
+  if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  (void)hipFree(scratch);
+  POCO_HIP_CHECK(e);
+  *ms_out = ms / iters;
   return POCO_OK;
 }
 

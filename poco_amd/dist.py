@@ -10,6 +10,7 @@ from typing import Dict, List, Tuple
 import torch
 
 REC = 254
+VIDEO_REC = REC + 98       # video mode: + the 49 raw 2-D joints of the prediction (the finished pose may be a smoothed one)
 FIELDS = (("pred_pose", 0, 216), ("pred_shape", 216, 226), ("pred_cam", 226, 229), ("var_pose", 229, 253),
           ("var_global", 253, 254))
 
@@ -97,8 +98,9 @@ def collective_device(group=None) -> torch.device:
     return torch.device("cpu")
 
 
-def gather_track_records(local: Dict[str, torch.Tensor], group=None, device=None) -> Dict[str, torch.Tensor]:
-    """All ranks end up with every track's [T, 254] records.  `local`: {person_id: [T,254] tensor} of this rank.
+def gather_track_records(local: Dict[str, torch.Tensor], group=None, device=None, width: int = REC) -> Dict[str, torch.Tensor]:
+    """All ranks end up with every track's [T, width] records.  `local`: {person_id: [T,width] tensor} of this rank
+    (width = 254 for the plain SMPL record, 352 = VIDEO_REC when the 49 raw 2-D joints ride along).
     One all-gather of the concatenated rows (padded to the largest rank) + one object gather of the (id, T) index.
     The collective's buffers are allocated on `device` (default: what the group's backend needs), also on a rank that
     owns no track at all (more ranks than people is the common video case)."""
@@ -110,11 +112,12 @@ def gather_track_records(local: Dict[str, torch.Tensor], group=None, device=None
     all_index: List[list] = [None] * world
     dist.all_gather_object(all_index, index, group=group)
     nmax = max(1, max(sum(t for _, t in idx) for idx in all_index))
-    send = torch.zeros(nmax, REC, device=dev, dtype=torch.float32)
+    send = torch.zeros(nmax, width, device=dev, dtype=torch.float32)
     if ids:
         rows = torch.cat([local[k].to(dev) for k in ids], 0)
+        assert rows.shape[1] == width, (rows.shape, width)
         send[: rows.shape[0]] = rows
-    buf = torch.empty(world * nmax, REC, device=dev, dtype=torch.float32)
+    buf = torch.empty(world * nmax, width, device=dev, dtype=torch.float32)
     dist.all_gather_into_tensor(buf, send, group=group)
     out = {}
     for r, idx in enumerate(all_index):

@@ -56,6 +56,7 @@ def _bind():
     L.poco_set_num_lanes.argtypes = [C.c_void_p, C.c_int]
     L.poco_smpl_lbs.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 5
     L.poco_realnvp.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    L.poco_realnvp_rep.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
     return L
 
 
@@ -358,18 +359,22 @@ class POCO:
                                     verts.data_ptr(), j49.data_ptr(), _stream()), "poco_smpl_lbs")
         return verts, j49
 
-    def realnvp_log_prob(self, x: torch.Tensor, ctx: torch.Tensor) -> torch.Tensor:
+    def _realnvp(self, x: torch.Tensor, ctx: torch.Tensor, rep: int, forward: int) -> torch.Tensor:
         self.finalize()
         N = x.shape[0]
-        out = torch.empty(N, device=self.device, dtype=torch.float32)
-        check(self._L.poco_realnvp(self._h, N, x.contiguous().data_ptr(), ctx.contiguous().data_ptr(), out.data_ptr(), 0,
-                                   _stream()), "poco_realnvp")
+        rows = (N + rep - 1) // rep
+        if tuple(x.shape) != (N, 9) or tuple(ctx.shape) != (rows, 512):
+            raise PocoHipError(f"realnvp: x must be [N,9] and ctx [ceil(N/rep),512], got {tuple(x.shape)} / {tuple(ctx.shape)} (rep {rep})")
+        out = torch.empty((N, 9) if forward else (N,), device=self.device, dtype=torch.float32)
+        check(self._L.poco_realnvp_rep(self._h, N, x.contiguous().data_ptr(), ctx.contiguous().data_ptr(), int(rep), out.data_ptr(),
+                                       forward, _stream()), "poco_realnvp")
         return out
 
-    def realnvp_forward(self, z: torch.Tensor, ctx: torch.Tensor) -> torch.Tensor:
-        self.finalize()
-        N = z.shape[0]
-        out = torch.empty(N, 9, device=self.device, dtype=torch.float32)
-        check(self._L.poco_realnvp(self._h, N, z.contiguous().data_ptr(), ctx.contiguous().data_ptr(), out.data_ptr(), 1,
-                                   _stream()), "poco_realnvp")
-        return out
+    def realnvp_log_prob(self, x: torch.Tensor, ctx: torch.Tensor, rep: int = 1) -> torch.Tensor:
+        """RealNVP.log_prob(x [N,9], x_cond) (real_nvp.py:55-65).  rep = 1: ctx is [N,512]; rep = 24: ctx is the per-crop
+        [N/24,512] context of nf_head.py:105-110 (its repeat_interleave is not materialised)."""
+        return self._realnvp(x, ctx, rep, 0)
+
+    def realnvp_forward(self, z: torch.Tensor, ctx: torch.Tensor, rep: int = 1) -> torch.Tensor:
+        """RealNVP.forward_p(z [N,9], x_cond) (real_nvp.py:25-38)."""
+        return self._realnvp(z, ctx, rep, 1)

@@ -73,29 +73,6 @@ def convert_crop_coords_to_orig_img(bbox, keypoints, crop_size):
     return kp
 
 
-def joints2d_from_params(joints3d, cam, bboxes, img_w, img_h, cliff: bool, img_res: int = 224, focal_crop: float = 5000.0):
-    """The regressor's `smpl_joints2d` re-derived on the host from (joints3d, cam) - used on the rank that merges
-    other ranks' packed SMPL records in multi-GPU video mode (the record carries no 2-D joints).
-    PARE: smpl_head.py:60-83 with geometry.py:447-463,480-508 (crop-normalised, f = 5000, / (res/2));
-    CLIFF: smplcam_head.py:99-139 (full-image pixels, f = sqrt(W^2+H^2), principal point = image centre)."""
-    J = np.asarray(joints3d, np.float64)
-    cam = np.asarray(cam, np.float64)
-    s, tx, ty = cam[:, 0], cam[:, 1], cam[:, 2]
-    if cliff:
-        b = np.asarray(bboxes, np.float64)
-        bh = np.maximum(b[:, 2], b[:, 3]) / 200.0 * 200.0            # scale * 200 (tester.py:196, smplcam_head.py:62)
-        f = float((img_w ** 2 + img_h ** 2) ** 0.5)
-        tz = 2.0 * f / (bh / 224.0 * 224.0 * s)
-        cx = 2.0 * (b[:, 0] - img_w / 2.0) / (s * bh)
-        cy = 2.0 * (b[:, 1] - img_h / 2.0) / (s * bh)
-        t = np.stack([tx + cx, ty + cy, tz], -1)
-        p = J + t[:, None, :]
-        return np.stack([f * p[..., 0] / p[..., 2] + img_w / 2.0, f * p[..., 1] / p[..., 2] + img_h / 2.0], -1).astype(np.float32)
-    t = np.stack([tx, ty, 2.0 * focal_crop / (img_res * s + 1e-9)], -1)
-    p = J + t[:, None, :]
-    return (np.stack([focal_crop * p[..., 0] / p[..., 2], focal_crop * p[..., 1] / p[..., 2]], -1) / (img_res / 2.0)).astype(np.float32)
-
-
 def write_obj(path, verts, faces=None):
     """Wavefront .obj of one mesh (the reference's --save_obj, tester.py:300-303,532-535: `meshes/<image or person>/
     <idx>.obj`).  verts [V,3] float, faces [F,3] 0-based vertex ids or None (vertex cloud)."""

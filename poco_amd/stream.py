@@ -54,7 +54,7 @@ class CropStream:
         self.want_vertices = want_vertices
         self._slot = 0
         self._L = lib()
-        self._L.poco_crop_normalize.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_int,
+        self._L.poco_crop_normalize.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_double, C.c_int,
                                                 C.c_void_p, C.c_void_p]
         self.focal = float((self.W ** 2 + self.H ** 2) ** 0.5)
 
@@ -73,6 +73,11 @@ class CropStream:
             self.ev_up[k].record(self.copy_stream)
         return k
 
+    def release(self, slot: int) -> None:
+        """Give back a ring slot whose frame will not be handed to run() (a frame without detections, an aborted batch):
+        upload() may reuse it.  run() releases the slots of its `groups` itself (also when it raises)."""
+        self._pending[slot] = False
+
     # -- a full batch: (slot, [n,4] boxes) pairs with sum(n) <= B -----------------------------------------
     def run(self, groups: Sequence[Tuple[int, np.ndarray]], host_buf: int = 0,
             keep: Sequence[int] = ()) -> Tuple[torch.Tensor, int]:
@@ -81,8 +86,22 @@ class CropStream:
         `host_buf` (0/1) selects the pinned staging buffers of this run; alternate it between consecutive runs that
         are in flight together.  `keep`: ring slots whose frame a later run() will crop from again (a frame with more
         people than fit into this batch); all other slots in `groups` become free for upload() once this run's
-        crops are done."""
+        crops are done.  A frame without detections must not stay uploaded: pass it with an empty box array (its slot is
+        released, nothing is cropped) or call release(slot)."""
+        try:
+            return self._run(groups, host_buf, keep)
+        finally:
+            # whatever happened, the slots of this call are no longer waiting for a run(): a failed / asserting call must not
+            # leave the ring guard set for ever (ADVICE r2); slots in `keep` stay reserved for the caller's next run()
+            for slot, _ in groups:
+                if slot not in keep:
+                    self._pending[slot] = False
+
+    def _run(self, groups, host_buf, keep):
         st = torch.cuda.current_stream()
+        groups = [(slot, boxes) for slot, boxes in groups if len(np.asarray(boxes).reshape(-1, 4))]     # empty box arrays: slot released only
+        if not groups:
+            return self.rec_h[host_buf], 0
         self.ev_meta[host_buf].synchronize()                # host: the previous H2D copy out of this staging buffer is done
         mh = self.meta_h[host_buf].numpy()
         n = 0
@@ -114,8 +133,6 @@ class CropStream:
                                               self.batch["img"][lo:lo + k].data_ptr(), C.c_void_p(st.cuda_stream)),
                   "poco_crop_normalize")
             self.ev_free[slot].record(st)
-            if slot not in keep:
-                self._pending[slot] = False
         out = self.m.graph_forward(self.batch, self.out)      # full-B replay; rows >= n are stale crops, ignored
         r = self.rec_d
         r[:, 0:216].copy_(out["pred_pose"].reshape(self.B, 216))

@@ -38,16 +38,18 @@ def calculate_bbox_info(center, scale, orig_shape):
 
 
 def crop_normalize(frame_u8: torch.Tensor, boxes: torch.Tensor, bbox_scale: float = 1.0, res: int = 224) -> torch.Tensor:
-    """frame uint8 [H,W,3] RGB cuda, boxes [N,4] (cx,cy,w,h) cuda fp32 -> [N,3,res,res] fp32."""
+    """frame uint8 [H,W,3] RGB cuda, boxes [N,4] (cx,cy,w,h) cuda float32 or float64 -> [N,3,res,res] fp32: the normalised
+    crop of get_single_image_crop_demo (vibe_image_utils.py:233-266), byte-exact with cv2's fixed-point warpAffine."""
     assert frame_u8.is_cuda and frame_u8.dtype == torch.uint8 and frame_u8.is_contiguous()
+    assert boxes.is_cuda and boxes.dtype in (torch.float32, torch.float64) and boxes.shape[1:] == (4,)
     H, W, _ = frame_u8.shape
     N = boxes.shape[0]
     out = torch.empty(N, 3, res, res, device=frame_u8.device, dtype=torch.float32)
     L = lib()
-    L.poco_crop_normalize.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_void_p,
-                                      C.c_void_p]
-    check(L.poco_crop_normalize(frame_u8.data_ptr(), H, W, boxes.contiguous().data_ptr(), N, float(bbox_scale), res,
-                                out.data_ptr(), C.c_void_p(torch.cuda.current_stream().cuda_stream)), "poco_crop_normalize")
+    fn = L.poco_crop_normalize if boxes.dtype == torch.float32 else L.poco_crop_normalize_f64
+    fn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_void_p, C.c_void_p]
+    check(fn(frame_u8.data_ptr(), H, W, boxes.contiguous().data_ptr(), N, float(bbox_scale), res, out.data_ptr(),
+             C.c_void_p(torch.cuda.current_stream().cuda_stream)), "poco_crop_normalize")
     return out
 
 
@@ -80,8 +82,10 @@ class POCOTester:
     # ---- one batch of detections of one frame ---------------------------------------------------
     def make_batch(self, frame_u8: torch.Tensor, dets: np.ndarray, bbox_scale: float = 1.0) -> Dict[str, torch.Tensor]:
         H, W = int(frame_u8.shape[0]), int(frame_u8.shape[1])
-        dets = np.asarray(dets, dtype=np.float32).reshape(-1, 4)
-        boxes = torch.from_numpy(dets).to(self.device)
+        raw = np.asarray(dets)
+        # the crop follows the detections' own dtype (float64 tracks stay float64: cv2 sees float32(cx) etc. of THOSE values)
+        boxes = torch.from_numpy(np.ascontiguousarray(raw.reshape(-1, 4), np.float64 if raw.dtype == np.float64 else np.float32)).to(self.device)
+        dets = raw.astype(np.float32).reshape(-1, 4)
         centers = dets[:, :2]
         scales = np.maximum(dets[:, 2], dets[:, 3]) / 200.0                        # tester.py:196
         info = np.stack([calculate_bbox_info(c, s, (H, W)) for c, s in zip(centers, scales)])
@@ -106,23 +110,63 @@ class POCOTester:
         return res
 
     @torch.no_grad()
-    def run_on_frames(self, frames, detections: List[np.ndarray], bbox_scale: float = 1.0):
-        """frames: iterable of uint8 [H,W,3] RGB arrays; detections[i]: [n_i,4].  Returns per-frame results."""
-        results = []
+    def iter_frame_results(self, items, bbox_scale: float = 1.0):
+        """items: iterable of (frame uint8 [H,W,3] RGB, detections [n,4]); yields one result dict (or None for a frame without
+        detections) per item, in order.  The reference runs one forward per image (pocolib/core/tester.py:168-213); crops are
+        independent of each other, so here the crops of CONSECUTIVE frames share forwards of up to `batch_size` crops (a photo
+        folder with one person per image would otherwise sit in the launch-bound B = 1 regime) and the
+        rows are handed back per frame.  At most `batch_size` crops and their frames are held at a time."""
+        from collections import deque
         bs = self.model.max_batch
-        for frame, dets in zip(frames, detections):
-            dets = np.asarray(dets, dtype=np.float32).reshape(-1, 4)
-            if len(dets) == 0:
-                results.append(None)
-                continue
-            fr = torch.from_numpy(np.ascontiguousarray(frame)).to(self.device)
-            parts = []
-            for lo in range(0, len(dets), bs):
-                d = dets[lo:lo + bs]
-                out = self.model(self.make_batch(fr, d, bbox_scale), want_segm=False)
-                parts.append(self.postprocess(out, d, frame.shape[1], frame.shape[0]))
-            results.append({k: np.concatenate([p[k] for p in parts], 0) for k in parts[0]})
-        return results
+        queue = deque()                    # frames in arrival order: {"dets", "W", "H", "parts", "todo"}
+        pieces, batches = [], []           # crops waiting for a forward: (entry, lo, k) + their batch dicts
+        npend = 0
+
+        def flush():
+            nonlocal npend
+            if not pieces:
+                return
+            batch = batches[0] if len(batches) == 1 else {k: torch.cat([b[k] for b in batches], 0) for k in batches[0]}
+            out = self.model(batch, want_segm=False)
+            out = {n: (v.cpu() if torch.is_tensor(v) else v) for n, v in out.items()}     # one D2H per tensor, sliced per frame below
+            off = 0
+            for e, lo, k in pieces:
+                sl = {n: (v[off:off + k] if torch.is_tensor(v) else v) for n, v in out.items()}
+                e["parts"].append(self.postprocess(sl, e["dets"][lo:lo + k], e["W"], e["H"]))
+                e["todo"] -= k
+                off += k
+            pieces.clear()
+            batches.clear()
+            npend = 0
+
+        def drain():
+            while queue and queue[0]["todo"] == 0:
+                e = queue.popleft()
+                yield None if not e["parts"] else {k: np.concatenate([p[k] for p in e["parts"]], 0) for k in e["parts"][0]}
+
+        for frame, dets in items:
+            raw = np.asarray(dets)
+            raw = raw.reshape(-1, 4) if raw.size else np.zeros((0, 4), np.float32)
+            e = {"dets": raw, "W": frame.shape[1], "H": frame.shape[0], "parts": [], "todo": len(raw)}
+            queue.append(e)
+            if len(raw):
+                fr = torch.from_numpy(np.ascontiguousarray(frame)).to(self.device)
+                lo = 0
+                while lo < len(raw):
+                    k = min(bs - npend, len(raw) - lo)
+                    batches.append(self.make_batch(fr, raw[lo:lo + k], bbox_scale))
+                    pieces.append((e, lo, k))
+                    npend += k
+                    lo += k
+                    if npend == bs:
+                        flush()
+            yield from drain()
+        flush()
+        yield from drain()
+
+    def run_on_frames(self, frames, detections: List[np.ndarray], bbox_scale: float = 1.0):
+        """frames: iterable of uint8 [H,W,3] RGB arrays; detections[i]: [n_i,4].  Returns the per-frame results."""
+        return list(self.iter_frame_results(zip(frames, detections), bbox_scale))
 
     @torch.no_grad()
     def run_on_video(self, tracking_results: dict, frames, orig_width: int, orig_height: int, bbox_scale: float = 1.0,
@@ -170,7 +214,7 @@ class POCOTester:
             while group:                     # a frame with more people than fit goes out in pieces
                 room = bs - len(pend_meta)
                 part, group = group[:room], group[room:]
-                dets = np.stack([np.asarray(tracking_results[pid]["bbox"][slot], np.float32) for _, pid, slot in part])
+                dets = np.stack([np.asarray(tracking_results[pid]["bbox"][slot]) for _, pid, slot in part])   # keeps the tracks' dtype
                 pend_batches.append(self.make_batch(fr, dets, bbox_scale))
                 pend_meta.extend((pid, slot) for _, pid, slot in part)
                 if len(pend_meta) == bs:
@@ -183,7 +227,8 @@ class POCOTester:
             return stacked
         return {pid: self._finish_track(tr, stacked[pid], orig_width, orig_height) for pid, tr in tracking_results.items()}
 
-    def _finish_track(self, tr: dict, st: Dict[str, np.ndarray], orig_width: int, orig_height: int) -> dict:
+    def _finish_track(self, tr: dict, st: Dict[str, np.ndarray], orig_width: int, orig_height: int,
+                      smooth: Optional[bool] = None) -> dict:
         """Per-track post-processing of tester.py:416-479 on the raw per-frame network outputs `st` (keys: pred_cam,
         smpl_vertices, pred_pose, pred_shape, smpl_joints3d, smpl_joints2d, var_pose): optional one-euro smoothing
         (meshes / 3-D joints re-derived from the filtered pose; the 2-D joints stay those of the raw prediction, as in
@@ -191,7 +236,7 @@ class POCOTester:
         bboxes = np.asarray(tr["bbox"], np.float32).reshape(-1, 4)
         pose, betas = st["pred_pose"], st["pred_shape"]
         verts, j3d = st["smpl_vertices"], st["smpl_joints3d"]
-        if getattr(self.args, "smooth", False):               # tester.py:442-447
+        if getattr(self.args, "smooth", False) if smooth is None else smooth:               # tester.py:442-447
             from .smooth import smooth_pose
             verts, pose, j3d = smooth_pose(self.model, pose, betas, getattr(self.args, "min_cutoff", 0.004),
                                            getattr(self.args, "beta", 1.5))
@@ -209,39 +254,48 @@ class POCOTester:
         }
 
     def run_on_image_folder(self, image_folder: str, detections, output_path: str, bbox_scale=1.0):
-        """pocolib/core/tester.py:153-245: images are streamed one at a time (decode -> regress -> write), every
-        `--skip_frame`-th image of the sorted listing (tester.py:171), so host memory does not grow with the folder."""
+        """pocolib/core/tester.py:153-245: images are streamed (decode -> regress -> write), every `--skip_frame`-th image of
+        the sorted listing (tester.py:171), so host memory does not grow with the folder.  Unlike the reference's one
+        forward per image, consecutive images share forwards of up to --batch_size crops (iter_frame_results); what is
+        written per image is the same."""
         from PIL import Image
         names_all = sorted(x for x in os.listdir(image_folder) if x.lower().endswith(IMG_EXT))
         skip = max(int(getattr(self.args, "skip_frame", 1) or 1), 1)
         os.makedirs(output_path, exist_ok=True)
-        n_img = n_crops = 0
-        dt = 0.0
-        for pos in range(0, len(names_all), skip):
-            n = names_all[pos]
-            img = np.asarray(Image.open(os.path.join(image_folder, n)).convert("RGB"))
-            d = None
-            if isinstance(detections, dict):
-                d = detections.get(n)
-            elif detections is not None and pos < len(detections):      # reference cache: indexed by image position
-                d = detections[pos]
-            if d is not None and len(d) > 0:
-                d = np.asarray(d, dtype=np.float32).reshape(-1, 4)
-            else:                       # no detector in scope: one centred square box over the image
-                H, W = img.shape[:2]
-                s = float(min(H, W))
-                d = np.array([[W / 2.0, H / 2.0, s, s]], dtype=np.float32)
-            t0 = time.time()
-            r = self.run_on_frames([img], [d], bbox_scale)[0]
-            torch.cuda.synchronize()
-            dt += time.time() - t0
+        picked = [(pos, names_all[pos]) for pos in range(0, len(names_all), skip)]
+        counts = []
+
+        def items():
+            for pos, n in picked:
+                img = np.asarray(Image.open(os.path.join(image_folder, n)).convert("RGB"))
+                d = None
+                if isinstance(detections, dict):
+                    d = detections.get(n)
+                elif detections is not None and pos < len(detections):      # reference cache: indexed by image position
+                    d = detections[pos]
+                if d is not None and len(d) > 0:
+                    d = np.asarray(d).reshape(-1, 4)
+                    if d.dtype not in (np.float32, np.float64):
+                        d = d.astype(np.float32)
+                else:                       # no detector in scope: one centred square box over the image
+                    H, W = img.shape[:2]
+                    s = float(min(H, W))
+                    d = np.array([[W / 2.0, H / 2.0, s, s]], dtype=np.float32)
+                counts.append(len(d))
+                yield img, d
+
+        t0 = time.time()
+        n_img = 0
+        for (pos, n), r in zip(picked, self.iter_frame_results(items(), bbox_scale)):
             n_img += 1
-            n_crops += len(d)
             if r is not None:
                 np.savez_compressed(os.path.join(output_path, os.path.splitext(n)[0] + "_poco.npz"), **r)
                 if getattr(self.args, "save_obj", False):          # tester.py:300-303
                     self._save_meshes(os.path.join(output_path, "meshes", os.path.splitext(n)[0]), r["verts"],
                                       [f"{i:06d}" for i in range(len(r["verts"]))])
+        torch.cuda.synchronize()
+        dt = time.time() - t0
+        n_crops = int(sum(counts))
         return {"images": n_img, "crops": n_crops, "seconds": dt, "fps": n_img / max(dt, 1e-9),
                 "crops_per_s": n_crops / max(dt, 1e-9)}
 
@@ -269,9 +323,11 @@ def _run_on_video_folder(self, frame_folder: str, tracking_path: Optional[str], 
     world = tdist.get_world_size() if tdist.is_available() and tdist.is_initialized() else 1
     rank = tdist.get_rank() if world > 1 else 0
     t0 = time.time()
+    mine = tracking
     if world > 1:
-        # whole tracks are the unit of sharding (temporal smoothing stays local); the only exchange is
-        # one all-gather of the packed per-frame SMPL records, everything else is re-derived from them
+        # whole tracks are the unit of sharding (temporal smoothing stays local: the owning rank smooths and
+        # finishes its tracks); the only exchange is one all-gather of the packed per-frame SMPL records, from which rank 0
+        # - the writer - re-derives the meshes of the tracks regressed elsewhere
         from . import dist as pdist
         mine = pdist.shard_tracks(tracking, rank, world)
         raw = self.run_on_video(mine, load, W, H, bbox_scale, raw=True) if mine else {}
@@ -283,56 +339,63 @@ def _run_on_video_folder(self, frame_folder: str, tracking_path: Optional[str], 
     if rank != 0:
         tdist.barrier()
         return {"rank": rank, "tracks_local": len(mine), "seconds": dt}
-    os.makedirs(output_path, exist_ok=True)
-    flat = {f"{pid}/{k}": v for pid, r in results.items() for k, v in r.items() if v is not None}
-    np.savez_compressed(os.path.join(output_path, "poco_results.npz"), **flat)
-    if getattr(self.args, "save_obj", False):                      # tester.py:532-535
-        for pid, r in results.items():
-            sub = f"{int(pid):04d}" if str(pid).lstrip("-").isdigit() else str(pid)
-            self._save_meshes(os.path.join(output_path, "meshes", sub), r["verts"], [f"{int(f):06d}" for f in r["frame_ids"]])
+    try:
+        os.makedirs(output_path, exist_ok=True)
+        flat = {f"{pid}/{k}": v for pid, r in results.items() for k, v in r.items() if v is not None}
+        np.savez_compressed(os.path.join(output_path, "poco_results.npz"), **flat)
+        if getattr(self.args, "save_obj", False):                      # tester.py:532-535
+            for pid, r in results.items():
+                sub = f"{int(pid):04d}" if str(pid).lstrip("-").isdigit() else str(pid)
+                self._save_meshes(os.path.join(output_path, "meshes", sub), r["verts"], [f"{int(f):06d}" for f in r["frame_ids"]])
+    finally:
+        if world > 1:               # the other ranks wait here: release them also when the write fails
+            tdist.barrier()
     n_crops = sum(len(v["frames"]) for v in tracking.values())
     n_frames = len({int(f) for v in tracking.values() for f in v["frames"]})
-    if world > 1:
-        tdist.barrier()
     return {"images": n_frames, "crops": n_crops, "tracks": len(tracking), "seconds": dt, "ranks": world,
             "fps": n_frames / max(dt, 1e-9), "crops_per_s": n_crops / max(dt, 1e-9)}
 
 
 def _merge_rank_results(self, local_raw: dict, tracking: dict, W: int, H: int) -> dict:
-    """Multi-GPU video mode: every rank packs the RAW per-frame outputs of its tracks into records [pose 216 | betas 10 |
-    cam 3 | var_pose 24 | global confidence 1], ONE all-gather (RCCL when the group's backend is nccl) hands every rank
-    every track, and the mesh-level entries of tracks regressed elsewhere are re-derived from the gathered parameters
-    with the batched LBS operator - 1 KB per crop crosses xGMI instead of 83 KB of vertices.  Smoothing and the
-    uncertainty post-processing then run identically on every rank (_finish_track)."""
+    """Multi-GPU video mode.  The OWNING rank finishes its tracks (one-euro smoothing included, _finish_track) and packs
+    per frame [final pose 216 | betas 10 | cam 3 | raw var_pose 24 | global confidence 1 | raw crop-space 2-D joints 98];
+    ONE all-gather (RCCL when the group's backend is nccl) moves 1.4 KB per crop instead of 83 KB of vertices.  Only rank 0
+    - the writer - re-derives the meshes / 3-D joints of the tracks regressed elsewhere from the gathered (already
+    smoothed) pose with the batched LBS operator; the other ranks return their own tracks (no rank repeats
+    another rank's LBS, smoothing or D2H)."""
+    import torch.distributed as tdist
     from . import dist as pdist
     dev = pdist.collective_device()
-    recs = {}
+    rank = tdist.get_rank()
+    out, recs = {}, {}
     for pid, st in local_raw.items():
-        out = {k: torch.from_numpy(st[k]) for k in ("pred_pose", "pred_shape", "pred_cam", "var_pose")}
-        recs[str(pid)] = pdist.pack_records(out, head=self.backbone, kinematic=self.model_cfg.POCO.KINEMATIC_UNCERT).to(dev)
-    full = pdist.gather_track_records(recs, device=dev)
-    out = {}
-    cliff = "cliff" in self.backbone
-    res = self.model_cfg.DATASET.IMG_RES
+        fin = self._finish_track(tracking[pid], st, W, H)
+        out[pid] = fin
+        t = {"pred_pose": torch.from_numpy(np.ascontiguousarray(fin["pose"], np.float32)), "pred_shape": torch.from_numpy(st["pred_shape"]),
+             "pred_cam": torch.from_numpy(st["pred_cam"]), "var_pose": torch.from_numpy(st["var_pose"])}
+        rec = pdist.pack_records(t, head=self.backbone, kinematic=self.model_cfg.POCO.KINEMATIC_UNCERT)
+        j2 = torch.from_numpy(np.ascontiguousarray(st["smpl_joints2d"], np.float32)).reshape(rec.shape[0], 98)
+        recs[str(pid)] = torch.cat([rec, j2], 1).to(dev)
+    full = pdist.gather_track_records(recs, device=dev, width=pdist.VIDEO_REC)
+    if rank != 0:
+        return out
     for pid, tr in tracking.items():
-        st = local_raw.get(pid)
-        if st is None:
-            rec = full[str(pid)].cpu().numpy()
-            T = rec.shape[0]
-            pose, betas, cam = rec[:, 0:216].reshape(T, 24, 3, 3), rec[:, 216:226], rec[:, 226:229]
-            verts = np.empty((T, 6890, 3), np.float32)
-            j3d = np.empty((T, 49, 3), np.float32)
-            for lo in range(0, T, self.model.max_batch):
-                hi = min(T, lo + self.model.max_batch)
-                v, j = self.model.smpl_lbs(torch.from_numpy(np.ascontiguousarray(betas[lo:hi])).to(self.device),
-                                           torch.from_numpy(np.ascontiguousarray(pose[lo:hi])).to(self.device))
-                verts[lo:hi], j3d[lo:hi] = v.cpu().numpy(), j.cpu().numpy()
-            bboxes = np.asarray(tr["bbox"], np.float32).reshape(-1, 4)
-            st = {"pred_cam": cam, "smpl_vertices": verts, "pred_pose": pose, "pred_shape": betas, "smpl_joints3d": j3d,
-                  "smpl_joints2d": postproc.joints2d_from_params(j3d, cam, bboxes, W, H, cliff, res),
-                  "var_pose": rec[:, 229:253]}
-        out[pid] = self._finish_track(tr, st, W, H)
-    return out
+        if pid in out:
+            continue
+        rec = full[str(pid)].cpu().numpy()
+        T = rec.shape[0]
+        pose, betas, cam = rec[:, 0:216].reshape(T, 24, 3, 3), rec[:, 216:226], rec[:, 226:229]
+        verts = np.empty((T, 6890, 3), np.float32)
+        j3d = np.empty((T, 49, 3), np.float32)
+        for lo in range(0, T, self.model.max_batch):
+            hi = min(T, lo + self.model.max_batch)
+            v, j = self.model.smpl_lbs(torch.from_numpy(np.ascontiguousarray(betas[lo:hi])).to(self.device),
+                                       torch.from_numpy(np.ascontiguousarray(pose[lo:hi])).to(self.device))
+            verts[lo:hi], j3d[lo:hi] = v.cpu().numpy(), j.cpu().numpy()
+        st = {"pred_cam": cam, "smpl_vertices": verts, "pred_pose": pose, "pred_shape": betas, "smpl_joints3d": j3d,
+              "smpl_joints2d": rec[:, pdist.REC:pdist.VIDEO_REC].reshape(T, 49, 2), "var_pose": rec[:, 229:253]}
+        out[pid] = self._finish_track(tr, st, W, H, smooth=False)        # the owner already smoothed this pose
+    return {pid: out[pid] for pid in tracking}
 
 
 POCOTester.run_on_video_folder = _run_on_video_folder

@@ -269,6 +269,43 @@ def test_realnvp_op(variant, L, cuda):
     assert np.abs(back.numpy() - x.numpy()).max() < 1e-3
 
 
+@pytest.mark.parametrize("variant,L", [("hrnet_w32-pare", 3), ("resnet50-cliff", 1)])
+@pytest.mark.parametrize("N", [1, 24, 1536, 3072, 24 * 128 * 8 + 5])
+def test_realnvp_op_at_reference_sizes(variant, L, N, cuda):
+    """the flow at the sizes the reference runs it - N = B*24 rows of 9 residuals with the crop's 512-d
+    context repeated per joint (nf_head.py:93-110: bar_pose.reshape(-1, 9), repeat_interleave(context, 24)): B = 64 -> 1536,
+    B = 128 -> 3072, 2*L = 2 and 6 coupling layers, plus 1 row, one crop's 24 rows and a ragged N far above any grid size.
+    Against the oracle (pinned to the reference's RealNVP), rows bitwise independent of their neighbours."""
+    from oracle import poco_ref
+    m = util.make_engine(variant, max_batch=2)
+    sd = poco_ref.to_torch(util.synth_weights(variant))
+    r = np.random.default_rng(80 + N % 97)
+    crops = (N + 23) // 24
+    c = torch.from_numpy(np.repeat(r.standard_normal((crops, 512)).astype(np.float32), 24, axis=0)[:N].copy())
+    x = torch.from_numpy(np.abs(r.standard_normal((N, 9))).astype(np.float32) * 1.5)
+    ref_lp = poco_ref.realnvp_log_prob(sd, x, c).numpy()
+    ref_fw = poco_ref.realnvp_forward(sd, x, c).numpy()
+    xd, cd = x.to(cuda), c.to(cuda)
+    lp = _np(m.realnvp_log_prob(xd, cd))
+    fw = _np(m.realnvp_forward(xd, cd))
+    assert lp.shape == (N,) and fw.shape == (N, 9)
+    assert np.abs(lp - ref_lp).max() < 1e-3 * max(1.0, np.abs(ref_lp).max()), np.abs(lp - ref_lp).max()
+    assert np.abs(fw - ref_fw).max() < 1e-3 * max(1.0, np.abs(ref_fw).max()), np.abs(fw - ref_fw).max()
+    assert np.abs(ref_lp).max() > 1.0 and (N == 1 or np.std(ref_lp) > 1e-2)            # the comparison is not vacuous
+    # the reference's call shape (one context per crop, used by its 24 rows) without the repeat: same rows, bitwise
+    cc = cd[::24].contiguous()
+    assert np.array_equal(_np(m.realnvp_log_prob(xd, cc, rep=24)), lp) or N > 256      # (the context GEMM kernel depends on the row count)
+    assert np.abs(_np(m.realnvp_log_prob(xd, cc, rep=24)) - lp).max() < 1e-4 * max(1.0, np.abs(lp).max())
+    assert np.abs(_np(m.realnvp_forward(xd, cc, rep=24)) - fw).max() < 1e-4 * max(1.0, np.abs(fw).max())
+    if N >= 48:      # a row's result does not depend on which rows share its block (same GEMM kernel for <= 256 context rows)
+        sub = slice(17, 41)
+        a = _np(m.realnvp_log_prob(xd[sub].contiguous(), cd[sub].contiguous()))
+        b = _np(m.realnvp_forward(xd[sub].contiguous(), cd[sub].contiguous()))
+        if N <= 256:
+            assert np.array_equal(a, lp[sub]) and np.array_equal(b, fw[sub])
+        assert np.abs(a - lp[sub]).max() < 1e-4 * max(1.0, np.abs(lp).max()) and np.abs(b - fw[sub]).max() < 1e-4 * max(1.0, np.abs(fw).max())
+
+
 @pytest.mark.parametrize("variant,B", [("hrnet_w48_cls-cliff", 64), ("hrnet_w32-pare", 32), ("resnet50-cliff", 128)])
 def test_full_size_properties(variant, B, cuda):
     """Size-independent properties at BASELINE.json's batch sizes (where the CPU oracle would take minutes):

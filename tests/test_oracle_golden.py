@@ -149,3 +149,68 @@ def test_smpl_invariants():
     root_a = ja[:, 8:9] * 0 + smpl_np.smpl_lbs_np(smpl, betas, Rg)[1][:, 8:9]  # joint_map[8] == 0 (pelvis)
     rel_a, rel_b = va - root_a, vb - root_a
     assert np.abs(rel_b - rel_a @ Q.T.astype(np.float64)).max() < 1e-5
+
+
+# ---- crop: the cv2 fixed-point restatement (oracle/crop_np.py) -------------------------------------------------------------
+def test_crop_points_pinned_to_reference(ops):
+    """the float32 point triples handed to cv2.getAffineTransform were recorded from the reference's own
+    gen_trans_from_patch_cv (vibe_image_utils.py:58-92, cv2 stubbed by a recorder; oracle/gen_golden.py)."""
+    from oracle import crop_np
+    for bx, sc, s, d in zip(ops["crop_boxes"], ops["crop_scale"], ops["crop_src"], ops["crop_dst"]):
+        ps, pd = crop_np.patch_points(*bx, 224, sc)
+        assert ps.dtype == np.float32 and np.array_equal(ps, s) and np.array_equal(pd, d)
+
+
+def test_crop_bilinear_table_and_closed_form():
+    """BilinearTab_i as initInterTab2D builds it: every entry sums to 2^15, entry (0,0) is {32767,0,0,1}, and the closed
+    form the HIP kernel uses ((32-fy)(32-fx)*32, ... with that one exception) IS the table."""
+    from oracle import crop_np
+    tab = crop_np.bilinear_tab_i()
+    assert tab.shape == (1024, 4) and (tab.sum(1) == 32768).all() and tab.min() >= 0 and tab.max() <= 32767
+    assert tab[0].tolist() == [32767, 0, 0, 1]
+    for fy in range(32):
+        for fx in range(32):
+            w = [(32 - fy) * (32 - fx) * 32, (32 - fy) * fx * 32, fy * (32 - fx) * 32, fy * fx * 32]
+            if fx == 0 and fy == 0:
+                w = [32767, 0, 0, 1]
+            assert tab[fy * 32 + fx].tolist() == w
+
+
+def test_crop_lu_solve_matches_exact_solution():
+    """LUImpl<double> restated: on the affine system of an axis-aligned box the solution is the closed form
+    [[s,0,tx],[0,s,ty]] up to double rounding; pivoting is exercised by a rotated triple."""
+    from oracle import crop_np
+    src, dst = crop_np.patch_points(640.25, 360.5, 300.0, 300.0, 224, 1.1)
+    M = crop_np.get_affine_transform_cv(src, dst)
+    s = 112.0 / float(src[2, 0] - src[0, 0])
+    assert np.allclose(M, [[s, 0, 112 - s * float(src[0, 0])], [0, 112.0 / float(src[1, 1] - src[0, 1]), 112 - 112.0 / float(src[1, 1] - src[0, 1]) * float(src[0, 1])]],
+                       rtol=1e-13, atol=1e-10)
+    rot = np.float32([[0, 0], [0, 1], [1, 0]]) @ np.float32([[0.6, 0.8], [-0.8, 0.6]]) * 50 + np.float32([10, 20])
+    M2 = crop_np.get_affine_transform_cv(rot.astype(np.float32), dst)
+    back = (M2[:, :2] @ rot.astype(np.float64).T).T + M2[:, 2]
+    assert np.abs(back - dst).max() < 1e-9
+    assert np.abs(np.linalg.solve(np.array([[*p, 1.0] for p in rot], np.float64), dst.astype(np.float64)).T - M2).max() < 1e-10
+
+
+def test_crop_fixed_point_properties():
+    """identity box reproduces the image bytes; integer translations are exact copies; the result never differs from the
+    exact-weight bilinear value by more than the 1/32-px quantisation allows; outside pixels are 0 (BORDER_CONSTANT)."""
+    from oracle import crop_np
+    r = np.random.default_rng(0)
+    img = r.integers(0, 256, (300, 400, 3), dtype=np.uint8)
+    assert np.array_equal(crop_np.crop_u8_np(img, [[112, 112, 224, 224]])[0], img[:224, :224])
+    assert np.array_equal(crop_np.crop_u8_np(img, [[112 + 37, 112 + 21, 224, 224]])[0], img[21:245, 37:261])
+    far = crop_np.crop_u8_np(img, [[-500, -500, 100, 100]])[0]
+    assert far.max() == 0
+    edge = crop_np.crop_u8_np(img, [[0, 0, 224, 224]])[0]            # top-left quadrant lies outside
+    assert edge[:111, :111].max() == 0 and np.array_equal(edge[112:, 112:], img[:112, :112])
+    yy, xx = np.mgrid[0:300, 0:400]
+    smooth = np.stack([xx * 0.6 + 5, yy * 0.8 + 3, (xx + yy) * 0.35], -1).astype(np.uint8)
+    boxes = np.array([[200.3, 150.7, 180.2, 160.9], [120, 90, 400, 333]], np.float64)
+    u = crop_np.crop_u8_np(smooth, boxes, 1.1).astype(np.float64)
+    f = crop_np.crop_normalize_float_np(smooth, boxes, 1.1)
+    inner = (slice(None), slice(40, 180), slice(40, 180))
+    assert np.abs(u - f)[inner].max() <= 1.6           # gradients < 1 grey level per px: 1/64 px + rounding
+    # normalisation is ToTensor + Normalize in float32
+    n = crop_np.normalize_np(np.full((1, 2, 2, 3), 255, np.uint8))
+    assert np.allclose(n[0, :, 0, 0], (1 - crop_np.MEAN) / crop_np.STD, rtol=1e-6)

@@ -110,3 +110,44 @@ def test_lbs_oracle_against_real_smplx():
     assert st == va.OK, msg
     st, msg = va.stage_lbs(args, smpl)
     assert st == va.OK, msg
+
+
+def test_crop_stage_logic_and_skip():
+    """Stage 4 (crop vs the real cv2): skips cleanly where cv2 is absent (this image); its comparison logic is exercised with a
+    stand-in `cv2` built from the oracle itself (must report zero differences) and with a deliberately different warp (exact
+    float weights, what the round-2 kernel did: must be reported as differing)."""
+    import types
+    from oracle import crop_np
+    try:
+        import cv2  # noqa: F401
+        have = True
+    except Exception:
+        have = False
+    args = va.argparse.Namespace(device="cuda:0")
+    if not have:
+        st, msg = va.stage_crop(args)
+        assert st == va.SKIP and "cv2" in msg
+    fake = types.SimpleNamespace(INTER_LINEAR=1, BORDER_CONSTANT=0, __version__="stand-in",
+                                 getAffineTransform=lambda s, d: crop_np.get_affine_transform_cv(s, d),
+                                 warpAffine=lambda img, M, size, flags, borderMode: crop_np.warp_affine_u8(img, M, size[0]))
+    w = va.crop_against_cv2(fake, n=3)
+    assert w["matrix_bits"] == 0 and w["u8_pixels"] == 0
+
+    def float_warp(img, M, size, flags, borderMode):
+        Mi = crop_np.invert_affine_cv(M)
+        ys, xs = np.meshgrid(np.arange(size[1], dtype=np.float64), np.arange(size[0], dtype=np.float64), indexing="ij")
+        sx, sy = Mi[0] * xs + Mi[1] * ys + Mi[2], Mi[3] * xs + Mi[4] * ys + Mi[5]
+        x0, y0 = np.floor(sx).astype(int), np.floor(sy).astype(int)
+        fx, fy = (sx - x0)[..., None], (sy - y0)[..., None]
+        H, W = img.shape[:2]
+
+        def px(xx, yy):
+            ok = (xx >= 0) & (xx < W) & (yy >= 0) & (yy < H)
+            return np.where(ok[..., None], img[np.clip(yy, 0, H - 1), np.clip(xx, 0, W - 1)].astype(np.float64), 0.0)
+
+        v = (1 - fy) * ((1 - fx) * px(x0, y0) + fx * px(x0 + 1, y0)) + fy * ((1 - fx) * px(x0, y0 + 1) + fx * px(x0 + 1, y0 + 1))
+        return np.clip(np.rint(v), 0, 255).astype(np.uint8)
+
+    fake.warpAffine = float_warp
+    w2 = va.crop_against_cv2(fake, n=3)
+    assert w2["u8_pixels"] > 0

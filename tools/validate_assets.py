@@ -15,6 +15,10 @@ Every stage whose inputs are missing is reported as SKIPPED (exit code 0); a sta
   3. Checkpoint: strict load of data/poco_{pare,cliff}.pt through poco_amd.checkpoint (pocolib/models/poco.py:131-154,
      train_utils.py:69-136): reports missing / unexpected / tolerated-unused keys and shape mismatches without needing a GPU;
      with a GPU it finalises the engine and runs one forward on a synthetic crop (finite outputs, orthonormal rotations).
+  4. Crop (needs `cv2` importable; licence-free): the reference's per-detection crop - cv2.getAffineTransform +
+     cv2.warpAffine(INTER_LINEAR, BORDER_CONSTANT) on uint8 exactly as pocolib/utils/vibe_image_utils.py:58-107 calls them - against
+     the fixed-point restatement oracle/crop_np.py (uint8, byte for byte; the transform matrix bit for bit) and, with a GPU, against
+     poco_crop_normalize.  `--crop` runs only this stage.
 """
 from __future__ import annotations
 
@@ -180,6 +184,58 @@ def stage_checkpoint(args, smpl):
     return (OK if ok else FAIL), msg + f" | forward on 2 synthetic crops: finite={finite}, |RR^T-I|={ortho:.1e}"
 
 
+def crop_against_cv2(cv2, n: int = 64, seed: int = 0, device=None):
+    """Random frames / boxes through the real cv2 calls the reference makes vs oracle/crop_np.py (and the HIP kernel on `device`).
+    `cv2` is passed in so that the CPU test can hand over a stand-in built from the oracle itself (logic check only)."""
+    from oracle import crop_np
+    r = np.random.default_rng(seed)
+    frame = r.integers(0, 256, (720, 1280, 3), dtype=np.uint8)
+    boxes = np.stack([r.uniform(-60, 1340, n), r.uniform(-60, 780, n), r.uniform(8, 900, n), r.uniform(8, 900, n)], 1)
+    boxes[0] = (112, 112, 224, 224)
+    worst = {"matrix_bits": 0, "u8_pixels": 0, "u8_maxdiff": 0, "gpu_values": 0}
+    for dt in (np.float32, np.float64):
+        for scale in (1.0, 1.1, 1.2):
+            bx = boxes.astype(dt).astype(np.float64)                 # numpy 1.18: float32 box * Python float promotes to float64
+            crops = []
+            for (cx, cy, w, h) in bx:
+                src, dst = crop_np.patch_points(cx, cy, w, h, 224, scale)
+                M = cv2.getAffineTransform(np.float32(src), np.float32(dst))
+                worst["matrix_bits"] += int((np.asarray(M, np.float64) != crop_np.get_affine_transform_cv(src, dst)).sum())
+                crops.append(cv2.warpAffine(frame.copy(), M, (224, 224), flags=cv2.INTER_LINEAR, borderMode=cv2.BORDER_CONSTANT))
+            ref = np.stack(crops)
+            mine = crop_np.crop_u8_np(frame, bx, scale)
+            d = np.abs(ref.astype(np.int32) - mine.astype(np.int32))
+            worst["u8_pixels"] += int((d > 0).sum())
+            worst["u8_maxdiff"] = max(worst["u8_maxdiff"], int(d.max()))
+            if device is not None:
+                import torch
+                from poco_amd.tester import crop_normalize
+                out = crop_normalize(torch.from_numpy(frame).to(device), torch.from_numpy(boxes.astype(dt)).to(device), scale)
+                worst["gpu_values"] += int((out.cpu().numpy() != crop_np.normalize_np(ref)).sum())
+    return worst
+
+
+def stage_crop(args):
+    try:
+        import cv2
+    except Exception as e:                                     # noqa: BLE001
+        return SKIP, f"cv2 is not importable ({type(e).__name__}); the reference pins opencv-python==4.5.5.64"
+    dev = None
+    try:
+        import torch
+        if torch.cuda.is_available():
+            dev = args.device
+    except Exception:                                          # noqa: BLE001
+        pass
+    w = crop_against_cv2(cv2, device=dev)
+    msg = (f"cv2 {cv2.__version__}: 384 crops; getAffineTransform entries differing {w['matrix_bits']}, uint8 pixels differing "
+           f"{w['u8_pixels']} (max {w['u8_maxdiff']} grey levels)" + (f", HIP kernel values differing {w['gpu_values']}" if dev else " (no GPU: HIP kernel not compared)"))
+    ok = w["u8_pixels"] == 0 and w["gpu_values"] == 0
+    if not ok and not cv2.__version__.startswith("4.5"):
+        msg += " - note: OpenCV >= 4.11 ships a different (floating-point) warpAffine; the reference pins 4.5.5.64"
+    return (OK if ok else FAIL), msg
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser(description=__doc__.split("\n")[0])
     ap.add_argument("--smpl-pkl", default="data/smpl/SMPL_NEUTRAL.pkl")
@@ -190,12 +246,18 @@ def main(argv=None):
     ap.add_argument("--cfg", default="configs/demo_poco_cliff.yaml")
     ap.add_argument("--inf_model", default="best")
     ap.add_argument("--device", default="cuda:0")
+    ap.add_argument("--crop", action="store_true", help="only stage 4: the crop against the real cv2")
     args = ap.parse_args(argv)
     results = []
+    if args.crop:
+        st, msg = stage_crop(args)
+        print(f"[{st:7s}] 4 crop vs cv2: {msg}")
+        return 1 if st == FAIL else 0
     st, msg, smpl = stage_smpl_file(args)
     results.append(("1 SMPL file", st, msg))
     results.append(("2 LBS vs smplx", *stage_lbs(args, smpl)))
     results.append(("3 checkpoint", *stage_checkpoint(args, smpl)))
+    results.append(("4 crop vs cv2", *stage_crop(args)))
     for name, st, msg in results:
         print(f"[{st:7s}] {name}: {msg}")
     return 1 if any(st == FAIL for _, st, _ in results) else 0
