@@ -425,6 +425,7 @@ def main():
     from poco_amd import dist as pdist
     gathered = torch.empty(world * B, pdist.REC, device=device) if world > 1 else None
     flops_per_crop = sum(f for _, f, _ in model.ops())
+    checked = []            # the RCCL buffers are validated once, before the first collective
 
     def step():
         if args.no_graph:
@@ -434,6 +435,9 @@ def main():
         if world > 1 and not args.no_gather:
             rec = pdist.pack_records(out, head=args.variant)
             if args.backend == "nccl":
+                if not checked:
+                    pdist.check_collective_buffers(rec, gathered, world, "nccl", device)
+                    checked.append(True)
                 dist.all_gather_into_tensor(gathered, rec)          # RCCL over xGMI, device buffers
             else:                                                   # gloo smoke path: staged through the host
                 parts = [torch.empty(B, pdist.REC) for _ in range(world)]

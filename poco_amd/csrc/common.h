@@ -21,6 +21,8 @@ enum { POCO_OK = 0, POCO_ERR_ARG = 1, POCO_ERR_HIP = 2, POCO_ERR_STATE = 3, POCO
        POCO_ERR_SHAPE = 5 };
 
 void poco_set_error(const std::string& msg);
+// Compute units of the current device (hipDeviceAttributeMultiprocessorCount; 256 on MI355X), cached per thread and device.
+int poco_num_cus();
 
 // ---------------------------------------------------------------------------------------------
 // Convolution (implicit GEMM on v_mfma_f32_16x16x4_f32), NHWC activations.
@@ -48,6 +50,8 @@ struct ConvCfg {
                //    (MT,NT) in {(2,4),(4,2),(4,4),(7,2),(7,4),(8,2)}, R = operand prefetch depth (2|3), NI = load schedule 1..6
                // 9: ALG 6 with coalesced global traffic: pixel / output tiles turned into the MFMA lane order through
                //    wave-private LDS (gemm1x1t.hip): (MT,NT) in {(4,4),(7,2),(7,4),(8,2)}, R = NI = 1
+               // 10: 3x3 conv (stride 1|2) as a register-direct gather GEMM over K = 9*Cin, no LDS / barriers (gemm3x3.hip):
+               //    (MT,NT) in {(2,4),(4,2..4),(7,2..4),(8,2)}, R = operand prefetch depth (2|3), NI = load schedule 1|3|6
 };
 constexpr int CONV_CFG_INTS = 7;   // ints per configuration in the C ABI / tuning table
 inline ConvCfg conv_cfg_from(const int* c) { return ConvCfg{c[0], c[1], c[2], c[3], c[4], c[5], c[6]}; }
@@ -100,6 +104,10 @@ int gemm1x1_launch(const ConvDesc& d, const ConvCfg& cfg, hipStream_t stream);
 bool gemm1x1t_cfg_valid(const ConvDesc& d, const ConvCfg& cfg);
 size_t gemm1x1t_lds_bytes(const ConvDesc& d, const ConvCfg& cfg);
 int gemm1x1t_launch(const ConvDesc& d, const ConvCfg& cfg, hipStream_t stream);
+
+// ---- 3x3 convs as a register-direct gather GEMM (gemm3x3.hip), ALG 10 -------------------------------------
+bool gemm3x3_cfg_valid(const ConvDesc& d, const ConvCfg& cfg);
+int gemm3x3_launch(const ConvDesc& d, const ConvCfg& cfg, hipStream_t stream);
 
 #include <vector>
 // ---- Winograd F(4x4,3x3) (conv_wino4.hip), ALG 7 -------------------------------------------

@@ -47,6 +47,18 @@ bool geometry(const ConvDesc& d, const ConvCfg& c, Geometry* g) {
 
 }  // namespace
 
+int poco_num_cus() {
+  static thread_local int dev_cached = -1, cus = 256;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return cus;
+  if (dev != dev_cached) {
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+    dev_cached = dev;
+  }
+  return cus;
+}
+
 size_t conv_packed_weight_floats(int Cin, int Cout16, int ks) {
   return (size_t)ks * ks * Cin * Cout16;
 }
@@ -85,6 +97,7 @@ size_t conv_lds_bytes(const ConvDesc& d, const ConvCfg& cfg) {
   if (cfg.ALG == 5) return linear_cfg_valid(d, cfg) ? (size_t)cfg.WM * 4 * 64 * sizeof(float4) : 0;
   if (cfg.ALG == 6) return gemm1x1_cfg_valid(d, cfg) ? 16 : 0;      // no LDS; non-zero = "valid" for the callers
   if (cfg.ALG == 9) return gemm1x1t_lds_bytes(d, cfg);
+  if (cfg.ALG == 10) return gemm3x3_cfg_valid(d, cfg) ? 16 : 0;     // no LDS; non-zero = "valid" for the callers
   if (cfg.ALG == 7) return conv_wino4_lds_bytes(d, cfg);
   if (cfg.ALG == 8) return conv_wino4p_lds_bytes(d, cfg);
   if (cfg.ALG == 3 || cfg.ALG == 4) return conv_wino_lds_bytes(d, cfg);
@@ -165,6 +178,7 @@ int conv_launch(const ConvDesc& d, const ConvCfg& cfg, hipStream_t stream) {
   if (cfg.ALG == 5) return linear_launch(d, cfg, stream);
   if (cfg.ALG == 6) return gemm1x1_launch(d, cfg, stream);
   if (cfg.ALG == 9) return gemm1x1t_launch(d, cfg, stream);
+  if (cfg.ALG == 10) return gemm3x3_launch(d, cfg, stream);
   if (cfg.ALG == 7) return conv_wino4_launch(d, cfg, stream);
   if (cfg.ALG == 8) return conv_wino4p_launch(d, cfg, stream);
   if (cfg.ALG == 3 || cfg.ALG == 4) {

@@ -653,12 +653,15 @@ int conv_wino4p_launch(const ConvDesc& d, const ConvCfg& cfg, hipStream_t stream
   p.dTX = make_fastdiv(g.TX); p.dTslab = make_fastdiv(g.tps);
   p.nblocks_m = (g.S + g.NI - 1) / g.NI; p.nb_n = (p.nT16 + cfg.NT - 1) / cfg.NT;
   // balanced persistent grid: every block walks the same number of items (one block per CU)
-  // cfg.MT = CU share divisor: the grid is sized for 256 / MT CUs.  A block needs a whole CU (LDS), all blocks of a launch run
+  // cfg.MT = CU share divisor: the grid is sized for (CUs of the device) / MT.  A block needs a whole CU (LDS), all blocks of a launch run
   // their K loops (MFMA-bound, HBM nearly idle) and their store phases (HBM-write-bound, MFMA idle) in lockstep; two launches
   // of different lanes on half of the CUs each run out of phase and overlap one's stores with the other's MFMAs.
-  static const int mt_env = [] { const char* e = getenv("POCO_W4P_MT"); return e ? atoi(e) : 0; }();
-  const int mt = std::max(1, mt_env > 0 ? mt_env : cfg.MT);
-  const long cus = std::max(8, 256 / mt);
+  int mt = std::max(1, cfg.MT);
+#if W4P_EXP
+  static const int mt_env = [] { const char* e = getenv("POCO_W4P_MT"); return e ? atoi(e) : 0; }();      // probe builds only
+  if (mt_env > 0) mt = mt_env;
+#endif
+  const long cus = std::max(8, poco_num_cus() / mt);
   const long items = (long)p.nblocks_m * p.nb_n;
   const long rounds = (items + cus - 1) / cus;
   long g4 = (items + rounds - 1) / rounds;

@@ -288,10 +288,16 @@ int launch_gemm1x1_dual(const float* a, int a_cs, int Ca, const float* b, int b_
   p.act = act; p.res_after_act = 0; p.relu_from = 0;
   p.dWo = make_fastdiv(Wo); p.dHo = make_fastdiv(Ho);
   const int mtiles = (p.P + 15) / 16;
-  // tile 7x4, depth 2; wave layout and load schedule by the pixel count (measured per ResNet-50 stage, B = 64)
+  // tile 7x4, depth 2, one wave per block, default load schedule: the fastest of the wave layouts / schedules probed per
+  // ResNet-50 stage at B = 64 (tools/dual_probe.sh builds with -DG1_DUAL_EXP to repeat that sweep)
   int WM = 1, WN = 1, NI = 1;
-  static const char* ov = getenv("POCO_G1_DUAL");         // "WM,WN,NI": timing probe
-  if (ov) sscanf(ov, "%d,%d,%d", &WM, &WN, &NI);
+#ifdef G1_DUAL_EXP
+  static const char* ov = getenv("POCO_G1_DUAL");         // "WM,WN,NI": timing probe, probe builds only
+  if (ov) {
+    int a = 1, b = 1, c = 1;
+    if (sscanf(ov, "%d,%d,%d", &a, &b, &c) == 3 && a >= 1 && b >= 1 && a * b <= 8 && (c == 1 || (c >= 3 && c <= 6))) { WM = a; WN = b; NI = c; }
+  }
+#endif
   p.WM = WM; p.WN = WN;
   const dim3 grid((mtiles + 7 * WM - 1) / (7 * WM), (p.nT16 / 4 + WN - 1) / WN);
   const dim3 block(WM * WN * 64);

@@ -278,7 +278,7 @@ void launch_avgpool(const float* in, float* dst, int B, int H, int W, int C, int
 // (~1 us), every thread then produces pixels x = t, t + 256, ... of those rows for the three channels (stores
 // coalesced along x in NCHW; the uint8 frame is read through L2, 12 bytes per output pixel).
 namespace {
-constexpr int CROP_ROWS = 8;
+constexpr int CROP_ROWS = 28;     // 8 blocks per 224-row crop: the ~3 us affine solve is paid once per 28 rows
 
 // cv::hal::LU64f (LUImpl<double>, opencv/modules/core/src/matrix_decomp.cpp) for the 6x6 system of getAffineTransform.
 __device__ __forceinline__ void lu_solve6(double (&A)[6][6], double (&b)[6]) {

@@ -74,6 +74,23 @@ def all_gather_records(rec: torch.Tensor, n_total: int, group=None) -> torch.Ten
     return torch.cat(parts, 0)
 
 
+def check_collective_buffers(send: torch.Tensor, recv: torch.Tensor, world: int, backend: str, device=None) -> None:
+    """What RCCL's all_gather_into_tensor needs, checked before the first collective so that a multi-GPU run can only fail
+    on the transport itself: float32, contiguous, recv = world x send rows, and - for the nccl (RCCL) backend - both
+    buffers in the HBM of THIS rank's own device (a host tensor or another rank's device would fault or hang inside RCCL)."""
+    if send.dtype != torch.float32 or recv.dtype != torch.float32:
+        raise TypeError(f"collective buffers must be float32, got {send.dtype} / {recv.dtype}")
+    if not (send.is_contiguous() and recv.is_contiguous()):
+        raise ValueError("collective buffers must be contiguous")
+    if recv.shape[0] != world * send.shape[0] or recv.shape[1:] != send.shape[1:]:
+        raise ValueError(f"recv {tuple(recv.shape)} is not world ({world}) x send {tuple(send.shape)}")
+    if backend == "nccl":
+        dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        for name, t in (("send", send), ("recv", recv)):
+            if not t.is_cuda or t.device != dev:
+                raise ValueError(f"RCCL {name} buffer lives on {t.device}, this rank's device is {dev}")
+
+
 # ---- video mode: tracks are the unit of sharding (SURVEY.md 8(e), tester.py:368) ------------------------------
 def shard_tracks(tracking_results: dict, rank: int, world: int) -> dict:
     """Greedy longest-first assignment of whole tracks to ranks (a track's frames stay together so that temporal

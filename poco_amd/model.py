@@ -77,7 +77,7 @@ class POCO:
                  num_flow_layers=3, sigma_dim=1, num_nf_rv=9, mask_params_id="", nflow_mask_type="alter",
                  exclude_uncert_idx="", use_dropout=False, use_iter_feats=False, cond_nflow=True, context_dim=512,
                  gt_pose_cond=False, gt_pose_cond_ds="h36m", gt_pose_cond_ratio=0.25, pretrained=None,
-                 inf_model="best", is_test=True, *, max_batch=64, smpl=None, device="cuda:0", keep_state_dict=True):
+                 inf_model="best", is_test=True, *, max_batch=64, smpl=None, device="cuda:0", keep_state_dict=False):
         if img_res != 224:
             raise ValueError("the engine is built for 224x224 crops (configs/demo_poco_*.yaml DATASET.IMG_RES)")
         if uncert_layer != "diff_branch" or activation_type != "sigmoid" or sigma_dim != 1 or num_nf_rv != 9:
@@ -95,7 +95,9 @@ class POCO:
               "poco_create")
         self._finalized = False
         self._loaded = set()
-        self._state = {} if keep_state_dict else None    # host references for state_dict() (the engine packs its own copy)
+        # host copies for state_dict(): off by default (the engine packs its own BN-folded copy on the device; keeping the
+        # originals would pin ~300 MB of host memory for HRNet-W48 for the life of the process)
+        self._state = {} if keep_state_dict else None
         if smpl is not None:
             self.load_smpl(smpl)
         if pretrained is not None:
@@ -130,13 +132,14 @@ class POCO:
     def _load_one(self, name: str, arr) -> None:
         if isinstance(arr, torch.Tensor):
             arr = arr.detach().cpu().numpy()
+        orig_dtype, orig_shape = np.asarray(arr).dtype, np.asarray(arr).shape
         arr = np.ascontiguousarray(arr, dtype=np.float32)
         shp = (C.c_int64 * max(1, arr.ndim))(*arr.shape)
         check(self._L.poco_load_tensor(self._h, name.encode(), C.c_void_p(arr.ctypes.data), shp, arr.ndim),
               f"poco_load_tensor({name})")
         self._loaded.add(name)
         if self._state is not None and not name.startswith("smpl."):
-            self._state[name] = arr
+            self._state[name] = (arr.reshape(orig_shape), orig_dtype)
 
     def load_state_dict(self, state_dict: Dict[str, object], strict: bool = True):
         """Keys as in the reference checkpoint after `model.` stripping: backbone.*, head.*,
@@ -156,16 +159,20 @@ class POCO:
 
     def state_dict(self) -> "Dict[str, torch.Tensor]":
         """The loaded parameters under the reference's state_dict keys (nn.Module.state_dict of pocolib.models.POCO,
-        poco.py:13-42, minus the `smpl.*` buffers), in the engine's declaration order, as CPU tensors.  The engine itself
-        keeps only BN-folded, MFMA-fragment-packed copies on the device; these are the host arrays handed to
-        load_state_dict (held by reference, `keep_state_dict=False` drops them)."""
+        poco.py:13-42), in the engine's declaration order, as CPU tensors.  Needs `keep_state_dict=True` at construction
+        (default False: the engine itself keeps only BN-folded, MFMA-fragment-packed copies on the device).
+        Differences from the reference's state_dict(): the `smpl.*` buffers are not included (the body model is loaded
+        separately, load_smpl); entries the engine tolerates but never reads (num_batches_tracked, backbone.final_layer, ...)
+        appear only if they were loaded; values come back in the dtype they were loaded with (an int64
+        num_batches_tracked stays int64; it crosses the C ABI as float32, exact up to 2^24)."""
         if self._state is None:
-            raise PocoHipError("state_dict(): the model was built with keep_state_dict=False")
+            raise PocoHipError("state_dict(): build the model with keep_state_dict=True")
         from collections import OrderedDict
         out = OrderedDict()
         for name, _, _ in self.expected_tensors():
             if name in self._state:
-                out[name] = torch.from_numpy(self._state[name])
+                arr, dt = self._state[name]
+                out[name] = torch.from_numpy(arr if dt == np.float32 else arr.astype(dt))
         return out
 
     def load_smpl(self, smpl) -> None:
@@ -337,7 +344,7 @@ class POCO:
         return {0: f"conv_mfma_kernel<{ks}, {st}, {MT}, {NT}>", 1: f"conv_dma_kernel<{ks}, {st}, {MT}, {NT}>",
                 2: f"conv_dma_persist_kernel<{ks}, {st}, {MT}, {NT}>", 3: f"conv_wino_kernel<{NT}>",
                 4: f"conv_wino2_kernel<{NT}>", 5: "linear_mfma_kernel", 6: f"gemm1x1_kernel<{MT}, {NT}, {R}", 7: f"conv_wino4_kernel<{NT}>", 8: f"conv_wino4p_kernel<{NT}>",
-                9: f"gemm1x1t_kernel<{MT}, {NT}"}[ALG]
+                9: f"gemm1x1t_kernel<{MT}, {NT}", 10: f"gemm3x3_kernel<{MT}, {NT}, {R}"}[ALG]
 
     def set_conv_cfg(self, op_index: int, B: int, cfg) -> None:
         arr = (C.c_int * 7)(*(tuple(cfg) + (0,) * (7 - len(cfg))))

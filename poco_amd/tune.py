@@ -12,6 +12,7 @@ from __future__ import annotations
 import argparse
 import ctypes as C
 import itertools
+import os
 import json
 import math
 import time
@@ -53,6 +54,17 @@ def candidates(B, H, W, Cin, Cout, ks, stride, lds_cap=150 * 1024) -> List[Tuple
             out.add((MT, NT, WM, WN, D, 1, 6))
             if D == 2 and (MT, NT) in ((4, 4), (7, 2), (7, 4), (8, 2)):   # the same through the LDS transposition (ALG 9)
                 out.add((MT, NT, WM, WN, 1, 1, 9))
+    if ks == 3 and (stride == 2 or os.environ.get("POCO_TUNE_G3_S1")):     # register-direct gather GEMM (ALG 10); R = depth, NI = schedule
+        for (MT, NT), (WM, WN), D, NI in itertools.product(
+                ((2, 4), (4, 2), (4, 3), (4, 4), (7, 2), (7, 3), (7, 4), (8, 2)),
+                ((1, 1), (1, 2), (2, 1), (1, 4), (2, 2), (4, 1), (1, 8), (2, 4), (4, 2), (8, 1)), (2, 3), (1, 3, 6)):
+            if WN > 1 and (WN - 1) * NT >= nT:
+                continue
+            if (nT + NT - 1) // NT * NT - nT >= NT or ((nT + NT - 1) // NT * NT - nT) * 4 > nT:     # > 25 % idle n-tiles
+                continue
+            if {1: 0, 3: 4, 6: 4}[NI] * (MT + NT) > 4 * MT * NT:
+                continue
+            out.add((MT, NT, WM, WN, D, NI, 10))
     for MT, NT, WM, WN in itertools.product((4, 7, 13), (1, 2, 3, 4), (1, 2, 4, 8), (1, 2, 3, 4, 6, 8)):
         if WM * WN > 8 or (MT == 13 and NT > (2 if ks == 3 else 3)) or nT % NT:
             continue
@@ -230,7 +242,8 @@ def apply_table(model, B: int, table=None) -> int:
     return n
 
 
-def tune_in_context(variant: str, B: int, top_shapes: int = 12, top_cands: int = 6, iters: int = 15, verbose=True) -> Dict[str, dict]:
+def tune_in_context(variant: str, B: int, top_shapes: int = 12, top_cands: int = 6, iters: int = 15, verbose=True,
+                    only=None, hysteresis_ms: float = 0.01) -> Dict[str, dict]:
     """Second tuning pass, measured INSIDE the whole forward (4 lanes): the configuration that wins a solo
     micro-benchmark is not always the one that wins next to the other lanes' kernels (7x7 384->384: 68.6 us solo vs
     75.3 us for the runner-up, yet 17.98 vs 17.75 ms per forward).  For the `top_shapes` most expensive shapes the
@@ -277,10 +290,17 @@ def tune_in_context(variant: str, B: int, top_shapes: int = 12, top_cands: int =
     if verbose:
         print(f"{variant} B={B}: {base:.3f} ms/forward before the in-context pass")
     res = {}
-    for k in sorted(cost, key=lambda kk: -cost[kk])[:top_shapes]:
+    ranked = [k for k in sorted(cost, key=lambda kk: -cost[kk]) if only is None or only(m.conv_desc(shapes[k][0])[:6])]
+    for k in ranked[:top_shapes]:
         idxs = shapes[k]
         H, W, Cin, Cout, ks, stride = m.conv_desc(idxs[0])[:6]
-        solo = sorted(r for r in solo_times(L, B, H, W, Cin, Cout, ks, stride) if r[0] > 0)[:top_cands]
+        solo = sorted(r for r in solo_times(L, B, H, W, Cin, Cout, ks, stride) if r[0] > 0)
+        if only is not None:       # a restricted pass (e.g. --g3): the best few of EVERY algorithm, so that a new kernel gets its trial
+            by_alg: Dict[int, list] = {}
+            for r in solo:
+                by_alg.setdefault(r[1][6], []).append(r)
+            solo = sorted(r for lst in by_alg.values() for r in lst[:3])
+        solo = solo[:top_cands]
         cur = tuple(m.conv_cfg(idxs[0], B))
         trial = [cur] + [c for _, c in solo if tuple(c) != cur]
         # ALG 8 on half of the CUs (cfg.MT = 2): always slower alone, but two such launches of different lanes then run out of
@@ -294,7 +314,7 @@ def tune_in_context(variant: str, B: int, top_shapes: int = 12, top_cands: int =
             except PocoHipError:
                 continue
             t = forward_ms()
-            if best_t is None or t < best_t - 0.01:      # 10 us hysteresis against noise
+            if best_t is None or t < best_t - hysteresis_ms:      # hysteresis against noise
                 best_cfg, best_t = tuple(cfg), t
         for i in idxs:
             m.set_conv_cfg(i, B, best_cfg)
@@ -321,12 +341,19 @@ def main():
     ap.add_argument("--ks", type=int, default=0, help="re-tune only the spatial convs of this kernel size (1 or 3)")
     ap.add_argument("--in-context", action="store_true",
                     help="second pass: re-pick the configuration of the most expensive shapes inside the whole forward")
+    ap.add_argument("--g3", action="store_true",
+                    help="in-context pass over the 3x3 stride-2 shapes only (ALG 10, gemm3x3.hip, against the tuned LDS-staged entry)")
     args = ap.parse_args()
     torch.cuda.set_device(0)
     fl = {"hrnet_w32-pare": 3, "hrnet_w48_cls-cliff": 1, "resnet50-cliff": 1}[args.variant]
     m = POCO(backbone=args.variant, num_flow_layers=fl, max_batch=1)   # declarations only: shapes, no weights
     full = json.loads(TABLE.read_text()) if TABLE.exists() else {}
     for B in args.batch:
+        if args.g3:
+            res = tune_in_context(args.variant, B, top_shapes=40, top_cands=8, iters=25, only=lambda d: d[4] == 3 and d[5] == 2,
+                                  hysteresis_ms=0.004)
+            full.update({k: v for k, v in res.items() if v["cfg"][0] > 0})
+            continue
         if args.in_context:
             full.update({k: v for k, v in tune_in_context(args.variant, B).items() if v["cfg"][0] > 0})
             continue

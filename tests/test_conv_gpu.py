@@ -237,6 +237,52 @@ def test_conv1x1_register_gemm_rejects_3x3(cuda):
         ops.conv2d_nhwc(x, w, cfg=(4, 2, 2, 2, 2, 1, 6))
 
 
+GEMM3X3 = [
+    # B, H, W, Cin, Cout, stride, residual
+    (2, 56, 56, 48, 144, 2, False),     # HRNet-W48 merged fuse down-path conv (9 n-tiles)
+    (3, 28, 28, 96, 192, 2, True),
+    (2, 14, 14, 192, 384, 2, False),
+    (1, 14, 14, 512, 1024, 2, False),   # cls head: K = 288 steps
+    (3, 13, 9, 32, 48, 2, True),        # ragged plane, odd sizes: the last row / column taps fall outside
+    (2, 7, 7, 64, 16, 2, False),        # 7 -> 4
+    (1, 1, 1, 16, 16, 2, False),        # one pixel: eight of nine taps are padding
+    (2, 12, 10, 48, 80, 1, True),       # stride 1 through the same kernel
+    (5, 56, 56, 16, 32, 2, True),       # many sub-tiles per image, K = 9 steps
+]
+GEMM3X3_CFG = [(2, 4, 2, 2, 2, 1, 10), (4, 2, 4, 2, 3, 1, 10), (4, 3, 1, 1, 2, 1, 10), (4, 3, 2, 3, 3, 3, 10), (4, 4, 1, 4, 2, 6, 10),
+               (7, 2, 2, 4, 3, 1, 10), (7, 3, 1, 2, 2, 3, 10), (7, 4, 1, 2, 2, 1, 10), (7, 4, 2, 2, 3, 6, 10), (8, 2, 8, 1, 2, 1, 10),
+               (8, 2, 1, 1, 3, 3, 10)]
+
+
+@pytest.mark.parametrize("cfg", GEMM3X3_CFG, ids=lambda c: "-".join(map(str, c)))
+@pytest.mark.parametrize("case", GEMM3X3, ids=lambda c: "x".join(map(str, c)))
+def test_conv3x3_register_gemm(case, cfg, cuda):
+    """ALG 10 (round 3): 3x3 convs (stride 1|2, pad 1) as a register-direct gather GEMM over K = 9*Cin without LDS
+    (csrc/gemm3x3.hip): the stride-2 convs of hrnet.py:196-264 (fuse down paths, transitions), hrnet_cls.py:306-353
+    (cls head) and resnet.py:101-121 (layer2-4.0 conv2), against the fp64 convolution incl. BN scale / shift, residual, ReLU."""
+    from poco_amd import ops
+    B, H, W, Cin, Cout, stride, has_res = case
+    rng = np.random.default_rng(B * 977 + Cin + Cout + H)
+    x = rng.standard_normal((B, H, W, Cin)).astype(np.float32)
+    w = (rng.standard_normal((Cout, Cin, 3, 3)) / np.sqrt(9 * Cin)).astype(np.float32)
+    scale = rng.uniform(0.5, 1.5, Cout).astype(np.float32)
+    shift = rng.uniform(-0.5, 0.5, Cout).astype(np.float32)
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    res = rng.standard_normal((B, Ho, Wo, Cout)).astype(np.float32) if has_res else None
+    ref = _ref(x, w, scale, shift, stride, res, True)
+    out = ops.conv2d_nhwc(torch.from_numpy(x).to(cuda), w, scale, shift, stride,
+                          None if res is None else torch.from_numpy(res).to(cuda), True, cfg=cfg).cpu().numpy()
+    assert out.shape == ref.shape
+    assert np.abs(out - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max())
+
+
+def test_conv3x3_register_gemm_rejects_1x1(cuda):
+    from poco_amd import ops
+    x = torch.zeros(1, 8, 8, 16, device=cuda)
+    with pytest.raises(RuntimeError):
+        ops.conv2d_nhwc(x, np.zeros((16, 16, 1, 1), np.float32), cfg=(4, 2, 2, 2, 2, 1, 10))
+
+
 WINO4 = [
     # B, H, W, Cin, Cout, res
     (2, 56, 56, 48, 48, True),      # HRNet-W48 branch 0 BasicBlock conv

@@ -65,10 +65,13 @@ def test_state_dict_round_trip():
     from tests import util
     variant = "resnet50-cliff"
     w = util.synth_weights(variant)
-    m = POCO(backbone=variant, num_flow_layers=1, max_batch=1)
+    m = POCO(backbone=variant, num_flow_layers=1, max_batch=1, keep_state_dict=True)
+    w["backbone.bn1.num_batches_tracked"] = np.array(7, np.int64)             # tolerated-unused entry keeps its dtype
     m.load_state_dict(w, strict=True)
     sd = m.state_dict()
-    assert set(sd) == set(w) and all(np.array_equal(sd[k].numpy(), w[k]) for k in w)
+    assert set(sd) == set(w) and all(np.array_equal(sd[k].numpy(), w[k]) and sd[k].numpy().dtype == w[k].dtype for k in w)
+    with pytest.raises(_lib.PocoHipError, match="keep_state_dict"):
+        POCO(backbone=variant, num_flow_layers=1, max_batch=1).state_dict()
     m2 = POCO(backbone=variant, num_flow_layers=1, max_batch=1)
     assert m2.load_state_dict(sd, strict=True) == []
     assert list(sd)[:2] == [n for n, _, _ in m.expected_tensors() if n in w][:2]

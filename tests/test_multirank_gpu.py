@@ -43,6 +43,38 @@ def test_bench_gpus2_starts_two_ranks_and_gathers(cuda):
     assert sum(ln.startswith("{") for ln in r.stdout.splitlines()) == 1          # ONE json line (rank 0 only)
 
 
+def test_bench_gpus4_ragged_batch_gathers(cuda):
+    """VERDICT r2 next #7: N > 2 ranks and a batch that is no multiple of anything (7 crops per rank)."""
+    r = _run(["bench.py", "--gpus", "4", "--backend", "gloo", "--steps", "2", "--warmup", "1", "--variant", "resnet50-cliff",
+              "--batch", "7", "--check-gather", "--no-stream", "--no-cpu-baseline", "--no-side"])
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = _json_line(r.stdout)
+    assert line["n_gpus"] == 4 and line["dist"]["world_size"] == 4 and line["config"]["global_batch"] == 28
+    assert line["dist"]["gather_check"].startswith("ok"), line["dist"]
+    assert sum(ln.startswith("{") for ln in r.stdout.splitlines()) == 1
+
+
+def test_rccl_buffers_dry_check(cuda):
+    """The nccl branch of bench.py hands RCCL exactly these buffers: validated here for an 8-rank job without a second GPU
+    (device tensors of this rank's own device, float32, contiguous, recv = world x send), and the check refuses host or
+    mis-shaped buffers - so that the first real `--gpus 8` run can only fail on RCCL itself."""
+    from poco_amd import dist as pdist
+    m = util.make_engine("resnet50-cliff", max_batch=4)
+    out = m(util.cuda_batch(synth.synth_batch(4, 1), cuda))
+    rec = pdist.pack_records(out, head="resnet50-cliff")
+    world = 8
+    gathered = torch.empty(world * 4, pdist.REC, device=cuda)
+    pdist.check_collective_buffers(rec, gathered, world, "nccl", cuda)
+    assert rec.is_cuda and rec.device == gathered.device and rec.shape == (4, pdist.REC)
+    with pytest.raises(ValueError, match="RCCL"):
+        pdist.check_collective_buffers(rec.cpu(), gathered, world, "nccl", cuda)
+    with pytest.raises(ValueError, match="world"):
+        pdist.check_collective_buffers(rec, gathered[:-4], world, "nccl", cuda)
+    with pytest.raises(TypeError):
+        pdist.check_collective_buffers(rec.double(), gathered.double(), world, "nccl", cuda)
+    pdist.check_collective_buffers(rec.cpu(), gathered.cpu(), world, "gloo")
+
+
 def test_bench_rccl_needs_one_gpu_per_rank(cuda):
     if torch.cuda.device_count() >= 2:
         pytest.skip("box has >= 2 GPUs")
