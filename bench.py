@@ -345,6 +345,24 @@ def side_kernels(device):
     return out
 
 
+def small_batch_leg(model, variant, device, sizes=(1, 4, 16), steps=30):
+    """the latency regime.  hipGraph replay of the forward at B = 1 / 4 / 16 on the SAME engine (the tuned
+    table has entries for these batch sizes; a photo folder with one person per image used to run here - the folder mode now
+    batches across images, poco_amd/tester.py:iter_frame_results)."""
+    from poco_amd import synth
+    out = {}
+    for b in sizes:
+        if b > model.max_batch:
+            continue
+        batch = {k: torch.from_numpy(v).to(device) for k, v in synth.synth_batch(b, 77).items()}
+        o = model._alloc_outputs(b, want_segm=False)
+        for _ in range(5):
+            model.graph_forward(batch, o)
+        us = _time_launches(lambda: model.graph_forward(batch, o), iters=steps, warm=3)
+        out[f"B{b}"] = {"ms_per_forward": round(us / 1e3, 4), "crops_per_s": round(b / (us * 1e-6), 1)}
+    return out
+
+
 def spawn_ranks(args) -> int:
     """`python bench.py --gpus N` without a launcher: start N ranks of this same script, one per GPU."""
     import socket
@@ -543,6 +561,7 @@ def main():
             dominant["frac"] = round(dominant["tflops"] / PEAK_F32_MFMA_TFLOPS, 4)
             line["roofline"]["dominant"] = dominant
         if world == 1 and not args.no_side:
+            line["small_batch"] = small_batch_leg(model, args.variant, device)
             line["side_kernels"] = side_kernels(device)
         if world == 1 and not args.no_stream:
             line["streaming_cfg5"] = streaming_leg(args.variant, device)

@@ -50,6 +50,8 @@ struct ConvCfg {
                //    (MT,NT) in {(2,4),(4,2),(4,4),(7,2),(7,4),(8,2)}, R = operand prefetch depth (2|3), NI = load schedule 1..6
                // 9: ALG 6 with coalesced global traffic: pixel / output tiles turned into the MFMA lane order through
                //    wave-private LDS (gemm1x1t.hip): (MT,NT) in {(4,4),(7,2),(7,4),(8,2)}, R = NI = 1
+               // 11: Winograd F(4x4,3x3) as 36 position GEMMs with V / M staged in memory, for planes <= 16x16 (conv_wino4g.hip):
+               //    three launches (input transform, GEMM, output transform); (MT,NT) in {(2,4),(4,2),(4,4),(8,2)}, R = depth 2|3
                // 10: 3x3 conv (stride 1|2) as a register-direct gather GEMM over K = 9*Cin, no LDS / barriers (gemm3x3.hip):
                //    (MT,NT) in {(2,4),(4,2..4),(7,2..4),(8,2)}, R = operand prefetch depth (2|3), NI = load schedule 1|3|6
 };
@@ -72,6 +74,9 @@ struct ConvDesc {
   const float* wfrag_wino;                // 3x3 stride-1 only: Winograd-transformed weights (ALG 3), nullable
   const float* wfrag_wino4 = nullptr;     // 3x3 stride-1 only: F(4x4,3x3) weight fragments, 36 positions (ALG 7), nullable
   const float* wfrag_wino4p = nullptr;    // the same weights in the LDS order of ALG 8 (conv_wino4p.hip), nullable
+  const float* wfrag_wino4g = nullptr;    // 3x3 stride-1 convs on planes <= 8x8: per-position GEMM fragments of ALG 11 (conv_wino4g.hip)
+  float* scratch = nullptr;               // ALG 11: V + M staging (conv_wino4g_scratch_floats), owned by the caller
+  size_t scratch_floats = 0;
   const float* bias;                      // [Cout_padded] folded BN shift / conv bias
   int B, H, W, Cin, Cout;                 // Cout = padded to a multiple of 16
   int ks, stride;                         // ks in {1,3}; pad = (ks-1)/2; stride in {1,2}
@@ -104,6 +109,13 @@ int gemm1x1_launch(const ConvDesc& d, const ConvCfg& cfg, hipStream_t stream);
 bool gemm1x1t_cfg_valid(const ConvDesc& d, const ConvCfg& cfg);
 size_t gemm1x1t_lds_bytes(const ConvDesc& d, const ConvCfg& cfg);
 int gemm1x1t_launch(const ConvDesc& d, const ConvCfg& cfg, hipStream_t stream);
+
+// ---- Winograd F(4x4,3x3) as a position-batched GEMM for small planes (conv_wino4g.hip), ALG 11 --------------
+size_t conv_wino4g_packed_floats(int Cin, int Cout16);
+void conv_wino4g_pack_weights(const float* w_oihw, const float* scale, int Cout, int Cin, int Cout16, float* dst);
+size_t conv_wino4g_scratch_floats(int B, int H, int W, int Cin, int Cout);
+bool conv_wino4g_cfg_valid(const ConvDesc& d, const ConvCfg& cfg);
+int conv_wino4g_launch(const ConvDesc& d, const ConvCfg& cfg, hipStream_t stream);
 
 // ---- 3x3 convs as a register-direct gather GEMM (gemm3x3.hip), ALG 10 -------------------------------------
 bool gemm3x3_cfg_valid(const ConvDesc& d, const ConvCfg& cfg);

@@ -73,6 +73,7 @@ struct Op {
   float* bdev = nullptr;
   float* wdev_wino = nullptr;   // 3x3 stride-1 convs: Winograd-transformed weights (ALG 3)
   float* wdev_wino4p = nullptr; // the same in the LDS order of ALG 8
+  float* wdev_wino4g = nullptr; // planes <= 8x8: per-position GEMM fragments of ALG 11 (conv_wino4g.hip)
   float* wdev_wino4 = nullptr;  // 3x3 stride-1 convs on planes >= 28x28: F(4x4,3x3) fragments (ALG 7)
   float* wdev2 = nullptr;       // OP_CHAIN: the second 1x1 conv (next block's conv1)
   float* bdev2 = nullptr;
@@ -108,6 +109,8 @@ struct Engine {
   Ref smpl_betas, smpl_rot, cam_ref;
   FlowDev flow{};
   bool has_flow = false;
+  float* wino4g_scratch[4] = {};          // ALG 11 (V + M staging): one buffer per lane, sized at finalize for max_batch
+  size_t wino4g_scratch_need = 0;
   float* flow_scratch = nullptr;          // step A of the flow (context GEMM), grown on demand by poco_realnvp
   size_t flow_scratch_floats = 0;
   int uncert_feat_dim = 0;
@@ -122,6 +125,7 @@ struct Engine {
     for (void* p : dev_allocs) (void)hipFree(p);
     if (ws) (void)hipFree(ws);
     if (flow_scratch) (void)hipFree(flow_scratch);
+    for (float* q : wino4g_scratch) if (q) (void)hipFree(q);
   }
 };
 
@@ -280,6 +284,12 @@ struct Builder {
           }
           conv_wino4p_pack_weights(wp, scale.data(), Cout, Cin, Cout16, pu4.data());     // same size, other order
           op.wdev_wino4p = upload(pu4);
+        }
+        if (ain.H <= 8 && ain.W <= 8 && ain.H * ain.W > 1 && actfn <= 1) {      // 7x7 planes: F(4x4,3x3) as 36 position GEMMs (ALG 11)
+          std::vector<float> pg(conv_wino4g_packed_floats(Cin, Cout16));
+          conv_wino4g_pack_weights(wp, scale.data(), Cout, Cin, Cout16, pg.data());
+          op.wdev_wino4g = upload(pg);
+          e.wino4g_scratch_need = std::max(e.wino4g_scratch_need, conv_wino4g_scratch_floats(e.max_batch, ain.H, ain.W, Cin, Cout16));
         }
       }
     }
@@ -1106,6 +1116,7 @@ int run_op(Engine& e, Op& op, int B, const IO& io, hipStream_t s) {
       if (op.res.act >= 0) { d.res = aptr(e, op.res); d.res_cs = e.acts[op.res.act].C; }
       d.out = aptr(e, op.out); d.out_cs = ao.C; d.out_co = 0;
       d.wfrag = op.wdev; d.bias = op.bdev; d.wfrag_wino = op.wdev_wino; d.wfrag_wino4 = op.wdev_wino4; d.wfrag_wino4p = op.wdev_wino4p;
+      d.wfrag_wino4g = op.wdev_wino4g; d.scratch = e.wino4g_scratch[op.lane & 3]; d.scratch_floats = e.wino4g_scratch_need;
       d.B = B; d.H = ai.H; d.W = ai.W; d.Cin = op.Cin; d.Cout = op.Cout; d.ks = op.ks; d.stride = op.stride;
       d.act = op.actfn; d.res_after_act = op.res_after; d.relu_from = op.relu_from;
       auto it = op.cfg.find(B);
@@ -1302,6 +1313,8 @@ extern "C" int poco_finalize(poco_handle_t h) {
   plan_workspace(*e);
   POCO_HIP_CHECK(hipMalloc(&e->ws, e->ws_floats * sizeof(float)));
   POCO_HIP_CHECK(hipMemset(e->ws, 0, e->ws_floats * sizeof(float)));
+  if (e->wino4g_scratch_need)          // ALG 11 staging: one buffer per lane (ops of different lanes run concurrently)
+    for (int k = 0; k < 4; ++k) POCO_HIP_CHECK(hipMalloc(&e->wino4g_scratch[k], e->wino4g_scratch_need * sizeof(float)));
   POCO_HIP_CHECK(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
   for (int k = 1; k < 4; ++k) {
     POCO_HIP_CHECK(hipStreamCreateWithFlags(&e->lane_stream[k], hipStreamNonBlocking));
@@ -1430,7 +1443,8 @@ extern "C" int poco_set_conv_cfg(poco_handle_t h, int op_index, int B, const int
   if (B < 1 || lds == 0 || lds > 160 * 1024 || ((c.ALG == 3 || c.ALG == 4) && (op.wdev_wino == nullptr && e->finalized)) ||
       ((c.ALG == 3 || c.ALG == 4) && (op.actfn == 3 || op.actfn == 2)) ||
       (c.ALG == 7 && ((op.wdev_wino4 == nullptr && e->finalized) || ai.H < 28 || ai.W < 28 || op.actfn >= 2)) ||
-      (c.ALG == 8 && ((op.wdev_wino4p == nullptr && e->finalized) || ai.H < 14 || ai.W < 14 || op.actfn >= 2))) {
+      (c.ALG == 8 && ((op.wdev_wino4p == nullptr && e->finalized) || ai.H < 14 || ai.W < 14 || op.actfn >= 2)) ||
+      (c.ALG == 11 && ((op.wdev_wino4g == nullptr && e->finalized) || ai.H > 8 || ai.W > 8 || ai.H * ai.W <= 1 || op.actfn >= 2 || B > e->max_batch))) {
     poco_set_error("poco_set_conv_cfg: configuration does not fit op '" + op.name + "' at this batch size");
     return POCO_ERR_ARG;
   }

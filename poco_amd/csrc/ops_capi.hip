@@ -44,7 +44,7 @@ static int conv_common(const float* d_in, int B, int H, int W, int Cin, const fl
   std::vector<float> shift(Cout16, 0.f);
   if (h_shift)
     for (int i = 0; i < Cout; ++i) shift[i] = h_shift[i];
-  DevBuf dw, db, dwu, dwu4, dwu4p;
+  DevBuf dw, db, dwu, dwu4, dwu4p, dwu4g, dscr;
   POCO_HIP_CHECK(dw.upload(packed));
   POCO_HIP_CHECK(db.upload(shift));
   ConvDesc d{};
@@ -65,6 +65,15 @@ static int conv_common(const float* d_in, int B, int H, int W, int Cin, const fl
       conv_wino4p_pack_weights(h_w, h_scale, Cout, Cin, Cout16, pu4.data());
       POCO_HIP_CHECK(dwu4p.upload(pu4));
       d.wfrag_wino4p = dwu4p.p;
+    }
+    if (cfg7 && cfg7[6] == 11) {                  // F(4x4,3x3) as 36 position GEMMs: per-position fragments + V / M staging
+      std::vector<float> pg(conv_wino4g_packed_floats(Cin, Cout16));
+      conv_wino4g_pack_weights(h_w, h_scale, Cout, Cin, Cout16, pg.data());
+      POCO_HIP_CHECK(dwu4g.upload(pg));
+      d.wfrag_wino4g = dwu4g.p;
+      d.scratch_floats = conv_wino4g_scratch_floats(B, H, W, Cin, Cout16);
+      POCO_HIP_CHECK(hipMalloc(&dscr.p, d.scratch_floats * sizeof(float)));
+      d.scratch = dscr.p;
     }
   }
   d.in = d_in; d.in_cs = Cin; d.in_co = 0;
@@ -138,7 +147,9 @@ extern "C" int poco_tune_conv(int B, int H, int W, int Cin, int Cout, int ks, in
   const float ws = 1.0f / sqrtf((float)(Cin * ks * ks));
   for (auto& v : hw) v = rnd() * ws;
   for (auto& v : hb) v = rnd() * 0.1f;
-  DevBuf din, dw, db, dout, dwu, dwu4;
+  DevBuf din, dw, db, dout, dwu, dwu4, dwu4g, dscr;
+  bool any11 = false;
+  for (int i = 0; i < ncfg; ++i) any11 = any11 || cfgs6[CONV_CFG_INTS * i + 6] == 11;
   if (ks == 3 && stride == 1) {
     std::vector<float> hu((size_t)16 * Cin * Cout);
     for (auto& v : hu) v = rnd() * ws;
@@ -158,6 +169,15 @@ extern "C" int poco_tune_conv(int B, int H, int W, int Cin, int Cout, int ks, in
   ConvDesc d{};
   d.in = din.p; d.in_cs = Cin; d.out = dout.p; d.out_cs = Cout; d.wfrag = dw.p; d.bias = db.p;
   d.wfrag_wino = dwu.p; d.wfrag_wino4 = dwu4.p; d.wfrag_wino4p = dwu4.p;     // timing only: random fragments serve both orders
+  if (any11 && ks == 3 && stride == 1 && H <= 16 && W <= 16) {
+    std::vector<float> hg(conv_wino4g_packed_floats(Cin, Cout));
+    for (auto& v : hg) v = rnd() * ws;
+    POCO_HIP_CHECK(dwu4g.upload(hg));
+    d.wfrag_wino4g = dwu4g.p;
+    d.scratch_floats = conv_wino4g_scratch_floats(B, H, W, Cin, Cout);
+    POCO_HIP_CHECK(hipMalloc(&dscr.p, d.scratch_floats * sizeof(float)));
+    d.scratch = dscr.p;
+  }
   d.B = B; d.H = H; d.W = W; d.Cin = Cin; d.Cout = Cout; d.ks = ks; d.stride = stride; d.act = 1;
   hipEvent_t e0, e1;
   POCO_HIP_CHECK(hipEventCreate(&e0));

@@ -125,6 +125,12 @@ def candidates(B, H, W, Cin, Cout, ks, stride, lds_cap=150 * 1024) -> List[Tuple
                     lds = (8 * plane + 2 * 16 * NT * 64) * 16
                     if lds <= 160 * 1024 and (plane // 64 + WM - 1) // WM <= 6 and (nT % NT == 0 or nT < NT):
                         out.add((1, NT, WM, 2, R, ni, 4))
+    if ks == 3 and stride == 1 and H <= 8 and W <= 8 and H * W > 1:     # Winograd F(4x4,3x3) as 36 position GEMMs (ALG 11)
+        for (MT, NT), (WM, WN), D in itertools.product(((1, 1), (1, 2), (1, 4), (2, 1), (2, 2), (2, 4), (4, 1), (4, 2), (4, 4), (8, 2)),
+                                                       ((1, 1), (2, 1), (1, 2), (4, 1), (2, 2), (1, 4), (8, 1), (4, 2), (2, 4)), (2, 3)):
+            if WN > 1 and (WN - 1) * NT >= nT:
+                continue
+            out.add((MT, NT, WM, WN, D, 1, 11))
     if ks == 3 and stride == 1 and H >= 14 and W >= 14:      # Winograd F(4x4,3x3): ALG 7 (planes >= 28x28) / ALG 8 (>= 14x14); 2 tile groups x 4 position quarters
         TX4, Hc = (W + 3) // 4, (H + 3) // 4 * 4
         for NT in (1, 2, 3):
@@ -341,6 +347,8 @@ def main():
     ap.add_argument("--ks", type=int, default=0, help="re-tune only the spatial convs of this kernel size (1 or 3)")
     ap.add_argument("--in-context", action="store_true",
                     help="second pass: re-pick the configuration of the most expensive shapes inside the whole forward")
+    ap.add_argument("--small-planes", action="store_true",
+                    help="in-context pass over the 3x3 stride-1 shapes on planes <= 8x8 (ALG 11, conv_wino4g.hip, against the tuned entry)")
     ap.add_argument("--g3", action="store_true",
                     help="in-context pass over the 3x3 stride-2 shapes only (ALG 10, gemm3x3.hip, against the tuned LDS-staged entry)")
     args = ap.parse_args()
@@ -349,6 +357,11 @@ def main():
     m = POCO(backbone=args.variant, num_flow_layers=fl, max_batch=1)   # declarations only: shapes, no weights
     full = json.loads(TABLE.read_text()) if TABLE.exists() else {}
     for B in args.batch:
+        if args.small_planes:
+            res = tune_in_context(args.variant, B, top_shapes=8, top_cands=10, iters=25,
+                                  only=lambda d: d[4] == 3 and d[5] == 1 and d[0] <= 8 and d[1] <= 8, hysteresis_ms=0.004)
+            full.update({k: v for k, v in res.items() if v["cfg"][0] > 0})
+            continue
         if args.g3:
             res = tune_in_context(args.variant, B, top_shapes=40, top_cands=8, iters=25, only=lambda d: d[4] == 3 and d[5] == 2,
                                   hysteresis_ms=0.004)

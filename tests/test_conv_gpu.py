@@ -283,6 +283,46 @@ def test_conv3x3_register_gemm_rejects_1x1(cuda):
         ops.conv2d_nhwc(x, np.zeros((16, 16, 1, 1), np.float32), cfg=(4, 2, 2, 2, 2, 1, 10))
 
 
+WINO4G = [
+    # B, H, W, Cin, Cout, residual, relu
+    (64, 7, 7, 384, 384, True, True),     # HRNet-W48 branch 3 BasicBlock conv2 at the bench batch size
+    (5, 7, 7, 256, 256, False, True),     # W32
+    (3, 8, 8, 32, 48, True, False),       # exact 2 x 2 tiles
+    (7, 5, 3, 16, 32, True, True),        # ragged plane: 2 x 1 tiles, clipped rows and columns
+    (2, 1, 2, 16, 16, False, False),      # one tile per image
+    (9, 4, 4, 48, 16, True, True),        # one tile, T = 9 (padded to 128 tile slots)
+    (33, 6, 7, 80, 112, False, True),     # T = 132 > one 128-tile group, Cin / Cout no multiple of the n-tile groups
+]
+WINO4G_CFG = [(4, 4, 4, 1, 3, 1, 11), (4, 4, 1, 1, 2, 1, 11), (4, 2, 2, 2, 3, 1, 11), (2, 4, 1, 4, 2, 1, 11), (8, 2, 1, 1, 3, 1, 11),
+              (8, 2, 2, 4, 2, 1, 11), (2, 4, 8, 1, 3, 1, 11)]
+
+
+@pytest.mark.parametrize("cfg", WINO4G_CFG, ids=lambda c: "-".join(map(str, c)))
+@pytest.mark.parametrize("case", WINO4G, ids=lambda c: "x".join(map(str, c)))
+def test_conv_winograd_f4x4_as_gemm(case, cfg, cuda):
+    """ALG 11 (round 3): Winograd F(4x4,3x3) on small planes as input transform -> 36 position GEMMs -> output transform
+    (csrc/conv_wino4g.hip; the 7x7 BasicBlock convs of hrnet.py:42-58) against the fp64 convolution."""
+    from poco_amd import ops
+    B, H, W, Cin, Cout, has_res, relu = case
+    rng = np.random.default_rng(B * 131 + Cin + Cout + H)
+    x = rng.standard_normal((B, H, W, Cin)).astype(np.float32)
+    w = (rng.standard_normal((Cout, Cin, 3, 3)) / np.sqrt(9 * Cin)).astype(np.float32)
+    scale = rng.uniform(0.5, 1.5, Cout).astype(np.float32)
+    shift = rng.uniform(-0.5, 0.5, Cout).astype(np.float32)
+    res = rng.standard_normal((B, H, W, Cout)).astype(np.float32) if has_res else None
+    ref = _ref(x, w, scale, shift, 1, res, relu)
+    out = ops.conv2d_nhwc(torch.from_numpy(x).to(cuda), w, scale, shift, 1, None if res is None else torch.from_numpy(res).to(cuda),
+                          relu, cfg=cfg).cpu().numpy()
+    assert out.shape == ref.shape
+    assert np.abs(out - ref).max() <= 2e-4 * max(1.0, np.abs(ref).max()), np.abs(out - ref).max()
+
+
+def test_conv_winograd_f4x4_as_gemm_rejects_large_planes(cuda):
+    from poco_amd import ops
+    with pytest.raises(RuntimeError):
+        ops.conv2d_nhwc(torch.zeros(1, 28, 28, 16, device=cuda), np.zeros((16, 16, 3, 3), np.float32), cfg=(4, 4, 1, 1, 2, 1, 11))
+
+
 WINO4 = [
     # B, H, W, Cin, Cout, res
     (2, 56, 56, 48, 48, True),      # HRNet-W48 branch 0 BasicBlock conv
@@ -364,7 +404,7 @@ def _conv_fp64_gpu(x, w, shift, stride, res, relu):
     return y.clamp_min(0) if relu else y
 
 
-ALG_TOL = {3: 1e-4, 4: 1e-4, 7: 2e-4, 8: 2e-4}     # Winograd F(2x2): transforms amplify fp32 rounding ~5x, F(4x4) ~10x
+ALG_TOL = {3: 1e-4, 4: 1e-4, 7: 2e-4, 8: 2e-4, 11: 2e-4}     # Winograd F(2x2): transforms amplify fp32 rounding ~5x, F(4x4) ~10x
 
 
 @pytest.mark.parametrize("batch", [32, 64, 128])
