@@ -1444,7 +1444,7 @@ extern "C" int poco_set_conv_cfg(poco_handle_t h, int op_index, int B, const int
       ((c.ALG == 3 || c.ALG == 4) && (op.actfn == 3 || op.actfn == 2)) ||
       (c.ALG == 7 && ((op.wdev_wino4 == nullptr && e->finalized) || ai.H < 28 || ai.W < 28 || op.actfn >= 2)) ||
       (c.ALG == 8 && ((op.wdev_wino4p == nullptr && e->finalized) || ai.H < 14 || ai.W < 14 || op.actfn >= 2)) ||
-      (c.ALG == 11 && ((op.wdev_wino4g == nullptr && e->finalized) || ai.H > 8 || ai.W > 8 || ai.H * ai.W <= 1 || op.actfn >= 2 || B > e->max_batch))) {
+      (c.ALG == 11 && ((op.wdev_wino4g == nullptr && e->finalized) || ai.H > 8 || ai.W > 8 || ai.H * ai.W <= 1 || op.actfn >= 2))) {     // (its scratch is sized for max_batch; poco_forward refuses larger batches)
     poco_set_error("poco_set_conv_cfg: configuration does not fit op '" + op.name + "' at this batch size");
     return POCO_ERR_ARG;
   }

@@ -113,6 +113,148 @@ attn_pool_partial_kernel(const float* __restrict__ heat, int heat_cs, const floa
   }
 }
 
+// Stage 1 on the fp32 MFMA (round 3; C a multiple of 64).  The pool IS a GEMM over the pixels:
+//   acc[part j][channel c] = sum_p exp(heat[p][1 + j] - m_j) * feat[p][c]
+// weights (parts x pixels) = A operand, features (pixels x channels) = B operand.  A wave owns every 4th group of 4 pixels of
+// the block's pixel range: per step a lane loads ONE heat value per 16-part tile (lane (m, k): part 16 mt + m of pixel 4 s + k),
+// takes its exp, and ONE float4 of features per 64-channel group (lane (n, k): channels 4 n .. 4 n + 3 of that pixel - K permuted
+// as in the conv kernels: MFMA i of the quad feeds the n-tile of channels {4 n + i}), 8 MFMAs per float4.  The softmax
+// denominators ride along in VALU (a lane sums its own weights; the four pixel lanes and the four waves are merged at the end).
+// The LDS-broadcast FMA loop of the VALU kernel above (6 ds_read_b128 per feature float) ran at 1.0 TB/s of algorithmic bytes.
+__global__ void __launch_bounds__(256)
+attn_pool_partial_mfma_kernel(const float* __restrict__ heat, int heat_cs, const float* __restrict__ feat, int C,
+                              float* __restrict__ scratch, int H, int W, int nsplit) {
+  const int HW = H * W;
+  __shared__ float red[4][32];
+  __shared__ float mloc[32];
+  extern __shared__ float accs[];            // [3 waves][(C/64) * 8 tiles][64 lanes][4]: partial accumulators of waves 1..3
+  const int b = blockIdx.x, s = blockIdx.y, tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int per = ((HW + nsplit - 1) / nsplit + 3) & ~3;        // pixels per split, a multiple of 4
+  const int p0 = s * per, p1 = min(HW, p0 + per);
+  const size_t img_heat = (size_t)b * H * (heat_cs >> 4) * (size_t)(W * 16);
+  const size_t img_feat = (size_t)b * H * (C >> 4) * (size_t)(W * 16);
+  // float offset of (pixel p, 16-channel slice sl) inside an image of a buffer with cs channels
+  auto pix = [&](int p, int sl, int cs) {
+    const int y = p / W, x = p - y * W;
+    return ((size_t)y * (cs >> 4) + sl) * (size_t)(W * 16) + (size_t)x * 16;
+  };
+  // ---- local max per part: thread = (pixel lane, channel 0..31 of the heat map) ----
+  {
+    const int ch = tid & 31, pl = tid >> 5;
+    float mx = -INFINITY;
+    for (int p = p0 + pl; p < p1; p += 8) mx = fmaxf(mx, heat[img_heat + pix(p, ch >> 4, heat_cs) + (ch & 15)]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32));                              // the two pixel lanes of a wave
+    if (lane < 32) red[wave][lane] = mx;
+  }
+  __syncthreads();
+  if (tid < 32) mloc[tid] = fmaxf(fmaxf(red[0][tid], red[1][tid]), fmaxf(red[2][tid], red[3][tid]));   // channel tid = part tid - 1
+  __syncthreads();
+  const int m = lane & 15, k = lane >> 4;
+  // A operand: m-tile 0 = parts 0..15 (heat channels 1..16), m-tile 1 = parts 16..23 (channels 17..24; rows 8..15 are padding)
+  const int hc0 = 1 + m, hc1 = 17 + m;
+  const bool a1ok = m < 8;
+  const float mx0 = mloc[hc0], mx1 = a1ok ? mloc[hc1] : 0.f;
+  const int NG = C >> 6;                                                  // 64-channel groups
+  f32x4 acc[2][2][4];
+#pragma unroll
+  for (int g = 0; g < 2; ++g)
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[g][mt][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float l0 = 0.f, l1 = 0.f;
+  const int n = m;                                                        // B operand: lane (n, k)
+  // 4 steps (16 pixels of this wave) per trip: all 8 heat + 8 feature loads are issued before the first exp / MFMA
+  for (int q0 = p0 + 4 * wave; q0 < p1; q0 += 64) {
+    float h0[4], h1[4];
+    float4 f[4][2];
+    bool ok[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int p = q0 + 16 * u + k;
+      ok[u] = p < p1;
+      const int pc = ok[u] ? p : p1 - 1;
+      h0[u] = heat[img_heat + pix(pc, hc0 >> 4, heat_cs) + (hc0 & 15)];
+      h1[u] = a1ok ? heat[img_heat + pix(pc, 1, heat_cs) + (hc1 & 15)] : 0.f;
+#pragma unroll
+      for (int g = 0; g < 2; ++g)
+        f[u][g] = (g < NG) ? *reinterpret_cast<const float4*>(feat + img_feat + pix(pc, g * 4 + (n >> 2), C) + (n & 3) * 4)
+                           : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float w0 = ok[u] ? __expf(h0[u] - mx0) : 0.f;
+      const float w1 = (ok[u] && a1ok) ? __expf(h1[u] - mx1) : 0.f;
+      l0 += w0; l1 += w1;
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        if (g < NG) {
+          const float fv[4] = {f[u][g].x, f[u][g].y, f[u][g].z, f[u][g].w};
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            acc[g][0][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0, fv[i], acc[g][0][i], 0, 0, 0);
+            acc[g][1][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1, fv[i], acc[g][1][i], 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+  // ---- merge: denominators over the 4 pixel lanes and the 4 waves; accumulators of waves 1..3 through LDS ----
+  l0 += __shfl_xor(l0, 16); l0 += __shfl_xor(l0, 32);
+  l1 += __shfl_xor(l1, 16); l1 += __shfl_xor(l1, 32);
+  __syncthreads();                                                        // red[] is free again
+  if (lane < 16) { red[wave][lane] = l0; red[wave][16 + lane] = l1; }
+  const int ntile = NG * 8;
+  if (wave > 0) {
+    float4* dstw = reinterpret_cast<float4*>(accs) + (size_t)(wave - 1) * ntile * 64 + lane;
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+      if (g < NG) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const f32x4 v = acc[g][mt][i];
+            dstw[((g * 2 + mt) * 4 + i) * 64] = make_float4(v[0], v[1], v[2], v[3]);
+          }
+      }
+  }
+  __syncthreads();
+  float* sc = scratch + ((size_t)b * nsplit + s) * (2 * NPART + (size_t)C * NPART);
+  if (tid < NPART) {
+    sc[tid] = mloc[1 + tid];
+    sc[NPART + tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+  }
+  if (wave == 0) {
+    float* accout = sc + 2 * NPART;
+    const float4* src = reinterpret_cast<const float4*>(accs) + lane;
+    // D[row 4 k + e][column n] of tile (g, mt, i): part 16 mt + 4 k + e, channel 64 g + 4 n + i
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+      if (g < NG) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            f32x4 v = acc[g][mt][i];
+            const int t = (g * 2 + mt) * 4 + i;
+#pragma unroll
+            for (int w = 0; w < 3; ++w) {
+              const float4 o = src[((size_t)w * ntile + t) * 64];
+              v[0] += o.x; v[1] += o.y; v[2] += o.z; v[3] += o.w;
+            }
+            const int ch = 64 * g + 4 * n + i;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const int part = 16 * mt + 4 * k + e;
+              if (part < NPART) accout[ch * NPART + part] = v[e];
+            }
+          }
+      }
+  }
+}
+
 // Stage 2: combine splits.  thread = (b, c, j)
 __global__ void attn_pool_combine_kernel(const float* __restrict__ scratch, float* __restrict__ dst, int dst_stride,
                                          int B, int C, int nsplit) {
@@ -193,8 +335,14 @@ size_t part_attention_scratch_floats(int B, int C) {
 
 void launch_part_attention_pool_ws(const float* heat, int heat_cs, const float* feat, int C, float* dst,
                                    int dst_stride, int B, int H, int W, float* scratch, hipStream_t s) {
-  hipLaunchKernelGGL(attn_pool_partial_kernel, dim3(B, ATTN_NSPLIT), dim3(256), 0, s, heat, heat_cs, feat, C,
-                     scratch, H, W, ATTN_NSPLIT);
+  if (C % 64 == 0 && heat_cs >= 32) {        // the PARE head's pools (C = 128 / 64): fp32-MFMA formulation
+    const size_t lds = (size_t)3 * (C / 64) * 8 * 64 * sizeof(float4);
+    hipLaunchKernelGGL(attn_pool_partial_mfma_kernel, dim3(B, ATTN_NSPLIT), dim3(256), lds, s, heat, heat_cs, feat, C,
+                       scratch, H, W, ATTN_NSPLIT);
+  } else {
+    hipLaunchKernelGGL(attn_pool_partial_kernel, dim3(B, ATTN_NSPLIT), dim3(256), 0, s, heat, heat_cs, feat, C,
+                       scratch, H, W, ATTN_NSPLIT);
+  }
   hipLaunchKernelGGL(attn_pool_combine_kernel, dim3(nblk((long)B * C * NPART, 256)), dim3(256), 0, s, scratch, dst,
                      dst_stride, B, C, ATTN_NSPLIT);
 }

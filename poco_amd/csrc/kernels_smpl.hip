@@ -13,7 +13,8 @@
 
 namespace {
 
-constexpr int CB = 8;    // crops per skinning block (posedirs is re-read once per CB crops)
+constexpr int CB = 8;    // crops per skinning block (posedirs is re-read once per CB crops).  Round 3 re-measured the neighbours at 64
+                         // crops (all three kernels): CB = 4 / 256 threads 80 us, CB = 8 / 256 threads 67 us, CB = 16 / 128 threads 117 us
 constexpr int SKIN_T = 256;  // vertices (threads) per skinning block
 
 // One wave per crop.  The chain is serial over the 24 joints (each needs its parent), but the 12 entries of a
