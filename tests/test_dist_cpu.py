@@ -78,30 +78,32 @@ def test_shard_tracks_partition_and_balance():
         assert parts == [pdist.shard_tracks(tracks, r, world) for r in range(world)]   # deterministic
 
 
-def _track_worker(rank, world, port, q, lengths=(5, 2, 7, 1)):
+def _track_worker(rank, world, port, q, lengths=(5, 2, 7, 1), width=None):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     tracks = {f"p{i}": {"frames": list(range(n))} for i, n in enumerate(lengths)}
     mine = pdist.shard_tracks(tracks, rank, world)
-    rec = lambda k, t: torch.full((t, pdist.REC), float(int(k[1:]) + 1)) + torch.arange(t).view(t, 1)   # noqa: E731
+    width = width or pdist.REC
+    rec = lambda k, t: torch.full((t, width), float(int(k[1:]) + 1)) + torch.arange(t).view(t, 1) + 0.001 * torch.arange(width)   # noqa: E731
     local = {k: rec(k, len(v["frames"])) for k, v in mine.items()}
-    full = pdist.gather_track_records(local)
+    full = pdist.gather_track_records(local, width=width)
     ok = set(full) == set(tracks) and all(torch.equal(full[k], rec(k, len(v["frames"]))) for k, v in tracks.items())
     q.put((rank, ok))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,lengths", [(2, (5, 2, 7, 1)), (3, (4,)), (2, ())])
-def test_track_gather_gloo(world, lengths):
-    """Incl. more ranks than tracks (ranks 1, 2 own nothing: ADVICE r1) and no track at all."""
+@pytest.mark.parametrize("world,lengths,width", [(2, (5, 2, 7, 1), None), (3, (4,), None), (2, (), None), (3, (3, 6, 2, 2, 1), pdist.VIDEO_REC)])
+def test_track_gather_gloo(world, lengths, width):
+    """Incl. more ranks than tracks (ranks 1, 2 own nothing: ADVICE r1), no track at all, and the 352-float video record
+    (final pose | betas | cam | var | confidence | raw 2-D joints) of the round-3 rank-0 merge."""
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_track_worker, args=(r, world, port, q, lengths)) for r in range(world)]
+    procs = [ctx.Process(target=_track_worker, args=(r, world, port, q, lengths, width)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=120) for _ in procs]

@@ -138,3 +138,54 @@ def test_reference_cache_files_load(tmp_path):
     assert list(got) == ["1"] and got["1"]["bbox"].shape == (30, 4) and got["1"]["frames"].dtype == np.int64
     (tmp_path / "t.json").write_text(json.dumps({"7": {"bbox": [[1, 2, 3, 4]] * 3, "frames": [0, 1, 2]}}))
     assert load_tracking(str(tmp_path / "t.json"))["7"]["frames"].tolist() == [0, 1, 2]     # json: explicit input, kept
+
+
+def test_folder_mode_cross_image_batching_host_logic():
+    """POCOTester.iter_frame_results (round 3: consecutive images share forwards) with a stub model on the
+    CPU: rows go back to the frame they came from, frames without detections yield None in place, a frame with more people
+    than the batch is split, forwards are full batches, and at most one batch of crops is pending."""
+    import torch
+    from poco_amd.tester import POCOTester
+
+    class StubModel:
+        max_batch = 4
+
+        def __init__(self):
+            self.calls = []
+
+        def __call__(self, batch, want_segm=False):
+            n = batch["img"].shape[0]
+            self.calls.append(n)
+            tag = batch["img"][:, 0, 0, 0]                        # the crop's tag rides in its first pixel
+            return {"tag": tag.clone(), "log_phi": None, "gt_pose_cond_idx": []}
+
+    t = POCOTester.__new__(POCOTester)
+    t.model = StubModel()
+    t.device = torch.device("cpu")
+    t.make_batch = lambda fr, dets, scale: {"img": torch.tensor(np.asarray(dets)[:, 0], dtype=torch.float32).view(-1, 1, 1, 1).repeat(1, 3, 2, 2)}
+    t.postprocess = lambda out, dets, W, H: {"tag": out["tag"].numpy(), "cx": np.asarray(dets)[:, 0].astype(np.float32), "wh": np.full(len(dets), W * 1000 + H)}
+    people = [1, 0, 3, 9, 0, 2, 1]
+    frames, dets, k = [], [], 0
+    for i, n in enumerate(people):
+        frames.append(np.zeros((10 + i, 20 + i, 3), np.uint8))
+        dets.append(np.array([[100 * i + j, 0, 5, 5] for j in range(n)], np.float64).reshape(-1, 4))
+    res = t.run_on_frames(frames, dets)
+    assert [None if r is None else len(r["tag"]) for r in res] == [1, None, 3, 9, None, 2, 1]
+    for i, r in enumerate(res):
+        if r is not None:
+            assert np.array_equal(r["tag"], np.array([100 * i + j for j in range(people[i])], np.float32))
+            assert np.array_equal(r["tag"], r["cx"]) and (r["wh"] == (20 + i) * 1000 + 10 + i).all()
+    assert t.model.calls == [4, 4, 4, 4]                       # 16 crops: four full forwards instead of five per-image ones
+    # a generator input is consumed lazily: a result comes out as soon as its frame's last crop has been regressed
+    t.model.calls.clear()
+    seen = []
+
+    def gen():
+        for f, d in zip(frames, dets):
+            seen.append(len(seen))
+            yield f, d
+
+    it = t.iter_frame_results(gen())
+    first = next(it)
+    assert first is not None and len(seen) <= 4 and t.model.calls == [4]
+    assert len([first] + list(it)) == len(frames)
