@@ -77,6 +77,9 @@ struct ConvDesc {
   const float* wfrag_wino4g = nullptr;    // 3x3 stride-1 convs on planes <= 8x8: per-position GEMM fragments of ALG 11 (conv_wino4g.hip)
   float* scratch = nullptr;               // ALG 11: V + M staging (conv_wino4g_scratch_floats), owned by the caller
   size_t scratch_floats = 0;
+  // ALG 11 chaining (engine only): the previous conv already left this conv's V in scratch half `wg_vsel`; this conv leaves the
+  // next conv's V in the other half (wg_mid_kernel) and writes its own output tensor only if somebody else still reads it
+  int wg_skip_in = 0, wg_vsel = 0, wg_emit_next = 0, wg_store_y = 1;
   const float* bias;                      // [Cout_padded] folded BN shift / conv bias
   int B, H, W, Cin, Cout;                 // Cout = padded to a multiple of 16
   int ks, stride;                         // ks in {1,3}; pad = (ks-1)/2; stride in {1,2}
@@ -114,6 +117,7 @@ int gemm1x1t_launch(const ConvDesc& d, const ConvCfg& cfg, hipStream_t stream);
 size_t conv_wino4g_packed_floats(int Cin, int Cout16);
 void conv_wino4g_pack_weights(const float* w_oihw, const float* scale, int Cout, int Cin, int Cout16, float* dst);
 size_t conv_wino4g_scratch_floats(int B, int H, int W, int Cin, int Cout);
+bool conv_wino4g_can_chain(int H, int W, int Cout, int next_Cin);
 bool conv_wino4g_cfg_valid(const ConvDesc& d, const ConvCfg& cfg);
 int conv_wino4g_launch(const ConvDesc& d, const ConvCfg& cfg, hipStream_t stream);
 

@@ -24,6 +24,8 @@ __device__ __forceinline__ int opnd_off(int t, int c) { return (t >> 4) * 256 + 
 struct WgParams {
   const float* in;  const float* res;  float* out;
   float* V;  float* M;
+  float* Vnext;          // fused tail (wg_mid_kernel): the NEXT conv's V, produced from this conv's output tile by tile; else nullptr
+  int store_y;           // fused tail: the output tensor itself is still needed (a later residual / another consumer)
   const float4* ufrag;   // [36][Cin/16][Cout/16][64] float4 (conv_pack_weights(ks = 1) per position)
   const float* bias;
   int B, H, W, TY, TX, T, Tp;       // tiles per image = TY*TX, T = B*TY*TX, Tp = T padded to a multiple of 128
@@ -211,6 +213,96 @@ wg_out_kernel(const WgParams p) {
   }
 }
 
+// ---- 3'. output transform of conv k fused with the input transform of conv k+1 (consecutive ALG 11 convs of a branch chain) -----
+// A block = 16 tiles x the 16 channels of one slice; with TY*TX dividing 16 these are whole images, so the 6 x 6 windows of the
+// next conv's tiles (which overlap the neighbouring tiles of the same image) can be read back from an LDS copy of the block's
+// output pixels: y = A^T M A + shift (+ residual) (ReLU) -> LDS (zero border) -> d -> B^T d B -> V of the next conv.
+// One launch and one 7.5 us kernel less per conv, and the intermediate of a BasicBlock (conv1's output) never reaches memory.
+__global__ void __launch_bounds__(256)
+wg_mid_kernel(const WgParams p) {
+  extern __shared__ float ytile[];                       // [16 / tpi images][4 TY + 2][4 TX + 2][16 channels]
+  const int c = threadIdx.x & 15;
+  const int tl = threadIdx.x >> 4;                        // tile inside the block
+  const int t = blockIdx.x * 16 + tl;
+  const int nt = blockIdx.y;
+  const int tpi = p.TY * p.TX;
+  const int PH = 4 * p.TY + 2, PW = 4 * p.TX + 2;
+  for (int i = threadIdx.x; i < (16 / tpi) * PH * PW * 16; i += 256) ytile[i] = 0.f;
+  __syncthreads();
+  const int il = tl / tpi, rem = tl - il * tpi;
+  const int ty = rem / p.TX, tx = rem - ty * p.TX;
+  float* yl = ytile + ((size_t)il * PH * PW) * 16 + c;     // + (py * PW + px) * 16
+  if (t < p.T) {
+    const float* mi = p.M + (size_t)nt * p.Tp * 16 + opnd_off(t, c);
+    const size_t pstride = (size_t)p.nT16 * p.Tp * 16;
+    float m[6][6];
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+#pragma unroll
+      for (int s = 0; s < 6; ++s) m[r][s] = mi[(size_t)(r * 6 + s) * pstride];
+    float z[4][6];
+#pragma unroll
+    for (int s = 0; s < 6; ++s) {
+      const float p12 = m[1][s] + m[2][s], m12 = m[1][s] - m[2][s], p34 = m[3][s] + m[4][s], m34 = m[3][s] - m[4][s];
+      z[0][s] = m[0][s] + p12 + p34;
+      z[1][s] = m12 + 2.f * m34;
+      z[2][s] = p12 + 4.f * p34;
+      z[3][s] = m12 + 8.f * m34 + m[5][s];
+    }
+    const int b = t / tpi;
+    const float sh = p.bias[nt * 16 + c];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float p12 = z[i][1] + z[i][2], m12 = z[i][1] - z[i][2], p34 = z[i][3] + z[i][4], m34 = z[i][3] - z[i][4];
+      const float y[4] = {z[i][0] + p12 + p34, m12 + 2.f * m34, p12 + 4.f * p34, m12 + 8.f * m34 + z[i][5]};
+      const int oy = 4 * ty + i;
+      if (oy >= p.H) continue;
+      const size_t row = (size_t)b * p.H + oy;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int ox = 4 * tx + j;
+        if (ox >= p.W) continue;
+        float v = y[j] + sh;
+        float r = 0.f;
+        if (p.res) r = p.res[row * p.res_rs + (size_t)nt * p.out_ss + ox * 16 + c];
+        if (!p.res_after_act) v += r;
+        if (p.act == 1) v = fmaxf(v, 0.f);
+        if (p.res_after_act) v += r;
+        if (p.store_y) p.out[row * p.out_rs + (size_t)nt * p.out_ss + ox * 16 + c] = v;
+        yl[((oy + 1) * PW + ox + 1) * 16] = v;
+      }
+    }
+  }
+  __syncthreads();
+  float d[6][6];
+#pragma unroll
+  for (int r = 0; r < 6; ++r)
+#pragma unroll
+    for (int s = 0; s < 6; ++s) d[r][s] = (t < p.T) ? yl[((4 * ty + r) * PW + 4 * tx + s) * 16] : 0.f;
+  float u[6][6];
+#pragma unroll
+  for (int s = 0; s < 6; ++s) {
+    u[0][s] = w4::bt_row<0>(d[0][s], d[1][s], d[2][s], d[3][s], d[4][s], d[5][s]);
+    u[1][s] = w4::bt_row<1>(d[0][s], d[1][s], d[2][s], d[3][s], d[4][s], d[5][s]);
+    u[2][s] = w4::bt_row<2>(d[0][s], d[1][s], d[2][s], d[3][s], d[4][s], d[5][s]);
+    u[3][s] = w4::bt_row<3>(d[0][s], d[1][s], d[2][s], d[3][s], d[4][s], d[5][s]);
+    u[4][s] = w4::bt_row<4>(d[0][s], d[1][s], d[2][s], d[3][s], d[4][s], d[5][s]);
+    u[5][s] = w4::bt_row<5>(d[0][s], d[1][s], d[2][s], d[3][s], d[4][s], d[5][s]);
+  }
+  // this conv's n-tile nt is slice nt of the next conv's input (Cout == next Cin)
+  float* vo = p.Vnext + (size_t)nt * p.Tp * 16 + opnd_off(t, c);
+  const size_t vstride = (size_t)p.nT16 * p.Tp * 16;
+#pragma unroll
+  for (int r = 0; r < 6; ++r) {
+    vo[(size_t)(r * 6 + 0) * vstride] = w4::bt_row<0>(u[r][0], u[r][1], u[r][2], u[r][3], u[r][4], u[r][5]);
+    vo[(size_t)(r * 6 + 1) * vstride] = w4::bt_row<1>(u[r][0], u[r][1], u[r][2], u[r][3], u[r][4], u[r][5]);
+    vo[(size_t)(r * 6 + 2) * vstride] = w4::bt_row<2>(u[r][0], u[r][1], u[r][2], u[r][3], u[r][4], u[r][5]);
+    vo[(size_t)(r * 6 + 3) * vstride] = w4::bt_row<3>(u[r][0], u[r][1], u[r][2], u[r][3], u[r][4], u[r][5]);
+    vo[(size_t)(r * 6 + 4) * vstride] = w4::bt_row<4>(u[r][0], u[r][1], u[r][2], u[r][3], u[r][4], u[r][5]);
+    vo[(size_t)(r * 6 + 5) * vstride] = w4::bt_row<5>(u[r][0], u[r][1], u[r][2], u[r][3], u[r][4], u[r][5]);
+  }
+}
+
 inline int tiles_padded(int T) { return (T + 127) / 128 * 128; }
 
 }  // namespace
@@ -231,21 +323,28 @@ void conv_wino4g_pack_weights(const float* w_oihw, const float* scale, int Cout,
 // scratch floats (V + M) for a conv of this shape
 size_t conv_wino4g_scratch_floats(int B, int H, int W, int Cin, int Cout) {
   const int T = B * ((H + 3) / 4) * ((W + 3) / 4);
-  return (size_t)36 * tiles_padded(T) * (Cin + Cout);
+  return (size_t)36 * tiles_padded(T) * (2 * std::max(Cin, Cout) + Cout);      // V (two of them: chained convs ping-pong) + M
 }
 
-// cfg: {MT, NT in (1,2,4) or (8,2): 16-tile x 16-channel sub-tiles per wave, WM, WN, R = prefetch depth D (2|3), NI = 1, ALG = 11}
+// can the output transform of this conv produce the next conv's V directly (wg_mid_kernel)?
+bool conv_wino4g_can_chain(int H, int W, int Cout, int next_Cin) {
+  const int tpi = ((H + 3) / 4) * ((W + 3) / 4);
+  return Cout == next_Cin && 16 % tpi == 0;
+}
+
+// cfg: {MT, NT in (1,2,4) or (8,2): 16-tile x 16-channel sub-tiles per wave, WM, WN, R = prefetch depth D (2|3|4|6; the weights of a conv are cold: read once per forward), NI = 1, ALG = 11}
 bool conv_wino4g_cfg_valid(const ConvDesc& d, const ConvCfg& cfg) {
   const bool tile = ((cfg.MT == 1 || cfg.MT == 2 || cfg.MT == 4) && (cfg.NT == 1 || cfg.NT == 2 || cfg.NT == 4)) || (cfg.MT == 8 && cfg.NT == 2);
   return d.ks == 3 && d.stride == 1 && d.H <= 16 && d.W <= 16 && d.Cin % 16 == 0 && d.Cout % 16 == 0 && tile && cfg.WM >= 1 && cfg.WN >= 1 &&
-         cfg.WM * cfg.WN <= 8 && (cfg.R == 2 || cfg.R == 3) && (d.act == 0 || d.act == 1) &&
+         cfg.WM * cfg.WN <= 8 && (cfg.R == 2 || cfg.R == 3 || cfg.R == 4 || cfg.R == 6) && (d.act == 0 || d.act == 1) &&
+         (cfg.R * (cfg.MT + cfg.NT) + cfg.MT * cfg.NT <= 56) &&
          conv_wino4g_scratch_floats(d.B, d.H, d.W, d.Cin, d.Cout) < (1ull << 31) &&
          (long)d.B * d.H * d.W * std::max(std::max(d.in_cs, d.out_cs), d.res_cs) < (1L << 31);
 }
 
 int conv_wino4g_launch(const ConvDesc& d, const ConvCfg& cfg, hipStream_t stream) {
   if (!conv_wino4g_cfg_valid(d, cfg)) {
-    poco_set_error("conv(winograd 4x4 as GEMM): ALG 11 needs ks = 3, stride 1, planes <= 16x16, (MT,NT) in {(2,4),(4,2),(4,4),(8,2)}, WM*WN <= 8, R (depth) 2|3, activation none|ReLU");
+    poco_set_error("conv(winograd 4x4 as GEMM): ALG 11 needs ks = 3, stride 1, planes <= 16x16, (MT,NT) in {(2,4),(4,2),(4,4),(8,2)}, WM*WN <= 8, R (depth) 2|3|4|6 within the register budget, activation none|ReLU");
     return POCO_ERR_ARG;
   }
   const size_t need = conv_wino4g_scratch_floats(d.B, d.H, d.W, d.Cin, d.Cout);
@@ -264,23 +363,38 @@ int conv_wino4g_launch(const ConvDesc& d, const ConvCfg& cfg, hipStream_t stream
   p.B = d.B; p.H = d.H; p.W = d.W; p.TY = (d.H + 3) / 4; p.TX = (d.W + 3) / 4;
   p.T = d.B * p.TY * p.TX; p.Tp = tiles_padded(p.T);
   p.nC16 = d.Cin / 16; p.nT16 = d.Cout / 16;
-  p.V = d.scratch; p.M = d.scratch + (size_t)36 * p.Tp * d.Cin;
+  const size_t vsz = (size_t)36 * p.Tp * std::max(d.Cin, d.Cout);
+  p.V = d.scratch + (d.wg_vsel ? vsz : 0);
+  p.M = d.scratch + 2 * vsz;
+  p.Vnext = d.wg_emit_next ? d.scratch + (d.wg_vsel ? 0 : vsz) : nullptr;
+  p.store_y = d.wg_store_y;
+  if (d.wg_emit_next && !conv_wino4g_can_chain(d.H, d.W, d.Cout, d.Cout)) {
+    poco_set_error("conv(winograd 4x4 as GEMM): the fused tail needs tiles-per-image dividing 16");
+    return POCO_ERR_ARG;
+  }
   p.ufrag = reinterpret_cast<const float4*>(d.wfrag_wino4g); p.bias = d.bias;
   p.in_rs = d.in_cs * d.W; p.in_ss = d.W * 16; p.res_rs = d.res_cs * d.W; p.out_rs = d.out_cs * d.W; p.out_ss = d.W * 16;
   p.act = d.act; p.res_after_act = d.res_after_act;
   p.WM = cfg.WM; p.WN = cfg.WN;
   p.dTpi = make_fastdiv(p.TY * p.TX); p.dTX = make_fastdiv(p.TX);
-  hipLaunchKernelGGL(wg_in_kernel, dim3(p.Tp / 16, p.nC16), dim3(256), 0, stream, p);
+  if (!d.wg_skip_in) hipLaunchKernelGGL(wg_in_kernel, dim3(p.Tp / 16, p.nC16), dim3(256), 0, stream, p);
   const dim3 grid((p.Tp / 16 + cfg.MT * cfg.WM - 1) / (cfg.MT * cfg.WM), (p.nT16 + cfg.NT * cfg.WN - 1) / (cfg.NT * cfg.WN), 36);
   const dim3 block(cfg.WM * cfg.WN * 64);
 #define WG_CASE(mt, nt)                                                                                                \
   if (cfg.MT == mt && cfg.NT == nt) {                                                                                  \
     if (cfg.R == 2) hipLaunchKernelGGL((wg_gemm_kernel<mt, nt, 2>), grid, block, 0, stream, p);                        \
-    else hipLaunchKernelGGL((wg_gemm_kernel<mt, nt, 3>), grid, block, 0, stream, p);                                   \
+    else if (cfg.R == 3) hipLaunchKernelGGL((wg_gemm_kernel<mt, nt, 3>), grid, block, 0, stream, p);                   \
+    else if (cfg.R == 4) hipLaunchKernelGGL((wg_gemm_kernel<mt, nt, 4>), grid, block, 0, stream, p);                   \
+    else hipLaunchKernelGGL((wg_gemm_kernel<mt, nt, 6>), grid, block, 0, stream, p);                                   \
   }
   WG_CASE(1, 1) WG_CASE(1, 2) WG_CASE(1, 4) WG_CASE(2, 1) WG_CASE(2, 2) WG_CASE(2, 4) WG_CASE(4, 1) WG_CASE(4, 2) WG_CASE(4, 4) WG_CASE(8, 2)
 #undef WG_CASE
-  hipLaunchKernelGGL(wg_out_kernel, dim3((p.T + 15) / 16, p.nT16), dim3(256), 0, stream, p);
+  if (p.Vnext) {
+    const size_t lds = (size_t)(16 / (p.TY * p.TX)) * (4 * p.TY + 2) * (4 * p.TX + 2) * 16 * sizeof(float);
+    hipLaunchKernelGGL(wg_mid_kernel, dim3(p.Tp / 16, p.nT16), dim3(256), lds, stream, p);
+  } else {
+    hipLaunchKernelGGL(wg_out_kernel, dim3((p.T + 15) / 16, p.nT16), dim3(256), 0, stream, p);
+  }
   POCO_HIP_CHECK(hipGetLastError());
   return POCO_OK;
 }

@@ -110,6 +110,10 @@ struct Engine {
   FlowDev flow{};
   bool has_flow = false;
   float* wino4g_scratch[4] = {};          // ALG 11 (V + M staging): one buffer per lane, sized at finalize for max_batch
+  int wg_ready_act[4] = {-1, -1, -1, -1}; // ALG 11 chaining: activation whose V the previous conv of the lane left in scratch ...
+  int wg_ready_vsel[4] = {0, 0, 0, 0};    // ... and in which half
+  std::vector<int> act_uses;              // how many op inputs / residuals / fuse terms read each activation (built at finalize)
+  bool wg_fuse = [] { const char* v = getenv("POCO_NO_WG_FUSE"); return !(v && atoi(v)); }();    // A/B knob
   size_t wino4g_scratch_need = 0;
   float* flow_scratch = nullptr;          // step A of the flow (context GEMM), grown on demand by poco_realnvp
   size_t flow_scratch_floats = 0;
@@ -1121,6 +1125,26 @@ int run_op(Engine& e, Op& op, int B, const IO& io, hipStream_t s) {
       d.act = op.actfn; d.res_after_act = op.res_after; d.relu_from = op.relu_from;
       auto it = op.cfg.find(B);
       if (it == op.cfg.end()) it = op.cfg.emplace(B, conv_default_cfg(d)).first;
+      if (it->second.ALG == 11) {
+        // consecutive ALG 11 convs of a lane (the 7x7 branch chain): the output transform of this one produces the V of the next
+        // one (wg_mid_kernel), and its own output tensor is written only if something else still reads it
+        const int ln = op.lane & 3;
+        if (e.wg_ready_act[ln] == op.in.act && op.in.co == 0) { d.wg_skip_in = 1; d.wg_vsel = e.wg_ready_vsel[ln]; }
+        e.wg_ready_act[ln] = -1;
+        const size_t k = (size_t)(&op - e.ops.data());
+        if (e.wg_fuse && k + 1 < e.ops.size()) {
+          Op& nx = e.ops[k + 1];
+          auto nit = nx.cfg.find(B);
+          if (nx.type == OP_CONV && nx.phase == op.phase && nx.lane == op.lane && nx.in.act == op.out.act && nx.in.co == 0 &&
+              op.out.co == 0 && nit != nx.cfg.end() && nit->second.ALG == 11 && nx.wdev_wino4g && ao.C == op.Cout &&
+              conv_wino4g_can_chain(ai.H, ai.W, op.Cout, nx.Cin)) {
+            d.wg_emit_next = 1;
+            d.wg_store_y = !(op.out.act < (int)e.act_uses.size() && e.act_uses[op.out.act] == 1);
+            e.wg_ready_act[ln] = op.out.act;
+            e.wg_ready_vsel[ln] = d.wg_vsel ^ 1;
+          }
+        }
+      }
       return conv_launch(d, it->second, s);
     }
     case OP_MAXPOOL: {
@@ -1313,6 +1337,12 @@ extern "C" int poco_finalize(poco_handle_t h) {
   plan_workspace(*e);
   POCO_HIP_CHECK(hipMalloc(&e->ws, e->ws_floats * sizeof(float)));
   POCO_HIP_CHECK(hipMemset(e->ws, 0, e->ws_floats * sizeof(float)));
+  e->act_uses.assign(e->acts.size(), 0);
+  for (const Op& op : e->ops) {
+    auto use = [&](const Ref& r) { if (r.act >= 0 && r.act < (int)e->act_uses.size()) ++e->act_uses[r.act]; };
+    use(op.in); use(op.in2); use(op.res);
+    for (int k = 0; k < op.fn && k < 4; ++k) use(op.fsrc[k]);
+  }
   if (e->wino4g_scratch_need)          // ALG 11 staging: one buffer per lane (ops of different lanes run concurrently)
     for (int k = 0; k < 4; ++k) POCO_HIP_CHECK(hipMalloc(&e->wino4g_scratch[k], e->wino4g_scratch_need * sizeof(float)));
   POCO_HIP_CHECK(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
@@ -1332,6 +1362,7 @@ static int enqueue_program(Engine* e, int B, const IO& io, hipStream_t main) {
   hipEvent_t fork_ev = e->ev_fork;
   hipEvent_t* join_ev = e->ev_join;
   const int nops = (int)e->ops.size();
+  for (int l = 0; l < 4; ++l) e->wg_ready_act[l] = -1;
   for (int i = 0; i < nops;) {
     int j = i;
     unsigned lanes = 0;
@@ -1407,6 +1438,7 @@ extern "C" int poco_profile_ops(poco_handle_t h, int B, const poco_inputs_t* in,
   std::vector<double> acc(n, 0.0);
   IO io{in, out};
   for (int it = 0; it < iters + 1; ++it) {
+    for (int l = 0; l < 4; ++l) e->wg_ready_act[l] = -1;
     POCO_HIP_CHECK(hipEventRecord(ev[0], s));
     for (int i = 0; i < n; ++i) {
       int rc = run_op(*e, e->ops[i], B, io, s);

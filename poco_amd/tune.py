@@ -127,8 +127,8 @@ def candidates(B, H, W, Cin, Cout, ks, stride, lds_cap=150 * 1024) -> List[Tuple
                         out.add((1, NT, WM, 2, R, ni, 4))
     if ks == 3 and stride == 1 and H <= 8 and W <= 8 and H * W > 1:     # Winograd F(4x4,3x3) as 36 position GEMMs (ALG 11)
         for (MT, NT), (WM, WN), D in itertools.product(((1, 1), (1, 2), (1, 4), (2, 1), (2, 2), (2, 4), (4, 1), (4, 2), (4, 4), (8, 2)),
-                                                       ((1, 1), (2, 1), (1, 2), (4, 1), (2, 2), (1, 4), (8, 1), (4, 2), (2, 4)), (2, 3)):
-            if WN > 1 and (WN - 1) * NT >= nT:
+                                                       ((1, 1), (2, 1), (1, 2), (4, 1), (2, 2), (1, 4), (8, 1), (4, 2), (2, 4)), (2, 3, 4, 6)):
+            if (WN > 1 and (WN - 1) * NT >= nT) or D * (MT + NT) + MT * NT > 56:
                 continue
             out.add((MT, NT, WM, WN, D, 1, 11))
     if ks == 3 and stride == 1 and H >= 14 and W >= 14:      # Winograd F(4x4,3x3): ALG 7 (planes >= 28x28) / ALG 8 (>= 14x14); 2 tile groups x 4 position quarters

@@ -210,6 +210,48 @@ def test_bench_batch_with_tuned_table(variant, B, profile, cuda):
             assert spread[k] >= 10 * tol, ("vacuous comparison", k, spread[k], tol)
 
 
+@pytest.mark.parametrize("variant,B", [("hrnet_w48_cls-cliff", 9), ("hrnet_w32-pare", 5)])
+def test_wino4g_chained_convs_match_unchained(variant, B, cuda, monkeypatch):
+    """ALG 11 (Winograd F(4x4) as position GEMMs) on the 7x7 branch: consecutive convs of the chain run with the fused tail
+    (wg_mid_kernel: output transform of conv k -> V of conv k+1 through LDS, conv1's output of a BasicBlock never stored) -
+    BITWISE the same model outputs as the unchained three-launch form (POCO_NO_WG_FUSE=1), in eager 4-lane, 1-lane and
+    graph-replay mode, and within the gate of the oracle."""
+    batch_np = synth.synth_batch(B, 21)
+    batch = util.cuda_batch(batch_np, cuda)
+    keys = ("pred_pose", "pred_shape", "pred_cam", "var_pose", "smpl_vertices", "uncert_feat")
+
+    def engine(fuse):
+        monkeypatch.setenv("POCO_NO_WG_FUSE", "0" if fuse else "1")
+        m = util.make_engine(variant, max_batch=B, profile="stress")
+        n = 0
+        for i, _ in enumerate(m.ops()):
+            d = m.conv_desc(i)
+            if d is not None and d[4] == 3 and d[5] == 1 and d[0] <= 8 and d[1] <= 8 and d[0] * d[1] > 1:
+                m.set_conv_cfg(i, B, (2, 4, 2, 2, 3, 1, 11))
+                n += 1
+        assert n >= 24
+        return m
+
+    plain = engine(False)
+    ref = {k: v.clone() for k, v in plain(batch).items() if k in keys}
+    fused = engine(True)
+    for lanes in (4, 1):
+        fused.set_num_lanes(lanes)
+        out = fused(batch)
+        for k in keys:
+            assert torch.equal(out[k], ref[k]), (k, lanes)
+    fused.set_num_lanes(4)
+    o = fused._alloc_outputs(B, False)
+    fused.graph_forward(batch, o)
+    fused.graph_forward(batch, o)
+    torch.cuda.synchronize()
+    for k in ("pred_pose", "pred_shape", "pred_cam", "var_pose", "smpl_vertices"):
+        assert torch.equal(o[k], ref[k]), (k, "graph")
+    orc = util.oracle_forward(variant, batch_np, profile="stress")
+    for k in ("pred_pose", "pred_shape", "pred_cam", "var_pose", "smpl_vertices"):
+        assert np.abs(_np(ref[k]) - orc[k].numpy()).max() < TOL, k
+
+
 def test_graph_replay_matches_eager(cuda):
     """hipGraph replay of the forward (with the forked lanes captured) is bit-identical to eager launches,
     also after the inputs were refilled in place."""
