@@ -257,42 +257,71 @@ class POCOTester:
         """pocolib/core/tester.py:153-245: images are streamed (decode -> regress -> write), every `--skip_frame`-th image of
         the sorted listing (tester.py:171), so host memory does not grow with the folder.  Unlike the reference's one
         forward per image, consecutive images share forwards of up to --batch_size crops (iter_frame_results); what is
-        written per image is the same."""
+        written per image is the same.  The host side is a pipeline: a small thread pool decodes the next images while the
+        GPU regresses (PIL releases the GIL while decoding), another one compresses and writes the per-image .npz files (zlib
+        releases it too); at most 2 x batch_size decoded images / unwritten results are in flight."""
+        from collections import deque
+        from concurrent.futures import ThreadPoolExecutor
         from PIL import Image
         names_all = sorted(x for x in os.listdir(image_folder) if x.lower().endswith(IMG_EXT))
         skip = max(int(getattr(self.args, "skip_frame", 1) or 1), 1)
         os.makedirs(output_path, exist_ok=True)
         picked = [(pos, names_all[pos]) for pos in range(0, len(names_all), skip)]
         counts = []
+        nthreads = max(1, min(8, (os.cpu_count() or 2) // 2))
+        ahead = max(4, 2 * self.model.max_batch)
 
-        def items():
-            for pos, n in picked:
-                img = np.asarray(Image.open(os.path.join(image_folder, n)).convert("RGB"))
-                d = None
-                if isinstance(detections, dict):
-                    d = detections.get(n)
-                elif detections is not None and pos < len(detections):      # reference cache: indexed by image position
-                    d = detections[pos]
-                if d is not None and len(d) > 0:
-                    d = np.asarray(d).reshape(-1, 4)
-                    if d.dtype not in (np.float32, np.float64):
-                        d = d.astype(np.float32)
-                else:                       # no detector in scope: one centred square box over the image
-                    H, W = img.shape[:2]
-                    s = float(min(H, W))
-                    d = np.array([[W / 2.0, H / 2.0, s, s]], dtype=np.float32)
-                counts.append(len(d))
-                yield img, d
+        def decode(n):
+            return np.asarray(Image.open(os.path.join(image_folder, n)).convert("RGB"))
+
+        def dets_of(pos, n, img):
+            d = None
+            if isinstance(detections, dict):
+                d = detections.get(n)
+            elif detections is not None and pos < len(detections):      # reference cache: indexed by image position
+                d = detections[pos]
+            if d is not None and len(d) > 0:
+                d = np.asarray(d).reshape(-1, 4)
+                return d if d.dtype in (np.float32, np.float64) else d.astype(np.float32)
+            H, W = img.shape[:2]                                        # no detector in scope: one centred square box
+            s = float(min(H, W))
+            return np.array([[W / 2.0, H / 2.0, s, s]], dtype=np.float32)
+
+        def write(n, r):
+            np.savez_compressed(os.path.join(output_path, os.path.splitext(n)[0] + "_poco.npz"), **r)
+            if getattr(self.args, "save_obj", False):          # tester.py:300-303
+                self._save_meshes(os.path.join(output_path, "meshes", os.path.splitext(n)[0]), r["verts"],
+                                  [f"{i:06d}" for i in range(len(r["verts"]))])
 
         t0 = time.time()
         n_img = 0
-        for (pos, n), r in zip(picked, self.iter_frame_results(items(), bbox_scale)):
-            n_img += 1
-            if r is not None:
-                np.savez_compressed(os.path.join(output_path, os.path.splitext(n)[0] + "_poco.npz"), **r)
-                if getattr(self.args, "save_obj", False):          # tester.py:300-303
-                    self._save_meshes(os.path.join(output_path, "meshes", os.path.splitext(n)[0]), r["verts"],
-                                      [f"{i:06d}" for i in range(len(r["verts"]))])
+        with ThreadPoolExecutor(nthreads) as dec_pool, ThreadPoolExecutor(nthreads) as wr_pool:
+            def items():
+                q = deque()
+                it = iter(picked)
+                for pos, n in it:
+                    q.append((pos, n, dec_pool.submit(decode, n)))
+                    if len(q) >= ahead:
+                        break
+                while q:
+                    pos, n, fut = q.popleft()
+                    nxt = next(it, None)
+                    if nxt is not None:
+                        q.append((nxt[0], nxt[1], dec_pool.submit(decode, nxt[1])))
+                    img = fut.result()
+                    d = dets_of(pos, n, img)
+                    counts.append(len(d))
+                    yield img, d
+
+            writes = deque()
+            for (pos, n), r in zip(picked, self.iter_frame_results(items(), bbox_scale)):
+                n_img += 1
+                if r is not None:
+                    writes.append(wr_pool.submit(write, n, r))
+                while len(writes) > ahead:
+                    writes.popleft().result()
+            for w in writes:
+                w.result()                                      # re-raises a failed write
         torch.cuda.synchronize()
         dt = time.time() - t0
         n_crops = int(sum(counts))

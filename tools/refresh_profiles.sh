@@ -3,7 +3,7 @@
 # kernel durations, and the default 4 lanes) and the PMC passes (separate passes; never mixed with hip/hsa tracing).
 # Usage (from the repo root on the box): tools/refresh_profiles.sh <tag> [pmc]   -> gpurun_out/<tag>/ ; copy what is to be
 # judged into profiles/ (bench.py's roofline.traffic reads profiles/<tag>_pmc_*_summary.json and checks its kernel-source digest).
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/$TAG
 rm -rf $OUT; mkdir -p $OUT
@@ -14,7 +14,7 @@ python $R/bench.py --variant hrnet_w32-pare --batch 32 --no-stream 2>/dev/null |
 python $R/bench.py --no-graph --no-cpu-baseline --no-stream 2>/dev/null | tail -1 > $OUT/${TAG}_bench_hrnet_w48_cls-cliff_nograph.json
 prof_variant() {   # variant batch short-tag
   V=$1; B=$2; T=$3
-  ARGS="--variant $V --batch $B --no-cpu-baseline --no-stream --no-dominant --no-graph"
+  ARGS="--variant $V --batch $B --no-cpu-baseline --no-stream --no-dominant --no-graph --no-side"
   for L in 1 4; do
     timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ks -o bench -- \
       python $R/bench.py --steps 10 --warmup 3 --lanes $L $ARGS > $OUT/ks_${T}_l$L.log 2>&1
