@@ -184,7 +184,7 @@ def cpu_baseline(variant, B=64, passes=3, inst_threads=32):
 
 def streaming_leg(variant, device, batch=128, people=4, batches=20):
     """BASELINE.json config #5 shape on this GPU (was tools/bench_video.py): synthetic 1080p uint8 frames cross PCIe
-    once each (pinned ring, copy stream), `people` boxes per frame are cropped + normalised on the GPU into the
+    once each (pinned ring filled by 4 staging threads, copy stream), `people` boxes per frame are cropped + normalised on the GPU into the
     resident batch, hipGraph forward at bs=`batch`, 253-float records come back.  Detector / tracker are out of scope
     (boxes are synthetic); friends.mp4 is not in the tree."""
     from poco_amd.stream import CropStream
@@ -198,7 +198,8 @@ def streaming_leg(variant, device, batch=128, people=4, batches=20):
                       for s in rng.uniform(150, 600, people)])
 
     def one(i, buf):
-        return cs.run([(cs.upload(frames[(i * fpb + k) % len(frames)]), boxes) for k in range(fpb)], buf)
+        slots = cs.upload_many([frames[(i * fpb + k) % len(frames)] for k in range(fpb)])      # staging copies on 4 threads
+        return cs.run([(k, boxes) for k in slots], buf)
 
     for i in range(3):
         one(i, i & 1)

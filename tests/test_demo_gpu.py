@@ -255,6 +255,13 @@ def test_crop_stream_matches_batch_path(tmp_path, cuda):
             assert np.abs(rec[row:row + k, 226:229] - out["pred_cam"].cpu().numpy()).max() < 1e-5
             assert np.abs(rec[row:row + k, 229:253] - out["var_pose"].cpu().numpy()).max() < 1e-5
             row += k
+    # upload_many (staging copies on a thread pool) == upload frame by frame, bitwise; a frame without boxes frees its slot;
+    # zero-copy staging through pinned_frame(slot)
+    slots = cs.upload_many(frames + [frames[0]], threads=3)
+    rec2, n2 = cs.run(list(zip(slots[:3], boxes)) + [(slots[3], np.zeros((0, 4), np.float32))], 0)
+    torch.cuda.synchronize()
+    assert n2 == 5 and np.array_equal(rec2.numpy()[:5], rec[:5]) and not any(cs._pending)
+    assert cs.pinned_frame(slots[1]).shape == (180, 240, 3) and np.array_equal(cs.pinned_frame(slots[1]), frames[1])
 
 
 def test_demo_folder_pare_b1_stress(tmp_path, cuda):
