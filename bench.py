@@ -542,7 +542,10 @@ def main():
                        "parallelism": f"dp{world} (crop sharding" + (f", {'RCCL' if args.backend == 'nccl' else 'gloo (smoke path)'} all-gather of 254-float SMPL records)"
                                                                           if world > 1 and not args.no_gather else ")")},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_note,
+                         "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
+                         "frac_kind": "ALGORITHMIC: direct-convolution flop count / time / peak; the Winograd kernels execute ~2.2x fewer "
+                                      "MFMAs, the executed-MFMA view is `mfma_pipe_busy`",
+                         "traffic": traffic, "traffic_source": traffic_note,
                          "note": f"whole forward: algorithmic {flops_per_crop/1e9:.3f} GFLOP/crop x {B} crops / mean "
                                  f"HIP-event forward time {ev_ms:.3f} ms on the launch stream (MFMA conv kernels are >96% "
                                  "of the kernel time, profiles/); `dominant` = the kernel symbol with the most time, "
@@ -555,6 +558,9 @@ def main():
                 "frac_at_2.4GHz": round(_PMC_MFMA_BUSY_PER_SIMD / (ev_ms * 1e-3 * 2.4e9), 4),
                 "busy_cycles_per_simd_per_forward": round(_PMC_MFMA_BUSY_PER_SIMD),
                 "source": "SQ_VALU_MFMA_BUSY_CYCLES of the committed PMC pass (single lane) / 1024 SIMDs / (this run's mean forward time x 2.4 GHz)"}
+        else:
+            line["roofline"]["mfma_pipe_busy"] = None
+            line["roofline"]["mfma_pipe_busy_note"] = "absent: no committed PMC profile taken from the kernel sources in the tree for this workload"
         if gather_check is not None:
             line["dist"]["gather_check"] = ("ok: all gathered rows bitwise equal to the per-rank forwards" if gather_check
                                             else "FAILED")
