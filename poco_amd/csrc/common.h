@@ -50,6 +50,7 @@ struct ConvCfg {
                //    (MT,NT) in {(2,4),(4,2),(4,4),(7,2),(7,4),(8,2)}, R = operand prefetch depth (2|3), NI = load schedule 1..6
                // 9: ALG 6 with coalesced global traffic: pixel / output tiles turned into the MFMA lane order through
                //    wave-private LDS (gemm1x1t.hip): (MT,NT) in {(4,4),(7,2),(7,4),(8,2)}, R = NI = 1
+               // 12: EXPERIMENT, never chosen by the table: 1x1 conv in split fp16 (gemm1x1h.hip), POCO_SPLIT_F16=1 only
                // 11: Winograd F(4x4,3x3) as 36 position GEMMs with V / M staged in memory, for planes <= 16x16 (conv_wino4g.hip):
                //    three launches (input transform, GEMM, output transform); (MT,NT) in {(2,4),(4,2),(4,4),(8,2)}, R = depth 2|3
                // 10: 3x3 conv (stride 1|2) as a register-direct gather GEMM over K = 9*Cin, no LDS / barriers (gemm3x3.hip):
@@ -75,6 +76,7 @@ struct ConvDesc {
   const float* wfrag_wino4 = nullptr;     // 3x3 stride-1 only: F(4x4,3x3) weight fragments, 36 positions (ALG 7), nullable
   const float* wfrag_wino4p = nullptr;    // the same weights in the LDS order of ALG 8 (conv_wino4p.hip), nullable
   const float* wfrag_wino4g = nullptr;    // 3x3 stride-1 convs on planes <= 8x8: per-position GEMM fragments of ALG 11 (conv_wino4g.hip)
+  const float* wfrag_h = nullptr;         // EXPERIMENT (ALG 12, gemm1x1h.hip): hi / lo fp16 halves of the 1x1 weights, nullable
   float* scratch = nullptr;               // ALG 11: V + M staging (conv_wino4g_scratch_floats), owned by the caller
   size_t scratch_floats = 0;
   // ALG 11 chaining (engine only): the previous conv already left this conv's V in scratch half `wg_vsel`; this conv leaves the
@@ -112,6 +114,12 @@ int gemm1x1_launch(const ConvDesc& d, const ConvCfg& cfg, hipStream_t stream);
 bool gemm1x1t_cfg_valid(const ConvDesc& d, const ConvCfg& cfg);
 size_t gemm1x1t_lds_bytes(const ConvDesc& d, const ConvCfg& cfg);
 int gemm1x1t_launch(const ConvDesc& d, const ConvCfg& cfg, hipStream_t stream);
+
+// ---- EXPERIMENT: 1x1 convs in split fp16 (hi + lo, 3 MFMAs of 16x16x32_f16 per product; gemm1x1h.hip), ALG 12 -----------
+size_t gemm1x1h_packed_floats(int Cin, int Cout16);
+void gemm1x1h_pack_weights(const float* w_oi, const float* scale, int Cout, int Cin, int Cout16, float* dst);
+bool gemm1x1h_cfg_valid(const ConvDesc& d, const ConvCfg& cfg);
+int gemm1x1h_launch(const ConvDesc& d, const ConvCfg& cfg, hipStream_t stream);
 
 // ---- Winograd F(4x4,3x3) as a position-batched GEMM for small planes (conv_wino4g.hip), ALG 11 --------------
 size_t conv_wino4g_packed_floats(int Cin, int Cout16);

@@ -74,6 +74,7 @@ struct Op {
   float* wdev_wino = nullptr;   // 3x3 stride-1 convs: Winograd-transformed weights (ALG 3)
   float* wdev_wino4p = nullptr; // the same in the LDS order of ALG 8
   float* wdev_wino4g = nullptr; // planes <= 8x8: per-position GEMM fragments of ALG 11 (conv_wino4g.hip)
+  float* wdev_h = nullptr;      // POCO_SPLIT_F16=1 only: hi / lo fp16 halves of a plain 1x1 conv's weights (ALG 12 experiment)
   float* wdev_wino4 = nullptr;  // 3x3 stride-1 convs on planes >= 28x28: F(4x4,3x3) fragments (ALG 7)
   float* wdev2 = nullptr;       // OP_CHAIN: the second 1x1 conv (next block's conv1)
   float* bdev2 = nullptr;
@@ -114,6 +115,7 @@ struct Engine {
   int wg_ready_vsel[4] = {0, 0, 0, 0};    // ... and in which half
   std::vector<int> act_uses;              // how many op inputs / residuals / fuse terms read each activation (built at finalize)
   bool wg_fuse = [] { const char* v = getenv("POCO_NO_WG_FUSE"); return !(v && atoi(v)); }();    // A/B knob
+  bool split_f16 = [] { const char* v = getenv("POCO_SPLIT_F16"); return v && atoi(v); }();      // EXPERIMENT: 1x1 convs on ALG 12
   size_t wino4g_scratch_need = 0;
   float* flow_scratch = nullptr;          // step A of the flow (context GEMM), grown on demand by poco_realnvp
   size_t flow_scratch_floats = 0;
@@ -275,6 +277,11 @@ struct Builder {
       std::copy(shift.begin(), shift.end(), sh.begin());
       op.wdev = upload(packed);
       op.bdev = upload(sh);
+      if (e.split_f16 && ks == 1 && !is_linear && Cin % 32 == 0 && ain.H * ain.W >= 16 && !kperm) {
+        std::vector<float> ph(gemm1x1h_packed_floats(Cin, Cout16));
+        gemm1x1h_pack_weights(wp, scale.data(), Cout, Cin, Cout16, ph.data());
+        op.wdev_h = upload(ph);
+      }
       if (ks == 3 && stride == 1 && !is_linear) {
         std::vector<float> wt, pu(conv_packed_weight_floats(Cin, Cout16, 4));
         conv_wino_transform_weights(wp, Cout, Cin, &wt);
@@ -1125,6 +1132,14 @@ int run_op(Engine& e, Op& op, int B, const IO& io, hipStream_t s) {
       d.act = op.actfn; d.res_after_act = op.res_after; d.relu_from = op.relu_from;
       auto it = op.cfg.find(B);
       if (it == op.cfg.end()) it = op.cfg.emplace(B, conv_default_cfg(d)).first;
+      if (op.wdev_h && (op.in.co & 31) == 0) {          // split-fp16 experiment: every plain 1x1 conv runs on ALG 12
+        d.wfrag_h = op.wdev_h;
+        const int nT16 = op.Cout / 16;
+        const long Pout = (long)B * ((ai.H - 1) / op.stride + 1) * ((ai.W - 1) / op.stride + 1);
+        const bool tiled = Pout >= 2048 && nT16 >= 4;      // 128 x 128 block tiles (LDS-staged, converted once per block)
+        const ConvCfg hc{Pout >= 16384 ? 4 : 2, nT16 % 4 == 0 ? 4 : 2, 2, nT16 >= 8 ? 2 : 1, tiled ? 8 : 2, 1, 12};
+        return conv_launch(d, hc, s);
+      }
       if (it->second.ALG == 11) {
         // consecutive ALG 11 convs of a lane (the 7x7 branch chain): the output transform of this one produces the V of the next
         // one (wg_mid_kernel), and its own output tensor is written only if something else still reads it

@@ -48,6 +48,13 @@ static int conv_common(const float* d_in, int B, int H, int W, int Cin, const fl
   POCO_HIP_CHECK(dw.upload(packed));
   POCO_HIP_CHECK(db.upload(shift));
   ConvDesc d{};
+  DevBuf dwh;
+  if (ks == 1 && cfg7 && cfg7[6] == 12 && Cin % 32 == 0) {       // split-fp16 experiment: hi / lo halves of the weights
+    std::vector<float> ph(gemm1x1h_packed_floats(Cin, Cout16));
+    gemm1x1h_pack_weights(h_w, h_scale, Cout, Cin, Cout16, ph.data());
+    POCO_HIP_CHECK(dwh.upload(ph));
+    d.wfrag_h = dwh.p;
+  }
   if (ks == 3 && stride == 1) {
     std::vector<float> wt, pu(conv_packed_weight_floats(Cin, Cout16, 4));
     conv_wino_transform_weights(h_w, Cout, Cin, &wt);
@@ -177,6 +184,16 @@ extern "C" int poco_tune_conv(int B, int H, int W, int Cin, int Cout, int ks, in
     d.scratch_floats = conv_wino4g_scratch_floats(B, H, W, Cin, Cout);
     POCO_HIP_CHECK(hipMalloc(&dscr.p, d.scratch_floats * sizeof(float)));
     d.scratch = dscr.p;
+  }
+  DevBuf dwh;
+  bool any12 = false;
+  for (int i = 0; i < ncfg; ++i) any12 = any12 || cfgs6[CONV_CFG_INTS * i + 6] == 12;
+  if (any12 && ks == 1 && Cin % 32 == 0) {               // split-fp16 experiment: timing only, hi / lo halves of random weights
+    std::vector<float> hw2((size_t)Cout * Cin), ph(gemm1x1h_packed_floats(Cin, Cout));
+    for (auto& v : hw2) v = rnd() * ws;
+    gemm1x1h_pack_weights(hw2.data(), nullptr, Cout, Cin, Cout, ph.data());
+    POCO_HIP_CHECK(dwh.upload(ph));
+    d.wfrag_h = dwh.p;
   }
   d.B = B; d.H = H; d.W = W; d.Cin = Cin; d.Cout = Cout; d.ks = ks; d.stride = stride; d.act = 1;
   hipEvent_t e0, e1;

@@ -229,6 +229,33 @@ def test_conv1x1_register_gemm(case, cfg, cuda):
     assert np.abs(out - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max())
 
 
+@pytest.mark.parametrize("cfg", [(4, 4, 2, 2, 2, 1, 12), (4, 2, 1, 4, 2, 1, 12), (2, 4, 4, 1, 2, 1, 12), (2, 2, 1, 1, 2, 1, 12),
+                                 (4, 4, 2, 2, 8, 1, 12)],      # R = 8: the LDS-tiled kernel
+                         ids=lambda c: "-".join(map(str, c)))
+@pytest.mark.parametrize("case", [(2, 56, 56, 64, 256, 1, True), (3, 14, 14, 1024, 512, 1, False), (2, 28, 28, 512, 128, 1, True),
+                                  (1, 13, 9, 32, 16, 1, True), (2, 56, 56, 256, 512, 2, False), (5, 7, 7, 96, 48, 1, False)],
+                         ids=lambda c: "x".join(map(str, c)))
+def test_conv1x1_split_f16_experiment(case, cfg, cuda):
+    """ALG 12 (EXPERIMENT, csrc/gemm1x1h.hip): 1x1 convs with every operand split into fp16 hi + lo, three
+    v_mfma_f32_16x16x32_f16 per product, fp32 accumulation.  22 mantissa bits per operand: within 2e-5 of the fp64 conv like
+    the fp32 kernels (values O(1), K up to 1024, odd K = 3 slices of 32)."""
+    from poco_amd import ops
+    B, H, W, Cin, Cout, stride, has_res = case
+    rng = np.random.default_rng(B * 977 + Cin + Cout)
+    x = (rng.standard_normal((B, H, W, Cin)) * rng.choice([1e-3, 1.0, 30.0], (1, 1, 1, Cin))).astype(np.float32)   # small / O(1) / large channels
+    w = (rng.standard_normal((Cout, Cin, 1, 1)) / np.sqrt(Cin)).astype(np.float32)
+    scale = rng.uniform(0.5, 1.5, Cout).astype(np.float32)
+    shift = rng.uniform(-0.5, 0.5, Cout).astype(np.float32)
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    res = rng.standard_normal((B, Ho, Wo, Cout)).astype(np.float32) if has_res else None
+    ref = _ref(x, w, scale, shift, stride, res, True)
+    out = ops.conv2d_nhwc(torch.from_numpy(x).to(cuda), w, scale, shift, stride,
+                          None if res is None else torch.from_numpy(res).to(cuda), True, cfg=cfg).cpu().numpy()
+    err = np.abs(out - ref).max() / max(1.0, np.abs(ref).max())
+    print("split-f16 relative deviation %.2e" % err)
+    assert err <= 2e-5
+
+
 def test_conv1x1_register_gemm_rejects_3x3(cuda):
     from poco_amd import ops
     x = torch.zeros(1, 8, 8, 16, device=cuda)
