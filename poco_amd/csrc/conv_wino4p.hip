@@ -177,7 +177,16 @@ __device__ __forceinline__ void raw_piece_offsets(const W4PParams& p, int item, 
     const uint32_t slot = (uint32_t)((w + nw * k) * 64 + lane);
     const uint32_t k9 = __umulhi(slot, 477218589u);                  // slot / 9 (exact for slot < 2^16)
     const uint32_t r9 = slot - 9 * k9;
-    const uint32_t pos = 8 * k9 + r9;
+    uint32_t pos = 8 * k9 + r9;
+    // opaque: the patch coordinates of a slot do not depend on the item, and hipcc hoists them (prow - 1, 16 ix, ... as 64-bit
+    // v_mad_u64_u32 addends) out of the item loop - eight registers that lived across the K loop and were spilled to scratch at
+    // NT = 3 and reloaded with a full vmcnt(0) wait at every item start (28 spilled VGPRs, 36 B of scratch;
+    // now 1 and 8 B - threadIdx.x, stored once per kernel).  Recomputing them costs ~20 VALU instructions per item and the launch
+    // is 0.5 % faster.  Builds without ANY scratch exist (also make the 4 g of the epilogue addresses opaque, or take the lane id from
+    // mbcnt inside each role) and are 2-8 % SLOWER per launch (55.0 / 49.3 / 80.4 against 53.7 / 46.1 / 73.7 us on the three W48
+    // shapes): at 166-168 registers every value the allocator cannot park in scratch across the K loop comes out of the operand
+    // prefetch depth of the exchange rounds.
+    asm volatile("" : "+v"(pos));
     if (r9 < 8 && pos < (uint32_t)p.npos) {
       const uint32_t psl = fdiv(pos, p.dSlab);
       const uint32_t prem = pos - psl * (uint32_t)(p.PR * p.PW);
@@ -341,7 +350,8 @@ __device__ __forceinline__ void w4p_consumer(const W4PParams& p, float4* smem, i
         f32x4 zr[6];
         zr[0] = ld(0, 0); zr[1] = ld(0, 1) + ld(1, 0); zr[2] = ld(1, 1);
         zr[3] = ld(2, 0); zr[4] = ld(2, 1) + ld(3, 0); zr[5] = ld(3, 1);
-        const float4 sh = *reinterpret_cast<const float4*>(p.bias + (nt0 + n) * 16 + g * 4);
+        const int g4 = g * 4;
+        const float4 sh = *reinterpret_cast<const float4*>(p.bias + (nt0 + n) * 16 + g4);
         const float lo = p.act == 1 ? 0.f : -INFINITY;        // ReLU as a clamp: no branch in the store loop
         const bool has_res = p.res != nullptr;
         const int ox = oxb + j;
@@ -352,9 +362,9 @@ __device__ __forceinline__ void w4p_consumer(const W4PParams& p, float4* smem, i
 #pragma unroll
         for (int i = 0; i < 4; ++i) {                         // per-row output offsets (clamped: dead pixels compute harmlessly, masked at the store)
           const size_t orow = (size_t)tl.b * p.H + min(oyb + i, p.H - 1);
-          ooff[i] = orow * p.out_rs + (size_t)(nt0 + n) * p.out_ss + g * 4 + xo;
+          ooff[i] = orow * p.out_rs + (size_t)(nt0 + n) * p.out_ss + g4 + xo;
           rr[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (has_res) rr[i] = *reinterpret_cast<const float4*>(p.res + orow * p.res_rs + (size_t)(nt0 + n) * p.out_ss + g * 4 + xo);
+          if (has_res) rr[i] = *reinterpret_cast<const float4*>(p.res + orow * p.res_rs + (size_t)(nt0 + n) * p.out_ss + g4 + xo);
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {

@@ -195,6 +195,8 @@ struct Builder {
   bool region_seq = false;
   // POCO_NO_KCAT=1 (experiments): keep the projection shortcut of layer1.0 a separate conv + residual
   bool kcat = [] { const char* v = getenv("POCO_NO_KCAT"); return !(v && atoi(v)); }();
+  // K-merge of the LAST convs of all down paths into the lowest-resolution branch of an HR module (see hr_module)
+  bool kmerge = [] { const char* v = getenv("POCO_NO_KMERGE"); return !(v && atoi(v)); }();
   // POCO_NO_CHAIN=1 (experiments): conv3 of a layer1 block and conv1 of the next one as two launches
   bool chain = [] { const char* v = getenv("POCO_NO_CHAIN"); return !(v && atoi(v)); }();
   // POCO_NO_DUAL=1 (experiments): stride-2 Bottlenecks keep conv3 and the projection shortcut as two launches
@@ -315,9 +317,9 @@ struct Builder {
   }
 
   // ---- blocks --------------------------------------------------------------------------------
-  int basic_block(const std::string& p, int x, int C) {           // hrnet.py:42-58
+  int basic_block(const std::string& p, int x, int C, Ref into = Ref()) {           // hrnet.py:42-58
     int y = conv_bn(p + ".conv1", p + ".bn1", x, C, C, 3, 1, 1);
-    return conv_bn(p + ".conv2", p + ".bn2", y, C, C, 3, 1, 1, x);
+    return conv_bn(p + ".conv2", p + ".bn2", y, C, C, 3, 1, 1, x, false, 0, into);
   }
   // `cat` >= 0 (stride-1 block with a projection shortcut): x lives in channels [planes, planes + Cin) of the act `cat`.
   // conv2 then writes its output into channels [0, planes) of the same act and
@@ -469,7 +471,7 @@ struct Builder {
   // consumers read in place.  ReLU members must come last (act 3 = ReLU for channels >= relu_from).
   struct SubConv { std::string convp, bnp; int Cout; int relu; };
   int conv_multi(const std::string& name, const std::vector<SubConv>& subs, Ref in, int Cin, int ks, int stride,
-                 std::vector<int>* offsets) {
+                 std::vector<int>* offsets, Ref into = Ref()) {
     const Act ain = e.acts[in.act];
     const int pad = (ks - 1) / 2;
     const int Ho = (ain.H + 2 * pad - ks) / stride + 1, Wo = (ain.W + 2 * pad - ks) / stride + 1;
@@ -479,7 +481,7 @@ struct Builder {
       if (sc.Cout % 16) { ok = false; e.err += "conv_multi: member widths must be multiples of 16; "; }
       if (sc.relu && relu_from < 0) relu_from = Ctot;
       if (!sc.relu && relu_from >= 0) { ok = false; e.err += "conv_multi: ReLU members must come last; "; }
-      offsets->push_back(Ctot);
+      offsets->push_back(Ctot + (into.act >= 0 ? into.co : 0));
       Ctot += sc.Cout;
     }
     const size_t per = (size_t)Cin * ks * ks;
@@ -500,8 +502,8 @@ struct Builder {
     op.actfn = relu_from < 0 ? 0 : (relu_from == 0 ? 1 : 3);
     op.relu_from = std::max(relu_from, 0);
     op.flops = 2.0 * Ho * Wo * (double)Ctot * Cin * ks * ks;
-    const int out_act = new_act(Ctot, Ho, Wo);
-    op.out = R(out_act);
+    const int out_act = into.act >= 0 ? into.act : new_act(Ctot, Ho, Wo);
+    op.out = into.act >= 0 ? into : R(out_act);
     if (have) {
       std::vector<float> packed(conv_packed_weight_floats(Cin, Ctot, ks));
       conv_pack_weights(wcat.data(), scat.data(), Ctot, Cin, ks, Ctot, packed.data());
@@ -518,16 +520,40 @@ struct Builder {
   // branch chains form ONE parallel region (lane i = sum_i, then the 8 convs of branch i): one join less per
   // module, and a lane's sum overlaps the other lanes' first convs.
   bool region_open = false;
+  // K-merge (round 3; `kmerge`, POCO_NO_KMERGE=1 restores the separate form): the sum of the lowest-resolution branch T = nb-1,
+  //     y_T = relu(x_T + sum_{j<T} bn_j(conv_j(t_j)))        (t_j = running tensor of down path j -> T before its last conv),
+  // is ONE stride-2 3x3 conv over the channel concatenation [t_{T-2} | ... | t_0 | x_{T-1}] with the BN-folded weights
+  // concatenated along K, the summed shifts as bias, x_T as the residual and the ReLU in the epilogue: T launches and the
+  // branch's fuse_sum launch become one, the Cout x 7x7 (14x14) partial results are never written, and the GEMM is T times
+  // deeper (K = 336 instead of 192 / 96 / 48 for W48 stage 4).  The concat costs nothing: the producers write into channel
+  // slices of one buffer `kc` = [A | t_{T-2} | ... | t_0 | x_{T-1}], where [A | t_{T-2}] is the output of the merged first convs
+  // that read x_{T-2} (A = last conv of path T-2 -> T-1) and x_{T-1} is written there by conv2 of the branch's last block.
   std::vector<int> hr_module(const std::string& p, std::vector<int> xs, const std::vector<int>& ch, Ref out0 = Ref(),
                              bool keep_open = false) {
     const int nb = (int)xs.size();
+    const int T = nb - 1;
+    const bool km = kmerge && nb >= 2;
+    int kc = -1;
+    std::vector<int> kc_off(nb, 0);
+    if (km && nb >= 3) {
+      int off = ch[T - 1];
+      for (int j = T - 2; j >= 0; --j) { kc_off[j] = off; off += ch[j]; }
+      kc_off[T - 1] = off; off += ch[T - 1];
+      kc = new_act(off, e.acts[xs[T - 1]].H, e.acts[xs[T - 1]].W);
+    }
     // phase 1: the branches are independent chains of 8 convs -> one lane (HIP stream) each
     if (!region_open) begin_parallel(1);
     region_open = false;
     static const std::string lmap = [] { const char* v = getenv("POCO_BRANCH_LANES"); return std::string(v ? v : "0123"); }();
+    std::vector<Ref> xr(nb);                 // branch outputs as views (branch T-1 lives inside kc)
     for (int i = 0; i < nb; ++i) {
       lane(i < (int)lmap.size() ? lmap[i] - '0' : i);
-      for (int k = 0; k < 4; ++k) xs[i] = basic_block(p + ".branches." + std::to_string(i) + "." + std::to_string(k), xs[i], ch[i]);
+      for (int k = 0; k < 4; ++k) {
+        const bool to_kc = kc >= 0 && i == T - 1 && k == 3;
+        xs[i] = basic_block(p + ".branches." + std::to_string(i) + "." + std::to_string(k), xs[i], ch[i],
+                            to_kc ? R(kc, kc_off[i]) : Ref());
+      }
+      xr[i] = (kc >= 0 && i == T - 1) ? R(kc, kc_off[i]) : R(xs[i]);
     }
     end_parallel();
     // phase 2: cross-resolution terms.  All first convs that read the same branch output xs[j] run as ONE
@@ -545,19 +571,26 @@ struct Builder {
         for (int i = 0; i < j; ++i) subs.push_back({fl(i, j) + ".0", fl(i, j) + ".1", ch[i], 0});
         std::vector<int> off;
         lane(rr++);
-        const int t = conv_multi(p + ".fuse_up." + std::to_string(j), subs, R(xs[j]), ch[j], 1, 1, &off);
+        const int t = conv_multi(p + ".fuse_up." + std::to_string(j), subs, xr[j], ch[j], 1, 1, &off);
         for (int i = 0; i < j; ++i) terms[i][j] = {R(t, off[i]), j - i};
       }
       if (j + 1 < nb) {                  // down paths: first 3x3 stride-2 conv of every chain (hrnet.py:208-236)
         std::vector<SubConv> subs;
+        std::vector<int> who;
         for (int i = j + 1; i < nb; ++i) {
           const bool last = (i == j + 1);
+          if (km && last && i == T) continue;        // the only conv of path T-1 -> T: part of the K-merged conv
           subs.push_back({fl(i, j) + ".0.0", fl(i, j) + ".0.1", last ? ch[i] : ch[j], last ? 0 : 1});
+          who.push_back(i);
         }
-        std::vector<int> off;
-        lane(rr++);
-        const int t = conv_multi(p + ".fuse_down." + std::to_string(j), subs, R(xs[j]), ch[j], 3, 2, &off);
-        for (int i = j + 1; i < nb; ++i) chain[i][j] = R(t, off[i - j - 1]);
+        if (!subs.empty()) {
+          std::vector<int> off;
+          lane(rr++);
+          // the convs reading x_{T-2} produce exactly [A | t_{T-2}]: straight into the head of kc
+          const Ref into = (kc >= 0 && j == T - 2) ? R(kc, 0) : Ref();
+          const int t = conv_multi(p + ".fuse_down." + std::to_string(j), subs, xr[j], ch[j], 3, 2, &off, into);
+          for (size_t m = 0; m < who.size(); ++m) chain[who[m]][j] = R(t, off[m]);
+        }
       }
     }
     end_parallel();
@@ -566,13 +599,17 @@ struct Builder {
     rr = 0;
     for (int i = 0; i < nb; ++i)
       for (int j = 0; j < i; ++j) {
-        if (i - j > 1) lane(rr++);
+        const bool merged = km && i == T;           // the last conv of this chain runs inside the K-merged conv
+        const int nconv = i - j - 1 - (merged ? 1 : 0);   // convs of the chain that run here
+        if (nconv > 0) lane(rr++);
         Ref t = chain[i][j];
-        for (int k = 1; k < i - j; ++k) {
+        for (int k = 1; k < i - j - (merged ? 1 : 0); ++k) {
           const bool lastk = (k == i - j - 1);
+          const bool to_kc = merged && kc >= 0 && k == i - j - 2;
           const std::string qq = fl(i, j) + "." + std::to_string(k);
-          const int y = conv(qq + ".0", qq + ".0", qq + ".1", t, ch[j], lastk ? ch[i] : ch[j], 3, 2, lastk ? 0 : 1, false);
-          t = R(y);
+          const int y = conv(qq + ".0", qq + ".0", qq + ".1", t, ch[j], lastk ? ch[i] : ch[j], 3, 2, lastk ? 0 : 1, false,
+                             Ref(), 0, to_kc ? R(kc, kc_off[j]) : Ref());
+          t = to_kc ? R(kc, kc_off[j]) : R(y);
         }
         terms[i][j] = {t, 0};
       }
@@ -583,13 +620,52 @@ struct Builder {
     for (int i = 0; i < nb; ++i) {
       lane(i);
       const Act a = e.acts[xs[i]];
-      terms[i][i] = {R(xs[i]), 0};
+      if (km && i == T) { outs[i] = kmerge_conv(p, fl, ch, T, kc >= 0 ? R(kc, ch[T - 1]) : xr[0], R(xs[T])); continue; }
+      terms[i][i] = {xr[i], 0};
       if (i == 0 && out0.act >= 0) { outs[i] = out0.act; fuse_sum(p + ".fuse" + std::to_string(i), terms[i], ch[i], out0, 1); }
-      else { outs[i] = new_act(a.C, a.H, a.W); fuse_sum(p + ".fuse" + std::to_string(i), terms[i], ch[i], R(outs[i]), 1); }
+      else { outs[i] = new_act(ch[i], a.H, a.W); fuse_sum(p + ".fuse" + std::to_string(i), terms[i], ch[i], R(outs[i]), 1); }
     }
     if (keep_open && !((seq_mask >> 7) & 1)) region_open = true;
     else end_parallel();
     return outs;
+  }
+
+  // relu(x_T + sum_j bn_j(conv_j(t_j))) as one conv over the concatenated inputs (see hr_module); K order = kc order:
+  // sources T-2, T-3, ..., 0, then T-1
+  template <class FL>
+  int kmerge_conv(const std::string& p, FL fl, const std::vector<int>& ch, int T, Ref in, Ref res) {
+    std::vector<int> order;
+    for (int j = T - 2; j >= 0; --j) order.push_back(j);
+    order.push_back(T - 1);
+    int K = 0;
+    for (int j : order) K += ch[j];
+    const int Cout = ch[T];
+    HostParam wm, bm;
+    wm.shape = {Cout, K, 3, 3};
+    bm.shape = {Cout};
+    bool have = !declare;
+    std::vector<double> bsum(Cout, 0.0);
+    if (have) wm.data.assign((size_t)Cout * K * 9, 0.f);
+    int koff = 0;
+    for (int j : order) {
+      const std::string q = fl(T, j) + "." + std::to_string(T - j - 1);
+      const HostParam* w = P(q + ".0.weight", {Cout, ch[j], 3, 3});
+      std::vector<float> scale, shift;
+      bn_fold(q + ".1", nullptr, Cout, scale, shift);
+      if (declare || !w) have = false;
+      if (have) {
+        for (int o = 0; o < Cout; ++o) {
+          for (int c = 0; c < ch[j]; ++c)
+            for (int t = 0; t < 9; ++t)
+              wm.data[((size_t)o * K + koff + c) * 9 + t] = (float)((double)scale[o] * w->data[((size_t)o * ch[j] + c) * 9 + t]);
+          bsum[o] += (double)shift[o];
+        }
+      }
+      koff += ch[j];
+    }
+    if (have) { bm.data.resize(Cout); for (int o = 0; o < Cout; ++o) bm.data[o] = (float)bsum[o]; }
+    return conv(p + ".fuse" + std::to_string(T) + "+down", "", "", in, K, Cout, 3, 2, 1, true, res, 0, Ref(), nullptr, 0, false, true,
+                have ? &wm : nullptr, have ? &bm : nullptr);
   }
 
   // stem + layer1 + transitions + stages 2-4 (hrnet.py:466-497 / hrnet_cls.py:438-469)
