@@ -252,6 +252,49 @@ def test_wino4g_chained_convs_match_unchained(variant, B, cuda, monkeypatch):
         assert np.abs(_np(ref[k]) - orc[k].numpy()).max() < TOL, k
 
 
+@pytest.mark.parametrize("variant,B", [("hrnet_w48_cls-cliff", 5), ("hrnet_w32-pare", 3)])
+def test_kmerged_fuse_convs_match_separate_form(variant, B, cuda, monkeypatch):
+    """K-merge (engine.hip hr_module): relu(x_T + sum_j bn_j(conv_j(t_j))) of the lowest-resolution branch of every HR module
+    (hrnet.py:208-236, 248-266) runs as ONE stride-2 conv over the channel concat with residual + ReLU in the epilogue.  Against
+    the separate form (POCO_NO_KMERGE=1: T convs + fuse_sum): 8 fuse_sum launches and 12 (W48) conv launches fewer, the same
+    parameters consumed, outputs equal up to the summation order (fp32 rounding, far inside the gate) on the STRESS weights,
+    and both inside the gate of the oracle."""
+    batch_np = synth.synth_batch(B, 33)
+    batch = util.cuda_batch(batch_np, cuda)
+    keys = ("pred_pose", "pred_shape", "pred_cam", "var_pose", "smpl_vertices")
+
+    def engine(merge):
+        monkeypatch.setenv("POCO_NO_KMERGE", "0" if merge else "1")
+        return util.make_engine(variant, max_batch=B, profile="stress")
+
+    sep = engine(False)
+    mrg = engine(True)
+    names_sep = [o[0] for o in sep.ops()]
+    names_mrg = [o[0] for o in mrg.ops()]
+    n_mod = 8                                                     # 1 + 4 + 3 modules
+    assert sum(n.endswith("+down") for n in names_mrg) == n_mod and not any(n.endswith("+down") for n in names_sep)
+    assert len(names_sep) - len(names_mrg) >= n_mod               # at least the fuse_sum of branch T per module
+    ref = {k: v.clone() for k, v in sep(batch).items() if k in keys}
+    out = {k: v.clone() for k, v in mrg(batch).items() if k in keys}
+    orc = util.oracle_forward(variant, batch_np, profile="stress")
+    for k in keys:
+        d = float((out[k] - ref[k]).abs().max())
+        assert d < 0.1 * TOL, (k, d)
+        assert np.abs(_np(out[k]) - orc[k].numpy()).max() < TOL, k
+        assert np.abs(_np(ref[k]) - orc[k].numpy()).max() < TOL, k
+    # graph replay and single lane: bitwise the eager 4-lane result
+    o = mrg._alloc_outputs(B, False)
+    mrg.graph_forward(batch, o)
+    mrg.graph_forward(batch, o)
+    torch.cuda.synchronize()
+    for k in keys:
+        assert torch.equal(o[k], out[k]), (k, "graph")
+    mrg.set_num_lanes(1)
+    out1 = mrg(batch)
+    for k in keys:
+        assert torch.equal(out1[k], out[k]), (k, "1 lane")
+
+
 def test_split_f16_experiment_passes_the_gate(cuda, monkeypatch):
     """VERDICT r2 next #9 (EXPERIMENT, bench.py --split-f16, never the default): ResNet-50-CLIFF with every plain 1x1 conv on the
     split-fp16 GEMM (fp16 hi + lo, 3 MFMAs per product) must pass the STRESS fixtures at the same 1e-3 gate - golden B = 2 made by
