@@ -14,6 +14,7 @@
 #include "kernels.h"
 
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstring>
 #include <map>
@@ -64,6 +65,8 @@ struct Ref {            // a (possibly strided) view: activation + channel offse
 struct Op {
   int type = 0;
   int phase = 0, lane = 0;
+  unsigned wait_mask = 0;   // lanes of its phase this op waits for (everything enqueued on them so far): cross-lane dependencies
+  int dep_ev = -1;          // first of the events that carry them (one per set bit)
   std::string name;
   double flops = 0;     // per crop
   Ref in, in2, res, out, out2;
@@ -104,6 +107,7 @@ struct Engine {
   int num_lanes = 4;      // 1 = run everything on the caller's stream
   hipStream_t lane_stream[4] = {};   // side lanes 1..3 (lane 0 is the caller's stream)
   hipEvent_t ev_fork = nullptr, ev_join[4] = {};
+  std::vector<hipEvent_t> ev_dep;   // one per op with a cross-lane dependency (Op::wait_lane)
   // SMPL / flow device models
   SmplDev smpl{};
   int a_A = -1, a_j24 = -1, a_verts = -1, a_j49 = -1, a_attn_scratch = -1, a_camt = -1, a_fullt = -1, a_j2d = -1;
@@ -128,6 +132,7 @@ struct Engine {
       if (ev_join[k]) (void)hipEventDestroy(ev_join[k]);
     }
     if (ev_fork) (void)hipEventDestroy(ev_fork);
+    for (hipEvent_t ev : ev_dep) (void)hipEventDestroy(ev);
     for (void* p : dev_allocs) (void)hipFree(p);
     if (ws) (void)hipFree(ws);
     if (flow_scratch) (void)hipFree(flow_scratch);
@@ -201,13 +206,53 @@ struct Builder {
   bool chain = [] { const char* v = getenv("POCO_NO_CHAIN"); return !(v && atoi(v)); }();
   // POCO_NO_DUAL=1 (experiments): stride-2 Bottlenecks keep conv3 and the projection shortcut as two launches
   bool dual = [] { const char* v = getenv("POCO_NO_DUAL"); return !(v && atoi(v)); }();
-  void begin_parallel(int kind = 0) { ++cur_phase; cur_lane = 0; in_parallel = true; region_seq = (seq_mask >> kind) & 1; }
+  // Stage boundaries inside ONE parallel region (round 3; POCO_NO_XDEP=1 restores the joins): the fuse sums of a stage's last module,
+  // the transition conv that creates the next stage's new branch and the next stage's first branch chains run as lanes of the
+  // same region; the transition conv is the only op that needs another lane's result (the K-merged conv of lane T) and waits for
+  // it through an event (Op::wait_lane) instead of a join of all lanes.
+  bool xdep = [] { const char* v = getenv("POCO_NO_XDEP"); return !(v && atoi(v)); }();
+  // Cross-lane dependencies are INFERRED, not declared: inside a region the builder remembers which lanes wrote (a slice of) every
+  // activation and up to which op a lane has already synchronised with every other lane; an op that reads an activation written
+  // on another lane after that point gets that lane in its wait mask.  (Activations are written once per region - concat
+  // buffers by slices - and the planner recycles memory only across regions, so read-after-write is the only hazard.)
+  std::vector<std::array<int, 4>> act_w;      // [act][lane]: index of the last op of this region that wrote it on that lane (-1)
+  int lane_last[4] = {-1, -1, -1, -1};        // last op pushed on each lane in this region
+  int lane_seen[4][4];                        // [a][b]: lane a has waited for lane b up to this op index
+  void region_reset() {
+    act_w.clear();
+    for (int a = 0; a < 4; ++a) { lane_last[a] = -1; for (int b2 = 0; b2 < 4; ++b2) lane_seen[a][b2] = -1; }
+  }
+  void begin_parallel(int kind = 0) {
+    ++cur_phase; cur_lane = 0; in_parallel = true; region_seq = (seq_mask >> kind) & 1;
+    region_reset();
+  }
   void end_parallel() { in_parallel = false; }
   void lane(int k) { cur_lane = region_seq ? 0 : k % 4; }
   void push(Op&& op) {
     if (!in_parallel) { ++cur_phase; cur_lane = 0; }
     op.phase = cur_phase;
     op.lane = cur_lane;
+    if (in_parallel && !region_seq) {
+      const int idx = (int)e.ops.size(), a = cur_lane;
+      unsigned mask = 0;
+      auto reads = [&](const Ref& r) {
+        if (r.act < 0 || r.act >= (int)act_w.size()) return;
+        for (int b2 = 0; b2 < 4; ++b2)
+          if (b2 != a && act_w[r.act][b2] > lane_seen[a][b2]) mask |= 1u << b2;
+      };
+      reads(op.in); reads(op.in2); reads(op.res);
+      for (int k = 0; k < op.fn && k < 4; ++k) reads(op.fsrc[k]);
+      for (int b2 = 0; b2 < 4; ++b2)
+        if (mask & (1u << b2)) lane_seen[a][b2] = lane_last[b2];
+      op.wait_mask = mask;
+      auto writes = [&](const Ref& r) {
+        if (r.act < 0) return;
+        if ((int)act_w.size() <= r.act) act_w.resize(r.act + 1, std::array<int, 4>{-1, -1, -1, -1});
+        act_w[r.act][a] = idx;
+      };
+      writes(op.out); writes(op.out2);
+      lane_last[a] = idx;
+    }
     e.ops.push_back(std::move(op));
   }
 
@@ -555,7 +600,15 @@ struct Builder {
       }
       xr[i] = (kc >= 0 && i == T - 1) ? R(kc, kc_off[i]) : R(xs[i]);
     }
-    end_parallel();
+    // xdep (round 3): ONE join per module instead of three.  The fuse convs that read x_j follow branch j's chain on ITS lane and
+    // the middle convs of a down chain stay on the lane of their source, so chains, first fuse convs and middle convs of a module
+    // need no synchronisation at all (round 2 joined all lanes after the chains and again after the first fuse convs and spread the
+    // fuse convs round-robin over the lanes): a lane that finishes its chain early does its fuse convs while the slowest chain is
+    // still running, and behind the slowest chain only its own fuse convs remain before the join in front of the sums.
+    // W48-CLIFF 64 crops 4508 -> 4654 crops/s (+3.2 %), PARE 32 crops +3.3 %, W48 16 crops +6.5 % (same box, POCO_NO_XDEP=1 against default).
+    const bool dag = xdep && !region_seq;
+    auto BL = [&](int i) { return i < (int)lmap.size() ? lmap[i] - '0' : i; };
+    if (!dag) end_parallel();
     // phase 2: cross-resolution terms.  All first convs that read the same branch output xs[j] run as ONE
     // launch each (the 1x1 up-path convs j -> i<j, and the first 3x3 stride-2 convs of the down paths
     // j -> i>j): the input is read once and the small per-path launches disappear.
@@ -563,14 +616,14 @@ struct Builder {
     std::vector<std::vector<Ref>> chain(nb, std::vector<Ref>(nb));   // [i][j]: running tensor of down path j -> i
     for (int i = 0; i < nb; ++i) terms[i].resize(nb);
     auto fl = [&](int i, int j) { return p + ".fuse_layers." + std::to_string(i) + "." + std::to_string(j); };
-    begin_parallel(2);
+    if (!dag) begin_parallel(2);
     int rr = 0;
     for (int j = 0; j < nb; ++j) {
       if (j > 0) {                       // up paths: 1x1 conv + BN (hrnet.py:196-207), upsampled inside the sum
         std::vector<SubConv> subs;
         for (int i = 0; i < j; ++i) subs.push_back({fl(i, j) + ".0", fl(i, j) + ".1", ch[i], 0});
         std::vector<int> off;
-        lane(rr++);
+        lane(dag ? BL(j) : rr++);
         const int t = conv_multi(p + ".fuse_up." + std::to_string(j), subs, xr[j], ch[j], 1, 1, &off);
         for (int i = 0; i < j; ++i) terms[i][j] = {R(t, off[i]), j - i};
       }
@@ -585,7 +638,7 @@ struct Builder {
         }
         if (!subs.empty()) {
           std::vector<int> off;
-          lane(rr++);
+          lane(dag ? BL(j) : rr++);
           // the convs reading x_{T-2} produce exactly [A | t_{T-2}]: straight into the head of kc
           const Ref into = (kc >= 0 && j == T - 2) ? R(kc, 0) : Ref();
           const int t = conv_multi(p + ".fuse_down." + std::to_string(j), subs, xr[j], ch[j], 3, 2, &off, into);
@@ -593,15 +646,15 @@ struct Builder {
         }
       }
     }
-    end_parallel();
+    if (!dag) end_parallel();
     // phase 2b: the rest of the down chains (different inputs -> separate launches), one lane per chain
-    begin_parallel(3);
+    if (!dag) begin_parallel(3);
     rr = 0;
     for (int i = 0; i < nb; ++i)
       for (int j = 0; j < i; ++j) {
         const bool merged = km && i == T;           // the last conv of this chain runs inside the K-merged conv
         const int nconv = i - j - 1 - (merged ? 1 : 0);   // convs of the chain that run here
-        if (nconv > 0) lane(rr++);
+        if (nconv > 0) lane(dag ? BL(j) : rr++);
         Ref t = chain[i][j];
         for (int k = 1; k < i - j - (merged ? 1 : 0); ++k) {
           const bool lastk = (k == i - j - 1);
@@ -613,12 +666,15 @@ struct Builder {
         }
         terms[i][j] = {t, 0};
       }
+    // phase 3: the sums (+ReLU), one lane per output branch - behind the ONE join of a module: every sum needs terms of (nearly)
+    // all lanes anyway.  (Measured without this join as well - the sums waiting for exactly their producers' lanes through
+    // events: correct in eager mode, but hipStreamEndCapture segfaults on the captured graph as soon as a stage with three
+    // branches is scheduled that way, ROCm 7.2; the join costs nothing measurable.)
     end_parallel();
-    // phase 3: the sums (+ReLU), one lane per output branch
     std::vector<int> outs(nb);
     begin_parallel(4);
     for (int i = 0; i < nb; ++i) {
-      lane(i);
+      lane(dag ? BL(i) : i);
       const Act a = e.acts[xs[i]];
       if (km && i == T) { outs[i] = kmerge_conv(p, fl, ch, T, kc >= 0 ? R(kc, ch[T - 1]) : xr[0], R(xs[T])); continue; }
       terms[i][i] = {xr[i], 0};
@@ -669,7 +725,7 @@ struct Builder {
   }
 
   // stem + layer1 + transitions + stages 2-4 (hrnet.py:466-497 / hrnet_cls.py:438-469)
-  std::vector<int> hrnet_trunk(const std::string& p, int w, Ref final_out0 = Ref()) {
+  std::vector<int> hrnet_trunk(const std::string& p, int w, Ref final_out0 = Ref(), bool open_after = false) {
     int x = stem(p, 3, 224);
     const int cat = kcat ? new_act(128, 56, 56) : -1;      // [layer1.0 conv2 output | stem output], see bottleneck()
     x = conv_bn(p + "conv2", p + "bn2", x, 64, 64, 3, 2, 1, -1, false, 0, kcat ? R(cat, 64) : Ref());
@@ -685,8 +741,11 @@ struct Builder {
       std::vector<int> xs(nb);
       // the transition convs are few and large (each fills the chip on its own): measured faster back to back
       // on one stream than as concurrent lanes (19.0-19.2 vs 19.35 ms per 64-crop forward)
-      begin_parallel(5);
-      region_seq = !((seq_mask >> 6) & 1);
+      const bool open = region_open;          // the previous stage's last module left its region open (xdep)
+      if (!open) {
+        begin_parallel(5);
+        region_seq = !((seq_mask >> 6) & 1);
+      }
       for (int i = 0; i < nb; ++i) {
         lane(i);
         const std::string ti = t + "." + std::to_string(i);
@@ -698,11 +757,12 @@ struct Builder {
           xs[i] = conv_bn(ti + ".0.0", ti + ".0.1", ys.back(), prev_ch.back(), ch[i], 3, 2, 1);
         }
       }
-      end_parallel();
+      if (!open) end_parallel();
       for (int m = 0; m < nmod[s]; ++m) {
         const bool last = (s == 2 && m == nmod[s] - 1);
+        const bool stage_end_open = xdep && (m + 1 == nmod[s]) && (s < 2 || open_after);
         xs = hr_module(p + "stage" + std::to_string(s + 2) + "." + std::to_string(m), xs, ch, last ? final_out0 : Ref(),
-                       m + 1 < nmod[s]);
+                       m + 1 < nmod[s] || stage_end_open);
       }
       ys = xs;
       prev_ch = ch;
@@ -874,12 +934,14 @@ bool build_graph(Engine& e, bool declare) {
     b.P(bp + "final_layer.weight", {24, 32, 1, 1}, 0);
     b.P(bp + "final_layer.bias", {24}, 0);
   } else if (e.backbone == "hrnet_w48_cls") {
-    std::vector<int> ys = b.hrnet_trunk(bp, 48);
+    std::vector<int> ys = b.hrnet_trunk(bp, 48, Ref(), /*open_after=*/true);
     const int hc[4] = {32, 64, 128, 256};
     // the four incre_modules (one Bottleneck per resolution, hrnet_cls.py:306-321) are independent and small
-    // (20-50 us kernels): one lane each, then the sequential downsample chain
+    // (20-50 us kernels): one lane each - the lane that ran the branch's fuse sum of the last module when the trunk left its
+    // region open - then the sequential downsample chain
     int inc[4];
-    b.begin_parallel(8);
+    if (!b.region_open) b.begin_parallel(8);
+    b.region_open = false;
     for (int i = 0; i < 4; ++i) {
       b.lane(i);
       inc[i] = b.bottleneck(bp + "incre_modules." + std::to_string(i) + ".0", ys[i], 48 << i, hc[i], 1, true);
@@ -1437,6 +1499,16 @@ extern "C" int poco_finalize(poco_handle_t h) {
   if (e->wino4g_scratch_need)          // ALG 11 staging: one buffer per lane (ops of different lanes run concurrently)
     for (int k = 0; k < 4; ++k) POCO_HIP_CHECK(hipMalloc(&e->wino4g_scratch[k], e->wino4g_scratch_need * sizeof(float)));
   POCO_HIP_CHECK(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
+  for (Op& op : e->ops)
+    if (op.wait_mask) {
+      op.dep_ev = (int)e->ev_dep.size();
+      for (int k = 0; k < 4; ++k)
+        if (op.wait_mask & (1u << k)) {
+          hipEvent_t ev;
+          POCO_HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+          e->ev_dep.push_back(ev);
+        }
+    }
   for (int k = 1; k < 4; ++k) {
     POCO_HIP_CHECK(hipStreamCreateWithFlags(&e->lane_stream[k], hipStreamNonBlocking));
     POCO_HIP_CHECK(hipEventCreateWithFlags(&e->ev_join[k], hipEventDisableTiming));
@@ -1468,6 +1540,16 @@ static int enqueue_program(Engine* e, int B, const IO& io, hipStream_t main) {
     for (int k = i; k < j; ++k) {
       Op& op = e->ops[k];
       hipStream_t s = (fork && op.lane > 0) ? side[op.lane] : main;
+      if (fork && op.wait_mask) {
+        // cross-lane dependencies: everything enqueued so far on those lanes (program order = enqueue order)
+        int n = 0;
+        for (int l = 0; l < 4; ++l)
+          if (op.wait_mask & (1u << l)) {
+            hipEvent_t ev = e->ev_dep[op.dep_ev + n++];
+            POCO_HIP_CHECK(hipEventRecord(ev, l > 0 ? side[l] : main));
+            POCO_HIP_CHECK(hipStreamWaitEvent(s, ev, 0));
+          }
+      }
       int rc = run_op(*e, op, B, io, s);
       if (rc != POCO_OK) return rc;
     }

@@ -295,6 +295,35 @@ def test_kmerged_fuse_convs_match_separate_form(variant, B, cuda, monkeypatch):
         assert torch.equal(out1[k], out[k]), (k, "1 lane")
 
 
+@pytest.mark.parametrize("variant,B", [("hrnet_w48_cls-cliff", 6), ("hrnet_w32-pare", 4)])
+def test_one_join_per_module_schedule_is_bitwise_the_three_join_one(variant, B, cuda, monkeypatch):
+    """Scheduling only (engine.hip hr_module / hrnet_trunk, `xdep`): the fuse convs on the lane of the branch they read, one
+    join per HR module instead of three, stage boundaries and the cls-head incre modules inside the open region with the
+    transition conv waiting for the K-merged conv's lane through an event.  Same kernels, same configurations, same operands:
+    every output must be BITWISE what the three-join schedule (POCO_NO_XDEP=1) produces - eager on 4 lanes, on 1 lane, and as a
+    replayed hipGraph (repeated: a missing dependency shows up as a rare differing tile)."""
+    batch = util.cuda_batch(synth.synth_batch(B, 57), cuda)
+    keys = ("pred_pose", "pred_shape", "pred_cam", "var_pose", "smpl_vertices", "uncert_feat")
+    monkeypatch.setenv("POCO_NO_XDEP", "1")
+    old = util.make_engine(variant, max_batch=B, profile="stress")
+    ref = {k: v.clone() for k, v in old(batch).items() if k in keys}
+    monkeypatch.setenv("POCO_NO_XDEP", "0")
+    new = util.make_engine(variant, max_batch=B, profile="stress")
+    assert [o[0] for o in new.ops()] != [] and len(new.ops()) == len(old.ops())
+    for lanes in (4, 1, 4):
+        new.set_num_lanes(lanes)
+        for _ in range(5):
+            out = new(batch)
+            for k in keys:
+                assert torch.equal(out[k], ref[k]), (k, lanes)
+    o = new._alloc_outputs(B, False)
+    for _ in range(10):
+        new.graph_forward(batch, o)
+        torch.cuda.synchronize()
+        for k in keys[:-1]:
+            assert torch.equal(o[k], ref[k]), (k, "graph")
+
+
 def test_split_f16_experiment_passes_the_gate(cuda, monkeypatch):
     """VERDICT r2 next #9 (EXPERIMENT, bench.py --split-f16, never the default): ResNet-50-CLIFF with every plain 1x1 conv on the
     split-fp16 GEMM (fp16 hi + lo, 3 MFMAs per product) must pass the STRESS fixtures at the same 1e-3 gate - golden B = 2 made by
