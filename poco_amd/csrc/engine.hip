@@ -654,7 +654,7 @@ struct Builder {
       for (int j = 0; j < i; ++j) {
         const bool merged = km && i == T;           // the last conv of this chain runs inside the K-merged conv
         const int nconv = i - j - 1 - (merged ? 1 : 0);   // convs of the chain that run here
-        if (nconv > 0) lane(dag ? BL(j) : rr++);
+        if (nconv > 0) lane(dag ? BL(j) : rr++);       // (on another, lighter lane with an event: -0.3 % - more waiting than balance)
         Ref t = chain[i][j];
         for (int k = 1; k < i - j - (merged ? 1 : 0); ++k) {
           const bool lastk = (k == i - j - 1);
@@ -742,7 +742,7 @@ struct Builder {
       // the transition convs are few and large (each fills the chip on its own): measured faster back to back
       // on one stream than as concurrent lanes (19.0-19.2 vs 19.35 ms per 64-crop forward)
       const bool open = region_open;          // the previous stage's last module left its region open (xdep)
-      if (!open) {
+      if (!open) {          // (transition 1 as lanes of the stage-2 region, i.e. without its join: W48 -0.6 %, PARE +0.2 % - not kept)
         begin_parallel(5);
         region_seq = !((seq_mask >> 6) & 1);
       }
