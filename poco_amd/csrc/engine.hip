@@ -907,11 +907,17 @@ bool build_graph(Engine& e, bool declare) {
   // ---- backbone ------------------------------------------------------------------------------
   if (e.backbone == "hrnet_w32") {
     feat480 = b.new_act(480, 56, 56);
-    std::vector<int> ys = b.hrnet_trunk(bp, 32, Builder::R(feat480, 0));
-    // hrnet.py:515-519: bilinear x2 (align_corners) + conv3x3 + BN + ReLU chains, channel concat
+    static const bool up_lanes = [] { const char* v = getenv("POCO_NO_UP_LANES"); return !(v && atoi(v)); }();
+    std::vector<int> ys = b.hrnet_trunk(bp, 32, Builder::R(feat480, 0), /*open_after=*/up_lanes);
+    // hrnet.py:515-519: bilinear x2 (align_corners) + conv3x3 + BN + ReLU chains, channel concat.  The three chains are
+    // independent: each one continues on the lane that ran its branch's fuse sum of the last module (POCO_NO_UP_LANES=1: one
+    // after the other on one stream, the round-2 form)
     const int chs[4] = {32, 64, 128, 256};
     const int offs[4] = {0, 32, 96, 224};
+    const bool up_open = b.region_open;
+    b.region_open = false;
     for (int br = 1; br < 4; ++br) {
+      if (up_open) b.lane(br);
       int y = ys[br];
       for (int t = 0; t < br; ++t) {
         const Act a = e.acts[y];
@@ -927,6 +933,7 @@ bool build_graph(Engine& e, bool declare) {
                    lastt ? Builder::R(feat480, offs[br]) : Ref());
       }
     }
+    if (up_open) b.end_parallel();
     // optional copy of the 480-channel map for parity checks (skipped when the caller passes no pointer)
     { Op op; op.type = OP_NCHW_OUT; op.name = "out.backbone_feat"; op.in = Builder::R(feat480); op.out = Builder::X(Y_BBFEAT);
       op.C = 480; b.push(std::move(op)); }
