@@ -211,6 +211,7 @@ struct Builder {
   // same region; the transition conv is the only op that needs another lane's result (the K-merged conv of lane T) and waits for
   // it through an event (Op::wait_lane) instead of a join of all lanes.
   bool xdep = [] { const char* v = getenv("POCO_NO_XDEP"); return !(v && atoi(v)); }();
+  bool tail_lanes = [] { const char* v = getenv("POCO_NO_TAIL_LANES"); return !(v && atoi(v)); }();
   // Cross-lane dependencies are INFERRED, not declared: inside a region the builder remembers which lanes wrote (a slice of) every
   // activation and up to which op a lane has already synchronised with every other lane; an op that reads an activation written
   // on another lane after that point gets that lane in its wait mask.  (Activations are written once per region - concat
@@ -900,6 +901,9 @@ bool build_graph(Engine& e, bool declare) {
   e.ops.clear();
   const bool cliff = e.head == "cliff";
   const std::string bp = "backbone.";
+  // (ResNet-50 is one chain of kernels and never forks a stream: a fork / join just for the tail costs more than the overlap gives,
+  // 808 -> 771 crops/s at one crop, -0.2 % at 64)
+  if (e.backbone == "resnet50") b.tail_lanes = false;
   int xc = -1;          // CLIFF fc1 input vector [XC_DIM]
   int feat480 = -1;
   if (cliff) xc = b.new_act(XC_DIM, 1, 1, true);
@@ -1056,13 +1060,18 @@ bool build_graph(Engine& e, bool declare) {
     int rot = b.new_act(224, 1, 1, true);
     { Op op; op.type = OP_ROT6D; op.name = hp + "rot6d"; op.in = Builder::R(xc, XC_STATE); op.out = Builder::R(rot);
       op.out2 = Builder::X(Y_POSE); b.push(std::move(op)); }
+    // the tail is two independent chains of small kernels: SMPL-LBS + camera on one lane, the output copies and the confidence
+    // MLP on another (POCO_NO_TAIL_LANES=1: one stream)
+    if (b.tail_lanes) { b.begin_parallel(9); b.lane(1); }
     add_copy(b, "out.pred_pose6d", Builder::R(xc, XC_STATE), Builder::X(Y_POSE6D), 144);
     add_copy(b, "out.pred_shape", Builder::R(xc, XC_STATE + 144), Builder::X(Y_SHAPE), 10);
     add_copy(b, "out.pred_cam", Builder::R(xc, XC_STATE + 154), Builder::X(Y_CAM), 3);
     add_copy(b, "out.uncert_feat", Builder::R(xc, 0), Builder::X(Y_UFEAT), 2048);
     add_copy(b, "out.body_feat2", Builder::R(h2), Builder::X(Y_BODY2), 1024);
     e.uncert_feat_dim = 2048;
+    if (b.tail_lanes) b.lane(0);
     build_tail(b, Builder::R(xc, XC_STATE + 144), Builder::R(rot), Builder::R(xc, XC_STATE + 154), true);
+    if (b.tail_lanes) b.lane(1);
     // poco_head 'feat-pose-net' (poco_head.py:122-141): sigmoid(featNet(feat)) || sigmoid(poseNet(R)) -> fc1 -> sigmoid
     int u = b.new_act(448, 1, 1, true);
     b.conv(up + "uncert_fc_featNet", up + "uncert_fc_featNet", "", Builder::R(xc, 0), 2048, 216, 1, 1, 2, true, Ref(), 0,
@@ -1072,6 +1081,7 @@ bool build_graph(Engine& e, bool declare) {
     int var = b.conv(up + "uncert_fc1", up + "uncert_fc1", "", Builder::R(u), 432, 24, 1, 1, 2, true, Ref(), 0, Ref(),
                      nullptr, 448, true);
     add_copy(b, "out.var_pose", Builder::R(var), Builder::X(Y_VAR), 24);
+    if (b.tail_lanes) b.end_parallel();
     build_flow(b, 2048);
   } else if (e.head == "pare") {
     if (feat480 < 0) { e.err = "pare head needs the hrnet_w32 backbone"; return false; }
@@ -1079,10 +1089,13 @@ bool build_graph(Engine& e, bool declare) {
       int y = b.conv_bn(hp + nm + ".0", hp + nm + ".1", feat480, 480, 128, 3, 1, 1);
       return b.conv_bn(hp + nm + ".3", hp + nm + ".4", y, 128, 128, 3, 1, 1);
     };
+    if (b.tail_lanes) { b.begin_parallel(9); b.lane(0); }
     int kp = branch("keypoint_deconv_layers");
     int heat = b.conv(hp + "keypoint_final_layer", hp + "keypoint_final_layer", "", Builder::R(kp), 128, 25, 1, 1, 0, true);
+    if (b.tail_lanes) b.lane(1);
     int sm = branch("smpl_deconv_layers");
     int cs = b.conv(hp + "smpl_final_layer", hp + "smpl_final_layer", "", Builder::R(sm), 128, 64, 1, 1, 0, true);
+    if (b.tail_lanes) b.end_parallel();
     int xu = b.new_act(XU_DIM, 1, 1, true);
     int flat = b.new_act(1536, 1, 1, true);
     e.a_attn_scratch = b.new_act((int)(part_attention_scratch_floats(1, 128)), 1, 1, true);
@@ -1117,6 +1130,7 @@ bool build_graph(Engine& e, bool declare) {
     b.P(hp + "init_pose", {1, 144}, 0);
     b.P(hp + "init_shape", {1, 10}, 0);
     b.P(hp + "init_cam", {1, 3}, 0);
+    if (b.tail_lanes) { b.begin_parallel(9); b.lane(1); }
     add_copy(b, "out.pred_pose6d", Builder::R(pose6d), Builder::X(Y_POSE6D), 144);
     add_copy(b, "out.pred_shape", Builder::R(sc13, 0), Builder::X(Y_SHAPE), 10);
     add_copy(b, "out.pred_cam", Builder::R(sc13, 10), Builder::X(Y_CAM), 3);
@@ -1125,13 +1139,16 @@ bool build_graph(Engine& e, bool declare) {
       op.C = 25; b.push(std::move(op)); }
     e.uncert_feat_dim = 3072;
     // rotmat for SMPL is read from the xu vector (channel 3072.., stride XU_DIM)
+    if (b.tail_lanes) b.lane(0);
     build_tail(b, Builder::R(sc13, 0), Builder::R(xu, 3072), Builder::R(sc13, 10), false);
+    if (b.tail_lanes) b.lane(1);
     // poco_head 'feat-pose' (poco_head.py:134-141): sigmoid(fc2(sigmoid(fc1([feat; R]))))
     int h = b.conv(up + "uncert_fc1", up + "uncert_fc1", "", Builder::R(xu), 3288, 512, 1, 1, 2, true, Ref(), 0, Ref(),
                    nullptr, XU_DIM, true);
     int var = b.conv(up + "uncert_fc2", up + "uncert_fc2", "", Builder::R(h), 512, 24, 1, 1, 2, true, Ref(), 0, Ref(),
                      nullptr, 0, true);
     add_copy(b, "out.var_pose", Builder::R(var), Builder::X(Y_VAR), 24);
+    if (b.tail_lanes) b.end_parallel();
     build_flow(b, 3072);
   } else {
     e.err = "unknown head " + e.head;
