@@ -4,7 +4,17 @@ import sys
 from collections import defaultdict
 
 rows = list(csv.DictReader(open(sys.argv[1])))
-ks = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Stream_Id", r.get("Queue_Id", "0"))) for r in rows]
+def _wgs(r):     # workgroups of the launch (the symbol alone does not tell a 128-block 14x14 conv from a 256-block 56x56 one)
+    try:
+        g = int(r.get("Grid_Size_X", r.get("Grid_Size", 0))) * max(1, int(r.get("Grid_Size_Y", 1))) * max(1, int(r.get("Grid_Size_Z", 1)))
+        w = int(r.get("Workgroup_Size_X", r.get("Workgroup_Size", 1))) * max(1, int(r.get("Workgroup_Size_Y", 1))) * max(1, int(r.get("Workgroup_Size_Z", 1)))
+        return g // max(1, w)
+    except (TypeError, ValueError):
+        return 0
+
+
+ks = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][:48] + f" [{_wgs(r)} wg]",
+       r.get("Stream_Id", r.get("Queue_Id", "0"))) for r in rows]
 ks.sort()
 # last forward = between the last two stem kernels
 stems = [i for i, k in enumerate(ks) if "stem_conv" in k[2]]
@@ -54,5 +64,5 @@ for t, kind, i in pts:
         live.discard(i)
     last = t
 print("wall time with exactly one kernel resident, by kernel:")
-for n, v in sorted(solo.items(), key=lambda kv: -kv[1])[:14]:
+for n, v in sorted(solo.items(), key=lambda kv: -kv[1])[:22]:
     print(f"  {v / 1e3:8.1f} us  {n}")
