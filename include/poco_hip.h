@@ -96,6 +96,12 @@ int poco_set_num_lanes(poco_handle_t h, int n);
 /* Introspection / tuning. */
 int poco_num_ops(poco_handle_t h);
 int poco_op_info(poco_handle_t h, int i, char* name, size_t name_cap, double* flops_per_crop, int* type);
+/* Schedule of op i (available after poco_create, no GPU needed): sched[0] = phase (parallel region; regions are separated by joins of
+ * all lanes), [1] = lane (HIP stream inside the region), [2] = bit mask of the lanes of the region this op additionally waits for
+ * through events (everything enqueued on them before it), [3] = number of reads, then (activation id, first channel, end channel)
+ * per read, then the number of writes and the same triples.  At most `cap` ints are written (cap >= 40 always suffices).  Lets a
+ * test check, without a GPU, that no op reads channels another lane writes in the same region without waiting for it. */
+int poco_op_sched(poco_handle_t h, int i, int* sched, int cap);
 int poco_profile_ops(poco_handle_t h, int B, const poco_inputs_t* in, const poco_outputs_t* out, int iters,
                      float* ms_per_op, int cap, void* stream);
 size_t poco_workspace_bytes(poco_handle_t h);

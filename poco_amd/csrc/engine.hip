@@ -144,6 +144,24 @@ struct Engine {
 // Builder: the same code path declares the tensors (declare=true, host only) and builds the
 // launch program (declare=false, uploads packed weights).
 // ------------------------------------------------------------------------------------------------
+// What an op reads and writes, as channel ranges of activations (concat buffers are written and read by slices): the one
+// description the builder's dependency inference (Builder::push) and the schedule introspection (poco_op_sched) share.
+struct OpAccess { int act, lo, hi; };
+static void op_accesses(const Engine& e, const Op& op, std::vector<OpAccess>* rd, std::vector<OpAccess>* wr) {
+  constexpr int ALL = 1 << 30;
+  auto add = [](std::vector<OpAccess>* to, const Ref& r, int n) {
+    if (r.act >= 0) to->push_back({r.act, n == ALL ? 0 : r.co, n == ALL ? ALL : r.co + n});
+  };
+  const bool conv = op.type == OP_CONV;
+  add(rd, op.in, conv ? op.Cin : ALL);
+  add(rd, op.in2, ALL);
+  add(rd, op.res, conv ? op.Cout : ALL);
+  for (int k = 0; k < op.fn && k < 4; ++k) add(rd, op.fsrc[k], op.type == OP_FUSE ? op.C : ALL);
+  if (op.type == OP_SMPL || op.type == OP_CAMERA) { add(rd, e.smpl_betas, ALL); add(rd, e.smpl_rot, ALL); add(rd, e.cam_ref, ALL); }   // implicit operands
+  add(wr, op.out, conv ? op.Cout : (op.type == OP_FUSE ? op.C : ALL));
+  add(wr, op.out2, ALL);
+}
+
 struct Builder {
   Engine& e;
   bool declare;
@@ -216,7 +234,8 @@ struct Builder {
   // activation and up to which op a lane has already synchronised with every other lane; an op that reads an activation written
   // on another lane after that point gets that lane in its wait mask.  (Activations are written once per region - concat
   // buffers by slices - and the planner recycles memory only across regions, so read-after-write is the only hazard.)
-  std::vector<std::array<int, 4>> act_w;      // [act][lane]: index of the last op of this region that wrote it on that lane (-1)
+  struct SliceW { int lo, hi, lane, idx; };   // channels [lo, hi) of an activation written by op idx on that lane
+  std::vector<std::vector<SliceW>> act_w;     // [act]: what this region has written so far (concat buffers: several slices)
   int lane_last[4] = {-1, -1, -1, -1};        // last op pushed on each lane in this region
   int lane_seen[4][4];                        // [a][b]: lane a has waited for lane b up to this op index
   void region_reset() {
@@ -236,22 +255,20 @@ struct Builder {
     if (in_parallel && !region_seq) {
       const int idx = (int)e.ops.size(), a = cur_lane;
       unsigned mask = 0;
-      auto reads = [&](const Ref& r) {
-        if (r.act < 0 || r.act >= (int)act_w.size()) return;
-        for (int b2 = 0; b2 < 4; ++b2)
-          if (b2 != a && act_w[r.act][b2] > lane_seen[a][b2]) mask |= 1u << b2;
-      };
-      reads(op.in); reads(op.in2); reads(op.res);
-      for (int k = 0; k < op.fn && k < 4; ++k) reads(op.fsrc[k]);
+      std::vector<OpAccess> rd, wr;
+      op_accesses(e, op, &rd, &wr);
+      for (const OpAccess& r : rd) {
+        if (r.act >= (int)act_w.size()) continue;
+        for (const SliceW& w : act_w[r.act])
+          if (w.lane != a && w.lo < r.hi && r.lo < w.hi && w.idx > lane_seen[a][w.lane]) mask |= 1u << w.lane;
+      }
       for (int b2 = 0; b2 < 4; ++b2)
         if (mask & (1u << b2)) lane_seen[a][b2] = lane_last[b2];
       op.wait_mask = mask;
-      auto writes = [&](const Ref& r) {
-        if (r.act < 0) return;
-        if ((int)act_w.size() <= r.act) act_w.resize(r.act + 1, std::array<int, 4>{-1, -1, -1, -1});
-        act_w[r.act][a] = idx;
-      };
-      writes(op.out); writes(op.out2);
+      for (const OpAccess& w : wr) {
+        if ((int)act_w.size() <= w.act) act_w.resize(w.act + 1);
+        act_w[w.act].push_back({w.lo, w.hi, a, idx});
+      }
       lane_last[a] = idx;
     }
     e.ops.push_back(std::move(op));
@@ -1620,6 +1637,21 @@ extern "C" int poco_op_info(poco_handle_t h, int i, char* name, size_t name_cap,
   if (name && name_cap) { std::strncpy(name, op.name.c_str(), name_cap - 1); name[name_cap - 1] = 0; }
   if (flops_per_crop) *flops_per_crop = op.flops;
   if (type) *type = op.type;
+  return POCO_OK;
+}
+
+extern "C" int poco_op_sched(poco_handle_t h, int i, int* sched, int cap) {
+  Engine* e = H(h);
+  if (!e || !sched || i < 0 || i >= (int)e->ops.size()) { poco_set_error("poco_op_sched: bad arguments"); return POCO_ERR_ARG; }
+  const Op& op = e->ops[i];
+  std::vector<OpAccess> rd, wr;
+  op_accesses(*e, op, &rd, &wr);
+  std::vector<int> v = {op.phase, op.lane, (int)op.wait_mask, (int)rd.size()};
+  for (const OpAccess& a : rd) { v.push_back(a.act); v.push_back(a.lo); v.push_back(a.hi); }
+  v.push_back((int)wr.size());
+  for (const OpAccess& a : wr) { v.push_back(a.act); v.push_back(a.lo); v.push_back(a.hi); }
+  if ((int)v.size() > cap) { poco_set_error("poco_op_sched: buffer too small"); return POCO_ERR_ARG; }
+  std::copy(v.begin(), v.end(), sched);
   return POCO_OK;
 }
 

@@ -44,6 +44,7 @@ def _bind():
     L.poco_finalize.argtypes = [C.c_void_p]
     L.poco_forward.argtypes = [C.c_void_p, C.c_int, C.POINTER(_Inputs), C.POINTER(_Outputs), C.c_void_p]
     L.poco_num_ops.argtypes = [C.c_void_p]
+    L.poco_op_sched.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_int]
     L.poco_op_info.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_size_t, C.POINTER(C.c_double), C.POINTER(C.c_int)]
     L.poco_profile_ops.argtypes = [C.c_void_p, C.c_int, C.POINTER(_Inputs), C.POINTER(_Outputs), C.c_int,
                                    C.POINTER(C.c_float), C.c_int, C.c_void_p]
@@ -312,6 +313,17 @@ class POCO:
             check(self._L.poco_op_info(self._h, i, name, 256, C.byref(fl), C.byref(ty)), "poco_op_info")
             out.append((name.value.decode(), fl.value, ty.value))
         return out
+
+    def op_sched(self, op_index: int):
+        """(phase, lane, wait_mask, reads, writes) of an op - the schedule the engine enqueues (include/poco_hip.h poco_op_sched; no
+        GPU needed); reads / writes are (activation id, first channel, end channel) triples."""
+        v = (C.c_int * 64)()
+        check(self._L.poco_op_sched(self._h, op_index, v, 64), "poco_op_sched")
+        nr = v[3]
+        rd = tuple((v[4 + 3 * k], v[5 + 3 * k], v[6 + 3 * k]) for k in range(nr))
+        p = 4 + 3 * nr
+        wr = tuple((v[p + 1 + 3 * k], v[p + 2 + 3 * k], v[p + 3 + 3 * k]) for k in range(v[p]))
+        return v[0], v[1], v[2], rd, wr
 
     def profile_ops(self, batch, iters=5):
         self.finalize()

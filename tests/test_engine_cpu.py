@@ -133,3 +133,63 @@ def test_c_abi_from_plain_c(tmp_path):
     env["LD_LIBRARY_PATH"] = "/opt/rocm/lib:" + env.get("LD_LIBRARY_PATH", "")
     r = subprocess.run([str(exe), str(_lib.LIB_PATH)], capture_output=True, text=True, env=env)
     assert r.returncode == 0 and r.stdout.startswith("ok "), (r.returncode, r.stdout, r.stderr)
+
+
+@pytest.mark.parametrize("xdep", ["1", "0"])
+@pytest.mark.parametrize("variant", list(VARIANTS))
+def test_schedule_has_no_unsynchronised_cross_lane_read(variant, xdep, monkeypatch):
+    """The schedule the engine enqueues (include/poco_hip.h poco_op_sched; csrc/engine.hip Builder::push, enqueue_program), checked
+    without a GPU by a vector-clock walk: regions (phases) are separated by joins of all lanes; inside a region an op on lane a may
+    read an activation that lane b != a writes in the SAME region only if a has waited (wait_mask, transitively) for an op of b at
+    or after the writer.  Covers the one-join-per-module schedule with its open stage boundaries and event dependencies (default)
+    and the three-join schedule (POCO_NO_XDEP=1).  Also: every cross-lane wait names a lane that has work in the region, and the
+    default schedule does contain such waits for the HRNet variants (the transition convs at the stage boundaries)."""
+    monkeypatch.setenv("POCO_NO_XDEP", "0" if xdep == "1" else "1")
+    m = POCO(backbone=variant, num_flow_layers=VARIANTS[variant], max_batch=2)      # declarations only
+    n = len(m.ops())
+    sched = [m.op_sched(i) for i in range(n)]
+    names = [o[0] for o in m.ops()]
+    waits, cross_reads = 0, 0
+    i = 0
+    while i < n:
+        ph = sched[i][0]
+        j = i
+        while j < n and sched[j][0] == ph:
+            j += 1
+        writer = {}                       # act -> list of (lane, op index) inside this region
+        last = [-1] * 4                   # last op enqueued on each lane
+        vc = [[-1] * 4 for _ in range(4)]   # vc[a][b]: lane a is ordered after op vc[a][b] of lane b
+        snap = {}                         # op index -> vector clock of its lane right after it
+        for k in range(i, j):
+            _, a, mask, rd, wr = sched[k]
+            assert 0 <= a < 4 and phase_monotone(sched, k)
+            for b in range(4):
+                if mask & (1 << b):
+                    assert b != a and last[b] >= 0, (names[k], "waits for a lane without work", b)
+                    waits += 1
+                    vc[a][b] = max(vc[a][b], last[b])
+                    for c in range(4):                                  # what lane b had seen when that op was enqueued
+                        vc[a][c] = max(vc[a][c], snap[last[b]][c])
+            for act, lo, hi in rd:
+                for (b, w, wlo, whi) in writer.get(act, []):
+                    if b != a and wlo < hi and lo < whi:
+                        cross_reads += 1
+                        assert vc[a][b] >= w, (variant, names[k], "reads activation", act, (lo, hi), "written by", names[w], "on lane", b,
+                                               "without waiting for it")
+            for act, lo, hi in wr:
+                for (b, w, wlo, whi) in writer.get(act, []):          # two lanes never write overlapping channels unordered
+                    if b != a and wlo < hi and lo < whi:
+                        assert vc[a][b] >= w, (variant, names[k], "overwrites", act, (lo, hi), "of", names[w], "unordered")
+                writer.setdefault(act, []).append((a, k, lo, hi))
+            last[a] = k
+            vc[a][a] = k
+            snap[k] = list(vc[a])
+        i = j
+    if variant.startswith("hrnet") and xdep == "1":
+        assert waits >= 2 and cross_reads >= 2        # transition convs read the K-merged conv's output of another lane
+    if xdep == "0":
+        assert waits == 0 and cross_reads == 0        # the three-join schedule never reads across lanes inside a region
+
+
+def phase_monotone(sched, k):
+    return k == 0 or sched[k][0] >= sched[k - 1][0]
