@@ -182,6 +182,9 @@ def cpu_baseline(variant, B=64, passes=3, inst_threads=32):
                       f"{' and '.join(legs) if legs else 'no multi-instance leg'} sharing the {B} crops (2 passes)"}
 
 
+STAGE_THREADS = int(os.environ.get("POCO_STAGE_THREADS", "4"))     # host threads copying decoded frames into the pinned ring
+
+
 def streaming_leg(variant, device, batch=128, people=4, batches=20):
     """BASELINE.json config #5 shape on this GPU (was tools/bench_video.py): synthetic 1080p uint8 frames cross PCIe
     once each (pinned ring filled by 4 staging threads, copy stream), `people` boxes per frame are cropped + normalised on the GPU into the
@@ -198,7 +201,7 @@ def streaming_leg(variant, device, batch=128, people=4, batches=20):
                       for s in rng.uniform(150, 600, people)])
 
     def one(i, buf):
-        slots = cs.upload_many([frames[(i * fpb + k) % len(frames)] for k in range(fpb)])      # staging copies on 4 threads
+        slots = cs.upload_many([frames[(i * fpb + k) % len(frames)] for k in range(fpb)], threads=STAGE_THREADS)
         return cs.run([(k, boxes) for k in slots], buf)
 
     for i in range(3):

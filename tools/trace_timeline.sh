@@ -1,3 +1,4 @@
+# kernel trace of bench.py at batch $B (default 16), graph and eager, analysed by tools/timeline.py -> gpurun_out/r3t/timeline_*.txt
 O=$GRAFT_REPO_ROOT/gpurun_out/r3t; mkdir -p $O
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
