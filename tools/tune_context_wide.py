@@ -3,7 +3,7 @@
 Re-picks the configuration of the <top_shapes> most expensive conv shapes inside the whole 4-lane forward, trying the
 <top_cands> best solo candidates each, and writes the merged table to <out.json> (and to poco_amd/tuned/gfx950.json)."""
 import json, sys
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, str(__import__('pathlib').Path(__file__).resolve().parent.parent))
 from pathlib import Path
 from poco_amd import tune
 v, B = sys.argv[1], int(sys.argv[2])
