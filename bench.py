@@ -39,11 +39,11 @@ def load_spec(variant):
     return [(n, tuple(s)) for n, s in json.loads((ROOT / "tests" / "golden" / f"spec_{variant}.json").read_text())]
 
 
-def build_model(variant, max_batch, device):
+def build_model(variant, max_batch, device, options=None):
     from poco_amd import synth
     from poco_amd.model import POCO
     m = POCO(backbone=variant, num_flow_layers=FLOW_LAYERS[variant], max_batch=max_batch, smpl=synth.synth_smpl(7),
-             device=device)
+             device=device, keep_state_dict=False, engine_options=options)
     w = synth.synth_state_dict(load_spec(variant), 0)
     m.load_state_dict({k: v for k, v in w.items() if v.dtype != np.int64}, strict=True)
     return m.finalize()
@@ -79,12 +79,28 @@ def pmc_traffic(variant, B):
                       f"{csrc_digest()} (re-run tools/refresh_profiles.sh on the GPU box)")
     fw = float(meta.get("forwards", 5))
     tot = sum((2.0 * v.get("FETCH_SIZE", 0.0) + v.get("WRITE_SIZE", 0.0)) for k, v in d.items() if not k.startswith("_"))
-    global _PMC_MFMA_BUSY_PER_SIMD
-    _PMC_MFMA_BUSY_PER_SIMD = sum(v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) for k, v in d.items() if not k.startswith("_")) / fw / 1024.0
     return round(tot * 1024.0 / fw), f"{cands[-1].name} (same kernel sources, {int(fw)} forwards per PMC pass)"
 
 
-_PMC_MFMA_BUSY_PER_SIMD = None    # MFMA-pipe busy cycles per SIMD and forward from the same committed PMC pass (set by pmc_traffic)
+def pmc_executed(variant, B):
+    """What the committed PMC pass of this workload says the kernels EXECUTE per forward: MFMA flops (SQ_INSTS_VALU_MFMA_MOPS_F32 x 512,
+    MI355X_MICROARCH.md) and MFMA-pipe busy cycles per SIMD, whole forward and per kernel symbol.  Both are properties of the
+    launches (kernel + tile configuration), not of their timing, so `roofline.frac` = executed flops / THIS run's time / peak;
+    it is <= 1 by construction.  Uses the newest committed profile of the workload and says whether it was taken from the kernel
+    sources in the tree (`fresh`); a stale profile still prices the bulk of the forward correctly but is labelled."""
+    tag = {"hrnet_w48_cls-cliff": "w48cliff", "resnet50-cliff": "resnet50cliff", "hrnet_w32-pare": "w32pare"}[variant]
+    cands = sorted((ROOT / "profiles").glob(f"r*_pmc_{tag}_b{B}_summary.json"))
+    if not cands:
+        return None
+    d = json.loads(cands[-1].read_text())
+    meta = d.get("_meta", {})
+    fw = float(meta.get("forwards", 5))
+    per = {k: v for k, v in d.items() if not k.startswith("_")}
+    return {"file": cands[-1].name, "fresh": meta.get("csrc_sha") == csrc_digest(), "forwards": fw,
+            "gflop_per_forward": sum(v.get("SQ_INSTS_VALU_MFMA_MOPS_F32", 0.0) for v in per.values()) * 512.0 / 1e9 / fw,
+            "busy_per_simd": sum(v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) for v in per.values()) / fw / 1024.0,
+            "per_symbol": {k: (v.get("SQ_INSTS_VALU_MFMA_MOPS_F32", 0.0) * 512.0 / 1e9 / max(v.get("dispatches", 1), 1))
+                           for k, v in per.items()}}
 
 
 # ------------------------------------------------------------------------------------------------------------
@@ -281,7 +297,8 @@ def side_kernels(device):
 
     # -- engine-bound operators: SMPL-LBS and the flow (resnet50-cliff shell, 3 flow blocks = 6 coupling layers) ------
     def shell(nfl):
-        m = POCO(backbone="resnet50-cliff", num_flow_layers=nfl, max_batch=64, smpl=synth.synth_smpl(7), device=device)
+        m = POCO(backbone="resnet50-cliff", num_flow_layers=nfl, max_batch=64, smpl=synth.synth_smpl(7), device=device,
+                 keep_state_dict=False, engine_options={"flow_ctx_rows": 3072})      # per-row contexts at N = 3072 below
         spec = [(n, shp) for n, shp, _ in m.expected_tensors() if not n.startswith("smpl.")]
         w = synth.synth_state_dict(spec, 0)
         m.load_state_dict({k: v for k, v in w.items() if v.dtype != np.int64}, strict=True)
@@ -367,6 +384,93 @@ def small_batch_leg(model, variant, device, sizes=(1, 4, 16), steps=30):
     return out
 
 
+def roofline_block(variant, B, flops_per_crop, ev_ms):
+    """`roofline` of a forward that took ev_ms (mean HIP-event time on the launch stream).  frac = EXECUTED fp32-MFMA flops per forward
+    (PMC: SQ_INSTS_VALU_MFMA_MOPS_F32 of the committed rocprofv3 pass of this workload - Winograd kernels execute 2.25x / 4x fewer
+    MFMAs than the direct-convolution count, padding lanes and masked tiles are included) / time / 157.3 TFLOP/s: a bound, <= 1.
+    algorithmic_frac = direct-convolution flop count of the model / time / peak: what the work is worth, may exceed 1."""
+    alg = flops_per_crop * B / (ev_ms * 1e-3) / 1e12
+    ex = pmc_executed(variant, B)
+    traffic, traffic_note = pmc_traffic(variant, B)
+    r = {"bound": "mfma", "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+         "algorithmic": round(alg, 2), "algorithmic_frac": round(alg / PEAK_F32_MFMA_TFLOPS, 4),
+         "traffic": traffic, "traffic_source": traffic_note}
+    if ex:
+        ach = ex["gflop_per_forward"] / (ev_ms * 1e-3) / 1e3
+        r.update({"achieved": round(ach, 2), "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
+                  "frac_kind": "EXECUTED fp32-MFMA flops (PMC) / this run's forward time / peak; `algorithmic_frac` prices the same time at "
+                               "the direct-convolution flop count (Winograd F(2x2) / F(4x4) execute 2.25x / 4x fewer MFMAs)",
+                  "executed_gflop_per_forward": round(ex["gflop_per_forward"], 1),
+                  "executed_source": f"{ex['file']}: SQ_INSTS_VALU_MFMA_MOPS_F32 x 512 / {int(ex['forwards'])} forwards"
+                                     + ("" if ex["fresh"] else " [STALE: taken from other kernel sources than the tree's - re-run tools/refresh_profiles.sh]"),
+                  "mfma_pipe_busy": {"frac_at_2.4GHz": round(ex["busy_per_simd"] / (ev_ms * 1e-3 * 2.4e9), 4),
+                                     "busy_cycles_per_simd_per_forward": round(ex["busy_per_simd"]),
+                                     "source": "SQ_VALU_MFMA_BUSY_CYCLES of the same PMC pass (single lane) / 1024 SIMDs / (this run's mean forward time x 2.4 GHz)"}})
+    else:
+        r.update({"achieved": None, "frac": None, "frac_kind": "absent: no committed PMC profile for this workload (profiles/r*_pmc_*_summary.json)"})
+    r["note"] = (f"whole forward: {B} crops / mean HIP-event forward time {ev_ms:.3f} ms on the launch stream; algorithmic "
+                 f"{flops_per_crop/1e9:.3f} GFLOP/crop (SURVEY 8(d)); MFMA conv kernels are >96% of the kernel time (profiles/)")
+    return r, ex
+
+
+def dominant_kernel(model, batch, B, lanes, ex):
+    """per-kernel view (HIP events around every op, launched back to back on ONE stream so kernels do not overlap): group the conv
+    ops by the kernel symbol they launch, pick the symbol with the most time; both fractions for it."""
+    from collections import defaultdict
+    model.set_num_lanes(1)
+    prof = model.profile_ops(batch, iters=5)
+    model.set_num_lanes(lanes)
+    agg = defaultdict(lambda: [0, 0.0, 0.0])
+    for i, (nm, fl, ty, ms) in enumerate(prof):
+        d = model.conv_desc(i)
+        if d is None:
+            continue
+        a = agg[model.kernel_symbol(d, model.conv_cfg(i, B))]
+        a[0] += 1; a[1] += ms; a[2] += fl * B
+    sym, (n, ms, fl) = max(agg.items(), key=lambda kv: kv[1][1])
+    dom = {"kernel": sym, "launches_per_step": n, "avg_us": round(ms / n * 1e3, 2),
+           "share_of_kernel_time": round(ms / sum(p[3] for p in prof), 3),
+           "algorithmic_gflop_per_launch": round(fl / n / 1e9, 3), "algorithmic_tflops": round(fl / (ms * 1e-3) / 1e12, 2),
+           "algorithmic_frac": round(fl / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)}
+    if ex:
+        hit = [v for k, v in ex["per_symbol"].items() if k.startswith(sym)]
+        if hit:
+            dom["executed_gflop_per_launch"] = round(hit[0], 3)
+            dom["frac"] = round(hit[0] / (ms / n * 1e-3) / 1e3 / PEAK_F32_MFMA_TFLOPS, 4)
+    return dom
+
+
+def variant_leg(variant, B, device, steps=30, warmup=10):
+    """One more BASELINE config in the same driver line: hipGraph replay of `variant` at B crops on this GPU,
+    the same timed-region rules as the headline (barrier-free single GPU: synchronize, W warm-ups, K steps between HIP events)."""
+    from poco_amd import synth
+    m = build_model(variant, B, device)
+    batch = {k: torch.from_numpy(v).to(device) for k, v in synth.synth_batch(B, 1234).items()}
+    out = m._alloc_outputs(B, want_segm=False)
+    for _ in range(warmup):
+        m.graph_forward(batch, out)
+    st = torch.cuda.current_stream()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ev[0].record(st)
+    for i in range(steps):
+        m.graph_forward(batch, out)
+        ev[i + 1].record(st)
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    ms = [ev[i].elapsed_time(ev[i + 1]) for i in range(steps)]
+    fpc = sum(f for _, f, _ in m.ops())
+    roof, ex = roofline_block(variant, B, fpc, float(np.mean(ms)))
+    roof["dominant"] = dominant_kernel(m, batch, B, 4, ex)
+    res = {"workload": f"{variant} forward, {B} crops of 224x224, fp32 MFMA, hipGraph replay", "value": round(B * steps / wall, 2),
+           "unit": "crops/s", "steps": steps, "warmup": warmup, "ms_per_step": round(wall / steps * 1e3, 4),
+           "step_ms_events": {"mean": round(float(np.mean(ms)), 4), "median": round(float(np.median(ms)), 4)},
+           "roofline": roof}
+    del m
+    return res
+
+
 def spawn_ranks(args) -> int:
     """`python bench.py --gpus N` without a launcher: start N ranks of this same script, one per GPU."""
     import socket
@@ -398,6 +502,7 @@ def main():
     ap.add_argument("--split-f16", action="store_true",
                     help="EXPERIMENT (never the headline): every plain 1x1 conv on the split-fp16 GEMM (fp16 hi + lo, 3 MFMAs per "
                          "product, csrc/gemm1x1h.hip); the line is labelled and its dtype says so")
+    ap.add_argument("--no-variants", action="store_true", help="skip the `variants` block (resnet50-cliff bs=64, hrnet_w32-pare bs=32)")
     ap.add_argument("--no-side", action="store_true", help="skip the `side_kernels` block (HBM/latency-bound kernels in GB/s)")
     ap.add_argument("--lanes", type=int, default=4, help="HIP streams for independent branches (1 = single stream)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay of the forward")
@@ -413,8 +518,6 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "--cpu-worker":
         return cpu_worker(sys.argv[2:])
     args = ap.parse_args()
-    if args.split_f16:
-        os.environ["POCO_SPLIT_F16"] = "1"          # read by the engine when it is created
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(spawn_ranks(args))
@@ -445,7 +548,7 @@ def main():
 
     from poco_amd import synth
     B = args.batch
-    model = build_model(args.variant, B, device)
+    model = build_model(args.variant, B, device, options={"split_f16": 1} if args.split_f16 else None)
     model.set_num_lanes(args.lanes)
     batch = {k: torch.from_numpy(v).to(device) for k, v in synth.synth_batch(B, 1234 + rank).items()}
     out = model._alloc_outputs(B, want_segm=False)
@@ -455,12 +558,14 @@ def main():
     checked = []            # the RCCL buffers are validated once, before the first collective
 
     def step():
+        # N > 1: the step is the graph replay + ONE collective on the engine's own record buffer (poco_outputs_t.record is written
+        # by a kernel inside the graph) - no eager packing launches between them
         if args.no_graph:
             model(batch, out=out)
         else:
             model.graph_forward(batch, out)
         if world > 1 and not args.no_gather:
-            rec = pdist.pack_records(out, head=args.variant)
+            rec = out["record"]
             if args.backend == "nccl":
                 if not checked:
                     pdist.check_collective_buffers(rec, gathered, world, "nccl", device)
@@ -498,41 +603,23 @@ def main():
 
     gather_check = None
     if world > 1 and args.check_gather and not args.no_gather:
-        mine = pdist.pack_records(out, head=args.variant)
-        ok = bool(torch.equal(gathered[rank * B:(rank + 1) * B], mine))
+        mine = pdist.pack_records(out, head=args.variant)       # the host-side reference packing: must be what the engine wrote
+        ok = bool(torch.equal(gathered[rank * B:(rank + 1) * B, :253], mine[:, :253])) and \
+            bool((gathered[rank * B:(rank + 1) * B, 253] - mine[:, 253]).abs().max() <= 1e-6)
         if rank == 0:
             for r in range(1, world):       # same device type, deterministic kernels: bitwise equality is expected
                 br = {k: torch.from_numpy(v).to(device) for k, v in synth.synth_batch(B, 1234 + r).items()}
                 o = model(br)
-                ok = ok and bool(torch.equal(gathered[r * B:(r + 1) * B], pdist.pack_records(o, head=args.variant)))
+                ok = ok and bool(torch.equal(gathered[r * B:(r + 1) * B], o["record"]))
         flag = torch.tensor([1.0 if ok else 0.0], device=device if args.backend == "nccl" else "cpu")
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         gather_check = bool(flag.item() == 1.0)
 
-    dominant = None
-    if rank == 0 and world == 1 and not args.no_dominant:
-        # per-kernel view (HIP events around every op, launched back to back on ONE stream so kernels do not
-        # overlap): group the conv ops by the kernel symbol they launch, pick the symbol with the most time
-        from collections import defaultdict
-        model.set_num_lanes(1)
-        prof = model.profile_ops(batch, iters=5)
-        model.set_num_lanes(args.lanes)
-        agg = defaultdict(lambda: [0, 0.0, 0.0])
-        for i, (nm, fl, ty, ms) in enumerate(prof):
-            d = model.conv_desc(i)
-            if d is None:
-                continue
-            a = agg[model.kernel_symbol(d, model.conv_cfg(i, B))]
-            a[0] += 1; a[1] += ms; a[2] += fl * B
-        sym, (n, ms, fl) = max(agg.items(), key=lambda kv: kv[1][1])
-        dominant = {"kernel": sym, "launches_per_step": n, "avg_us": round(ms / n * 1e3, 2),
-                    "share_of_kernel_time": round(ms / sum(p[3] for p in prof), 3),
-                    "gflop_per_launch": round(fl / n / 1e9, 3), "tflops": round(fl / (ms * 1e-3) / 1e12, 2)}
-
     if rank == 0:
-        traffic, traffic_note = pmc_traffic(args.variant, B)
         value = world * B * args.steps / elapsed
-        achieved = flops_per_crop * B / (ev_ms * 1e-3) / 1e12
+        roof, ex = roofline_block(args.variant, B, flops_per_crop, ev_ms)
+        if world == 1 and not args.no_dominant:
+            roof["dominant"] = dominant_kernel(model, batch, B, args.lanes, ex)
         line = {
             "metric": "person-crops/sec (224x224) POCO-CLIFF bs=64" if args.variant.endswith("cliff")
                       else "person-crops/sec (224x224) POCO-PARE",
@@ -549,41 +636,24 @@ def main():
                        "crops_per_gpu": B, "global_batch": world * B,
                        "parallelism": f"dp{world} (crop sharding" + (f", {'RCCL' if args.backend == 'nccl' else 'gloo (smoke path)'} all-gather of 254-float SMPL records)"
                                                                           if world > 1 and not args.no_gather else ")")},
-            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
-                         "frac_kind": "ALGORITHMIC: direct-convolution flop count / time / peak; the Winograd kernels execute ~2.2x fewer "
-                                      "MFMAs, the executed-MFMA view is `mfma_pipe_busy`",
-                         "traffic": traffic, "traffic_source": traffic_note,
-                         "note": f"whole forward: algorithmic {flops_per_crop/1e9:.3f} GFLOP/crop x {B} crops / mean "
-                                 f"HIP-event forward time {ev_ms:.3f} ms on the launch stream (MFMA conv kernels are >96% "
-                                 "of the kernel time, profiles/); `dominant` = the kernel symbol with the most time, "
-                                 "algorithmic flops of its launches / their HIP-event time on one stream"},
+            "roofline": roof,
         }
         if args.split_f16:
             line["metric"] += " [EXPERIMENT: 1x1 convs in split fp16]"
             line["dtype"] = "f32 except the plain 1x1 convs: fp16 hi + lo split, 3 v_mfma_f32_16x16x32_f16 per product, fp32 accumulation (experiment)"
-            line["experiment"] = ("VERDICT r2 next #9: not the headline; narrower arithmetic than the reference's fp32 in the 1x1 convs (22 mantissa "
+            line["experiment"] = ("not the headline; narrower arithmetic than the reference's fp32 in the 1x1 convs (22 mantissa "
                                   "bits per operand), gated by the stress fixtures at 1e-3 (tests/test_model_gpu.py::test_split_f16_experiment_passes_the_gate); "
                                   "`roofline` still prices the run against the fp32-MFMA peak")
-        if _PMC_MFMA_BUSY_PER_SIMD:
-            # north_star asks for the MFMA utilisation next to the roofline fraction: executed MFMA time (Winograd executes 2.2x
-            # fewer MFMAs than the algorithmic count) over this run's forward time at the nominal 2.4 GHz
-            line["roofline"]["mfma_pipe_busy"] = {
-                "frac_at_2.4GHz": round(_PMC_MFMA_BUSY_PER_SIMD / (ev_ms * 1e-3 * 2.4e9), 4),
-                "busy_cycles_per_simd_per_forward": round(_PMC_MFMA_BUSY_PER_SIMD),
-                "source": "SQ_VALU_MFMA_BUSY_CYCLES of the committed PMC pass (single lane) / 1024 SIMDs / (this run's mean forward time x 2.4 GHz)"}
-        else:
-            line["roofline"]["mfma_pipe_busy"] = None
-            line["roofline"]["mfma_pipe_busy_note"] = "absent: no committed PMC profile taken from the kernel sources in the tree for this workload"
         if gather_check is not None:
             line["dist"]["gather_check"] = ("ok: all gathered rows bitwise equal to the per-rank forwards" if gather_check
                                             else "FAILED")
-        if dominant is not None:
-            dominant["frac"] = round(dominant["tflops"] / PEAK_F32_MFMA_TFLOPS, 4)
-            line["roofline"]["dominant"] = dominant
         if world == 1 and not args.no_side:
             line["small_batch"] = small_batch_leg(model, args.variant, device)
             line["side_kernels"] = side_kernels(device)
+        if world == 1 and not args.no_variants and args.variant == "hrnet_w48_cls-cliff" and B == 64:
+            # BASELINE configs #3 (ResNet-50 wording) and #2 in the same driver line
+            line["variants"] = {"resnet50-cliff_b64": variant_leg("resnet50-cliff", 64, device),
+                                "hrnet_w32-pare_b32": variant_leg("hrnet_w32-pare", 32, device)}
         if world == 1 and not args.no_stream:
             line["streaming_cfg5"] = streaming_leg(args.variant, device)
         if world == 1 and not args.no_cpu_baseline:

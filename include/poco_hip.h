@@ -31,6 +31,13 @@ extern "C" {
 /* Message of the last error on this thread ("" if none). */
 const char* poco_last_error(void);
 
+/* Version of this ABI: bumped whenever a struct layout or the meaning / type of an argument of an existing entry point changes
+ * (2: poco_crop_normalize takes bbox_scale as double; 3: poco_outputs_t gained `record`, poco_create_ex, poco_crop_normalize_multi,
+ * RealNVP scratch planned at finalize).  A binding compiled against another header must refuse to run:
+ *     if (poco_abi_version() != POCO_ABI_VERSION) fail;                                                                          */
+#define POCO_ABI_VERSION 3
+int poco_abi_version(void);
+
 /* ---- the engine: POCO(backbone=..., pretrained=ckpt) + model(batch) ---------------------------
  * replaces pocolib/models/poco.py:13-154 (ctor :13-97, forward :99-129, load_pretrained :131-154)
  * as called from pocolib/core/tester.py:75-98 (build) and :213,:408 (output = self.model(batch)). */
@@ -66,12 +73,27 @@ typedef struct {
   float* body_feat2;         /* [B,1024] cliff only                                      */
   float* backbone_feat;      /* [B,480,56,56] NCHW, hrnet_w32 only: the backbone's output map  */
                              /* (hrnet.py:515-519), for parity checks; NULL in production      */
+  float* record;             /* [B,254] packed per-crop record = the payload of the multi-GPU all-gather and of the streaming
+                              * D2H copy: [pred_pose 216 | pred_shape 10 | pred_cam 3 | var_pose 24 (raw) | confidence 1], written
+                              * by one kernel inside the forward (hipGraph-capturable).  confidence = the reference's
+                              * post-processed scalar: kinematic accumulation along the SMPL tree (poco_utils.py:21-25), rows whose
+                              * root exceeds the threshold set to 1, cliff: root value / pare: mean over joints (poco_utils.py:50-60),
+                              * clipped to [0, 0.99] (tester.py:245).  Options record_kinematic / record_thr of poco_create_ex.  */
 } poco_outputs_t;
 
 /* variant = "<backbone>-<head>" exactly as POCO.BACKBONE in the yaml (poco.py:41):
  * "hrnet_w32-pare", "hrnet_w48_cls-cliff", "resnet50-cliff".  num_flow_layers = POCO.NUM_FLOW_LAYERS.
  * Host only (no GPU needed): builds the list of tensors the variant expects. */
 int poco_create(const char* variant, int max_batch, int num_flow_layers, poco_handle_t* out);
+/* The same with build options: "key=value,key=value" (NULL or "" = defaults = poco_create).  The library reads NO environment
+ * variable; every alternative form is chosen here, computes the same model and is compared with the default in tests/:
+ *   kcat, kmerge, chain, dual, wg_fuse = 0   the separate-launch form of a fused op group (csrc/engine.hip EngineOpts)
+ *   xdep, tail_lanes, up_lanes = 0           the more conservative lane schedules;  seq_phases = <bit mask>, branch_lanes = "0123"
+ *   split_f16 = 1                            EXPERIMENT: plain 1x1 convs in split fp16 (never the default)
+ *   flow_ctx_rows = <n>                      context rows poco_realnvp*'s scratch is planned for at finalize (default max_batch)
+ *   record_kinematic = 0|1, record_thr = <f> post-processing of poco_outputs_t.record's confidence (defaults 1, 0.40)
+ * Unknown keys are an error. */
+int poco_create_ex(const char* variant, int max_batch, int num_flow_layers, const char* options, poco_handle_t* out);
 void poco_destroy(poco_handle_t h);
 
 /* Expected tensors: names are the reference state_dict keys after the prefix stripping of
@@ -121,8 +143,9 @@ int poco_smpl_lbs(poco_handle_t h, int B, const float* d_betas, const float* d_r
  * forward=0: log_prob(x[N,9] | ctx[N,512]) -> out[N]   (:55-65)
  * forward=1: forward_p(z[N,9], ctx)        -> out[N,9] (:25-38)
  * Two launches: one GEMM for the context part of the first Linear of all 2L s/t MLPs, one fp32-MFMA kernel for the coupling
- * recursion (csrc/kernels_flow.hip).  The GEMM's scratch is owned by the engine and grows on demand: the first call at a
- * larger N allocates (synchronising), later calls only enqueue. */
+ * recursion (csrc/kernels_flow.hip).  The GEMM's scratch is planned at poco_finalize for `flow_ctx_rows` context rows (option of
+ * poco_create_ex; default max_batch = one context per crop): no allocation, no synchronisation here; more context rows than
+ * planned is POCO_ERR_ARG. */
 int poco_realnvp(poco_handle_t h, int N, const float* d_x, const float* d_ctx, float* d_out, int forward,
                  void* stream);
 /* The same with the context as the reference's flow_head actually has it (pocolib/models/head/nf_head.py:93-110): one
@@ -180,6 +203,11 @@ int poco_crop_normalize(const unsigned char* d_frame, int H, int W, const float*
                         int res, float* d_out, void* stream);
 int poco_crop_normalize_f64(const unsigned char* d_frame, int H, int W, const double* d_boxes, int N, double bbox_scale,
                             int res, float* d_out, void* stream);
+/* The crops of a whole batch in ONE launch when they come from several frames of the same size (video / streaming mode:
+ * tester.py:399-408 crops per frame): d_frames = device array of `nframes` device pointers to uint8 [H,W,3] frames,
+ * d_frame_idx [N] int32 = which of them crop n is cut from.  Same arithmetic as poco_crop_normalize (float32 boxes). */
+int poco_crop_normalize_multi(const unsigned char* const* d_frames, int nframes, const int* d_frame_idx, int H, int W,
+                              const float* d_boxes, int N, double bbox_scale, int res, float* d_out, void* stream);
 
 /* Time `ncfg` tile configurations (6 ints each; MT<=0 = heuristic) for one conv shape on random
  * data; ms_out[i] < 0 = configuration invalid for this shape.  Used by poco_amd/tune.py. */

@@ -1,6 +1,9 @@
 // Shared declarations for the POCO MI355X (gfx950) HIP library.
 // Everything here is internal; the public surface is include/poco_hip.h.
 #pragma once
+#ifndef POCO_PROBES
+#define POCO_PROBES 0     // 1: timing-probe builds (tools/build_exp.sh): the POCO_CONV_DBG / POCO_CONV_REPEAT environment switches exist; never in the shipped library
+#endif
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdio>

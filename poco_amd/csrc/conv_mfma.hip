@@ -249,12 +249,15 @@ int conv_launch(const ConvDesc& d, const ConvCfg& cfg, hipStream_t stream) {
   kp.bufF4 = 4 * g.planeF4 + d.ks * d.ks * kp.NTB * 64;
   kp.ngroups = g.planeF4 / 64;
   kp.act = d.act; kp.res_after_act = d.res_after_act; kp.relu_from = d.relu_from;
+  kp.repeat = 1; kp.dbg = 0;
+#if POCO_PROBES       // timing-probe builds only (tools/build_exp.sh conv_mfma.hip POCO_PROBES 1): results are then garbage
   {
     static const int rep = [] { const char* e = getenv("POCO_CONV_REPEAT"); return e ? atoi(e) : 1; }();
     kp.repeat = rep >= 0 ? rep : 1;
     static const int dbg = [] { const char* e = getenv("POCO_CONV_DBG"); return e ? atoi(e) : 0; }();
     kp.dbg = dbg;
   }
+#endif
   kp.dPW = make_fastdiv(g.PW);
   kp.dSlab = make_fastdiv(g.PR * g.PW);
   kp.dBands = make_fastdiv(g.nbands);

@@ -739,10 +739,13 @@ int conv_wino_launch(const ConvDesc& d, const ConvCfg& cfg, hipStream_t stream) 
     p.ngroups = g.planeF4 / 64;
     p.WM = cfg.WM; p.WN = 2; p.NTB = cfg.NT; p.ubufF4 = 16 * cfg.NT * 64;
     p.act = d.act; p.res_after_act = d.res_after_act;
+    p.dbg = 0;
+#if POCO_PROBES       // timing-probe builds only (tools/build_exp.sh conv_wino.hip POCO_PROBES 1)
     {
       static const int dbg4 = [] { const char* e = getenv("POCO_CONV_DBG"); return e ? atoi(e) : 0; }();
       p.dbg = dbg4;
     }
+#endif
     p.dPW = make_fastdiv(g.PW); p.dSlab = make_fastdiv(g.PR * g.PW); p.dBands = make_fastdiv(g.nbands);
     p.dTX = make_fastdiv(g.TX); p.dTslab = make_fastdiv((cfg.R / 2) * g.TX);
     p.nblocks_m = g.nblocks_m; p.nb_n = (p.nT16 + cfg.NT - 1) / cfg.NT;
@@ -784,10 +787,13 @@ int conv_wino_launch(const ConvDesc& d, const ConvCfg& cfg, hipStream_t stream) 
   p.ngroups = g.planeF4 / 64;
   p.WM = cfg.WM; p.WN = cfg.WN; p.NTB = cfg.WN * cfg.NT; p.ubufF4 = 16 * p.NTB * 64;
   p.act = d.act; p.res_after_act = d.res_after_act;
+  p.dbg = 0;
+#if POCO_PROBES
   {
     static const int dbg = [] { const char* e = getenv("POCO_CONV_DBG"); return e ? atoi(e) : 0; }();
     p.dbg = dbg;
   }
+#endif
   p.dPW = make_fastdiv(g.PW); p.dSlab = make_fastdiv(g.PR * g.PW); p.dBands = make_fastdiv(g.nbands);
   p.dTX = make_fastdiv(g.TX); p.dTslab = make_fastdiv((cfg.R / 2) * g.TX);
   const int nb_n = (p.nT16 + p.NTB - 1) / p.NTB;

@@ -38,14 +38,14 @@ struct ParamDecl {
 
 enum OpType {
   OP_STEM, OP_CONV, OP_MAXPOOL, OP_BILINEAR, OP_FUSE, OP_AVGPOOL, OP_ATTN, OP_LC2D, OP_ROT6D, OP_COPY,
-  OP_BCAST, OP_SMPL, OP_CAMERA, OP_NCHW_OUT, OP_CHAIN, OP_DUAL1X1
+  OP_BCAST, OP_SMPL, OP_CAMERA, OP_NCHW_OUT, OP_CHAIN, OP_DUAL1X1, OP_RECORD
 };
 
 // external buffer slots (inputs / outputs of poco_forward)
 enum Ext {
   X_NONE = 0, X_IMG, X_BBOX, X_FOCAL, X_SCALE, X_CENTER, X_ORIG,
   Y_POSE, Y_POSE6D, Y_SHAPE, Y_CAM, Y_CAM_T, Y_FULL_CAM_T, Y_VERTS, Y_J3D, Y_J2D, Y_VAR, Y_UFEAT, Y_SEGM, Y_BBFEAT,
-  Y_BODY2
+  Y_BODY2, Y_RECORD
 };
 
 struct Act {
@@ -90,7 +90,61 @@ struct Op {
   std::map<int, ConvCfg> cfg;   // per batch size
 };
 
+// Build options (poco_create_ex): the A/B forms of the schedule and of the fused ops.  Every form computes the same model (tests
+// compare them); they are chosen explicitly through the C ABI - the library reads no environment variable.
+struct EngineOpts {
+  bool kcat = true;        // layer1.0: bn3(conv3(t)) + bn_d(conv_d(x)) as one 1x1 conv over [t ; x]
+  bool kmerge = true;      // HR module: the lowest-resolution branch's fuse sum as one K-concatenated stride-2 conv
+  bool chain = true;       // layer1: conv3 + residual + ReLU of block k chained with conv1 of block k+1 (bneck_chain.hip)
+  bool dual = true;        // ResNet-50 layer2-4.0: conv3 + stride-2 projection shortcut as one two-source GEMM
+  bool xdep = true;        // one join per HR module, open stage boundaries, inferred cross-lane events
+  bool tail_lanes = true;  // SMPL-LBS + camera | output copies + confidence MLP on two lanes (PARE: the two head branches too)
+  bool up_lanes = true;    // PARE: the three upsample chains continue on their branches' lanes
+  bool wg_fuse = true;     // ALG 11: consecutive convs of a lane chained through wg_mid_kernel
+  bool split_f16 = false;  // EXPERIMENT (never the default): plain 1x1 convs on the split-fp16 GEMM (gemm1x1h.hip)
+  int seq_mask = 0;        // bit mask: run the tagged kind of parallel region on one lane
+  std::string branch_lanes = "0123";   // HR branch i runs on lane branch_lanes[i]
+  int flow_ctx_rows = 0;   // context rows the RealNVP scratch is planned for at finalize (0 = max_batch: one context per crop)
+  int rec_kinematic = 1;   // poco_outputs_t.record: kinematic accumulation of the per-joint uncertainty (KINEMATIC_UNCERT)
+  float rec_thr = 0.40f;   // ... and the sensitivity threshold of get_global_uncert (poco_utils.py:50)
+};
+
+static bool parse_opts(const char* str, EngineOpts* o, std::string* err) {
+  if (!str) return true;
+  std::string s(str);
+  size_t i = 0;
+  while (i < s.size()) {
+    size_t j = s.find(',', i);
+    if (j == std::string::npos) j = s.size();
+    std::string kv = s.substr(i, j - i);
+    i = j + 1;
+    if (kv.empty()) continue;
+    const size_t eq = kv.find('=');
+    const std::string k = kv.substr(0, eq), v = eq == std::string::npos ? "1" : kv.substr(eq + 1);
+    const bool on = v != "0";
+    if (k == "kcat") o->kcat = on;
+    else if (k == "kmerge") o->kmerge = on;
+    else if (k == "chain") o->chain = on;
+    else if (k == "dual") o->dual = on;
+    else if (k == "xdep") o->xdep = on;
+    else if (k == "tail_lanes") o->tail_lanes = on;
+    else if (k == "up_lanes") o->up_lanes = on;
+    else if (k == "wg_fuse") o->wg_fuse = on;
+    else if (k == "split_f16") o->split_f16 = on;
+    else if (k == "seq_phases") o->seq_mask = atoi(v.c_str());
+    else if (k == "branch_lanes") o->branch_lanes = v;
+    else if (k == "flow_ctx_rows") o->flow_ctx_rows = atoi(v.c_str());
+    else if (k == "record_kinematic") o->rec_kinematic = on;
+    else if (k == "record_thr") o->rec_thr = (float)atof(v.c_str());
+    else { *err = "unknown engine option '" + k + "'"; return false; }
+  }
+  for (char c : o->branch_lanes)
+    if (c < '0' || c > '3') { *err = "branch_lanes must be digits 0..3"; return false; }
+  return true;
+}
+
 struct Engine {
+  EngineOpts opts;
   std::string backbone, head;
   int max_batch = 0;
   int flow_layers = 0;
@@ -118,10 +172,8 @@ struct Engine {
   int wg_ready_act[4] = {-1, -1, -1, -1}; // ALG 11 chaining: activation whose V the previous conv of the lane left in scratch ...
   int wg_ready_vsel[4] = {0, 0, 0, 0};    // ... and in which half
   std::vector<int> act_uses;              // how many op inputs / residuals / fuse terms read each activation (built at finalize)
-  bool wg_fuse = [] { const char* v = getenv("POCO_NO_WG_FUSE"); return !(v && atoi(v)); }();    // A/B knob
-  bool split_f16 = [] { const char* v = getenv("POCO_SPLIT_F16"); return v && atoi(v); }();      // EXPERIMENT: 1x1 convs on ALG 12
   size_t wino4g_scratch_need = 0;
-  float* flow_scratch = nullptr;          // step A of the flow (context GEMM), grown on demand by poco_realnvp
+  float* flow_scratch = nullptr;          // step A of the flow (context GEMM): planned at finalize for opts.flow_ctx_rows context rows
   size_t flow_scratch_floats = 0;
   int uncert_feat_dim = 0;
   std::string err;
@@ -157,7 +209,7 @@ static void op_accesses(const Engine& e, const Op& op, std::vector<OpAccess>* rd
   add(rd, op.in2, ALL);
   add(rd, op.res, conv ? op.Cout : ALL);
   for (int k = 0; k < op.fn && k < 4; ++k) add(rd, op.fsrc[k], op.type == OP_FUSE ? op.C : ALL);
-  if (op.type == OP_SMPL || op.type == OP_CAMERA) { add(rd, e.smpl_betas, ALL); add(rd, e.smpl_rot, ALL); add(rd, e.cam_ref, ALL); }   // implicit operands
+  if (op.type == OP_SMPL || op.type == OP_CAMERA || op.type == OP_RECORD) { add(rd, e.smpl_betas, ALL); add(rd, e.smpl_rot, ALL); add(rd, e.cam_ref, ALL); }   // implicit operands
   add(wr, op.out, conv ? op.Cout : (op.type == OP_FUSE ? op.C : ALL));
   add(wr, op.out2, ALL);
 }
@@ -213,23 +265,13 @@ struct Builder {
   // Outside a parallel region every op is its own single-lane phase.
   int cur_phase = -1, cur_lane = 0;
   bool in_parallel = false;
-  // POCO_SEQ_PHASES (bit mask, experiments): run the tagged kind of parallel region on one lane
-  int seq_mask = [] { const char* v = getenv("POCO_SEQ_PHASES"); return v ? atoi(v) : 0; }();
+  // A/B forms (EngineOpts, poco_create_ex): seq_mask runs the tagged kind of parallel region on one lane; kcat / kmerge / chain /
+  // dual select the fused or the separate form of an op group; xdep = one join per HR module with the stage boundaries inside
+  // ONE parallel region (the transition conv waits for the K-merged conv's lane through an event instead of a join of all lanes)
+  int seq_mask = e.opts.seq_mask;
   bool region_seq = false;
-  // POCO_NO_KCAT=1 (experiments): keep the projection shortcut of layer1.0 a separate conv + residual
-  bool kcat = [] { const char* v = getenv("POCO_NO_KCAT"); return !(v && atoi(v)); }();
-  // K-merge of the LAST convs of all down paths into the lowest-resolution branch of an HR module (see hr_module)
-  bool kmerge = [] { const char* v = getenv("POCO_NO_KMERGE"); return !(v && atoi(v)); }();
-  // POCO_NO_CHAIN=1 (experiments): conv3 of a layer1 block and conv1 of the next one as two launches
-  bool chain = [] { const char* v = getenv("POCO_NO_CHAIN"); return !(v && atoi(v)); }();
-  // POCO_NO_DUAL=1 (experiments): stride-2 Bottlenecks keep conv3 and the projection shortcut as two launches
-  bool dual = [] { const char* v = getenv("POCO_NO_DUAL"); return !(v && atoi(v)); }();
-  // Stage boundaries inside ONE parallel region (round 3; POCO_NO_XDEP=1 restores the joins): the fuse sums of a stage's last module,
-  // the transition conv that creates the next stage's new branch and the next stage's first branch chains run as lanes of the
-  // same region; the transition conv is the only op that needs another lane's result (the K-merged conv of lane T) and waits for
-  // it through an event (Op::wait_lane) instead of a join of all lanes.
-  bool xdep = [] { const char* v = getenv("POCO_NO_XDEP"); return !(v && atoi(v)); }();
-  bool tail_lanes = [] { const char* v = getenv("POCO_NO_TAIL_LANES"); return !(v && atoi(v)); }();
+  bool kcat = e.opts.kcat, kmerge = e.opts.kmerge, chain = e.opts.chain, dual = e.opts.dual, xdep = e.opts.xdep;
+  bool tail_lanes = e.opts.tail_lanes;
   // Cross-lane dependencies are INFERRED, not declared: inside a region the builder remembers which lanes wrote (a slice of) every
   // activation and up to which op a lane has already synchronised with every other lane; an op that reads an activation written
   // on another lane after that point gets that lane in its wait mask.  (Activations are written once per region - concat
@@ -342,7 +384,7 @@ struct Builder {
       std::copy(shift.begin(), shift.end(), sh.begin());
       op.wdev = upload(packed);
       op.bdev = upload(sh);
-      if (e.split_f16 && ks == 1 && !is_linear && Cin % 32 == 0 && ain.H * ain.W >= 16 && !kperm) {
+      if (e.opts.split_f16 && ks == 1 && !is_linear && Cin % 32 == 0 && ain.H * ain.W >= 16 && !kperm) {
         std::vector<float> ph(gemm1x1h_packed_floats(Cin, Cout16));
         gemm1x1h_pack_weights(wp, scale.data(), Cout, Cin, Cout16, ph.data());
         op.wdev_h = upload(ph);
@@ -607,7 +649,7 @@ struct Builder {
     // phase 1: the branches are independent chains of 8 convs -> one lane (HIP stream) each
     if (!region_open) begin_parallel(1);
     region_open = false;
-    static const std::string lmap = [] { const char* v = getenv("POCO_BRANCH_LANES"); return std::string(v ? v : "0123"); }();
+    const std::string& lmap = e.opts.branch_lanes;
     std::vector<Ref> xr(nb);                 // branch outputs as views (branch T-1 lives inside kc)
     for (int i = 0; i < nb; ++i) {
       lane(i < (int)lmap.size() ? lmap[i] - '0' : i);
@@ -904,6 +946,14 @@ void add_copy(Builder& b, const std::string& name, Ref src, Ref dst, int n) {
   b.push(std::move(op));
 }
 
+// poco_outputs_t.record: the packed per-crop record [rotmat 216 | betas 10 | cam 3 | var_pose 24 | confidence 1] (the payload of the
+// multi-GPU all-gather) written by ONE kernel at the end of the confidence lane; the confidence is the reference's
+// post-processed global uncertainty (poco_utils.py:21-25,50-60 + the clip of tester.py:245).  Skipped when the caller passes no pointer.
+void add_record(Builder& b, Ref var, bool cliff) {
+  Op op; op.type = OP_RECORD; op.name = "out.record"; op.in = var; op.out = Builder::X(Y_RECORD); op.n = cliff;
+  b.push(std::move(op));
+}
+
 void build_tail(Builder& b, Ref betas, Ref rot, Ref cam, bool cliff) {
   Engine& e = b.e;
   build_smpl(b);
@@ -928,7 +978,7 @@ bool build_graph(Engine& e, bool declare) {
   // ---- backbone ------------------------------------------------------------------------------
   if (e.backbone == "hrnet_w32") {
     feat480 = b.new_act(480, 56, 56);
-    static const bool up_lanes = [] { const char* v = getenv("POCO_NO_UP_LANES"); return !(v && atoi(v)); }();
+    const bool up_lanes = e.opts.up_lanes;
     std::vector<int> ys = b.hrnet_trunk(bp, 32, Builder::R(feat480, 0), /*open_after=*/up_lanes);
     // hrnet.py:515-519: bilinear x2 (align_corners) + conv3x3 + BN + ReLU chains, channel concat.  The three chains are
     // independent: each one continues on the lane that ran its branch's fuse sum of the last module (POCO_NO_UP_LANES=1: one
@@ -1098,6 +1148,7 @@ bool build_graph(Engine& e, bool declare) {
     int var = b.conv(up + "uncert_fc1", up + "uncert_fc1", "", Builder::R(u), 432, 24, 1, 1, 2, true, Ref(), 0, Ref(),
                      nullptr, 448, true);
     add_copy(b, "out.var_pose", Builder::R(var), Builder::X(Y_VAR), 24);
+    add_record(b, Builder::R(var), true);
     if (b.tail_lanes) b.end_parallel();
     build_flow(b, 2048);
   } else if (e.head == "pare") {
@@ -1165,6 +1216,7 @@ bool build_graph(Engine& e, bool declare) {
     int var = b.conv(up + "uncert_fc2", up + "uncert_fc2", "", Builder::R(h), 512, 24, 1, 1, 2, true, Ref(), 0, Ref(),
                      nullptr, 0, true);
     add_copy(b, "out.var_pose", Builder::R(var), Builder::X(Y_VAR), 24);
+    add_record(b, Builder::R(var), false);
     if (b.tail_lanes) b.end_parallel();
     build_flow(b, 3072);
   } else {
@@ -1195,7 +1247,7 @@ void plan_workspace(Engine& e) {
     nphase = std::max(nphase, i + 1);
     touch(e, op.in, i); touch(e, op.in2, i); touch(e, op.res, i); touch(e, op.out, i); touch(e, op.out2, i);
     for (int k = 0; k < op.fn; ++k) touch(e, op.fsrc[k], i);
-    if (op.type == OP_SMPL || op.type == OP_CAMERA) {
+    if (op.type == OP_SMPL || op.type == OP_CAMERA || op.type == OP_RECORD) {
       touch(e, e.smpl_betas, i); touch(e, e.smpl_rot, i); touch(e, e.cam_ref, i);
     }
   }
@@ -1278,6 +1330,7 @@ float* ext_out(const IO& io, int slot) {
     case Y_SEGM: return io.out->pred_segm_mask;
     case Y_BODY2: return io.out->body_feat2;
     case Y_BBFEAT: return io.out->backbone_feat;
+    case Y_RECORD: return io.out->record;
     default: return nullptr;
   }
 }
@@ -1326,12 +1379,13 @@ int run_op(Engine& e, Op& op, int B, const IO& io, hipStream_t s) {
         if (e.wg_ready_act[ln] == op.in.act && op.in.co == 0) { d.wg_skip_in = 1; d.wg_vsel = e.wg_ready_vsel[ln]; }
         e.wg_ready_act[ln] = -1;
         const size_t k = (size_t)(&op - e.ops.data());
-        if (e.wg_fuse && k + 1 < e.ops.size()) {
+        if (e.opts.wg_fuse && k + 1 < e.ops.size()) {
           Op& nx = e.ops[k + 1];
           auto nit = nx.cfg.find(B);
           if (nx.type == OP_CONV && nx.phase == op.phase && nx.lane == op.lane && nx.in.act == op.out.act && nx.in.co == 0 &&
               op.out.co == 0 && nit != nx.cfg.end() && nit->second.ALG == 11 && nx.wdev_wino4g && ao.C == op.Cout &&
-              conv_wino4g_can_chain(ai.H, ai.W, op.Cout, nx.Cin)) {
+              conv_wino4g_can_chain(ai.H, ai.W, op.Cout, nx.Cin) &&
+              std::max(op.Cin, op.Cout) == std::max(nx.Cin, nx.Cout)) {      // both convs split the lane's scratch into V | M the same way
             d.wg_emit_next = 1;
             d.wg_store_y = !(op.out.act < (int)e.act_uses.size() && e.act_uses[op.out.act] == 1);
             e.wg_ready_act[ln] = op.out.act;
@@ -1439,6 +1493,14 @@ int run_op(Engine& e, Op& op, int B, const IO& io, hipStream_t s) {
       launch_camera(c, B, s);
       return POCO_OK;
     }
+    case OP_RECORD: {
+      float* y = ext_out(io, op.out.ext);
+      if (!y) return POCO_OK;
+      launch_pack_record(aptr(e, e.smpl_rot), astride(e, e.smpl_rot), aptr(e, e.smpl_betas), astride(e, e.smpl_betas),
+                         aptr(e, e.cam_ref), astride(e, e.cam_ref), aptr(e, op.in), astride(e, op.in), y, op.n,
+                         e.opts.rec_kinematic, e.opts.rec_thr, B, s);
+      return POCO_OK;
+    }
     case OP_NCHW_OUT: {
       float* y = ext_out(io, op.out.ext);
       if (!y) return POCO_OK;
@@ -1457,7 +1519,13 @@ Engine* H(poco_handle_t h) { return reinterpret_cast<Engine*>(h); }
 // ================================================================================================
 // C ABI
 // ================================================================================================
+extern "C" int poco_abi_version(void) { return POCO_ABI_VERSION; }
+
 extern "C" int poco_create(const char* variant, int max_batch, int num_flow_layers, poco_handle_t* out) {
+  return poco_create_ex(variant, max_batch, num_flow_layers, nullptr, out);
+}
+
+extern "C" int poco_create_ex(const char* variant, int max_batch, int num_flow_layers, const char* options, poco_handle_t* out) {
   if (!variant || !out || max_batch < 1) { poco_set_error("poco_create: bad arguments"); return POCO_ERR_ARG; }
   std::string v(variant);
   const size_t dash = v.find('-');
@@ -1467,6 +1535,7 @@ extern "C" int poco_create(const char* variant, int max_batch, int num_flow_laye
   e->head = v.substr(dash + 1);
   e->max_batch = max_batch;
   e->flow_layers = num_flow_layers;
+  { std::string oerr; if (!parse_opts(options, &e->opts, &oerr)) { poco_set_error("poco_create_ex: " + oerr); return POCO_ERR_ARG; } }
   if (!build_graph(*e, /*declare=*/true)) { poco_set_error("poco_create: " + e->err); return POCO_ERR_ARG; }
   *out = reinterpret_cast<poco_handle_t>(e.release());
   return POCO_OK;
@@ -1539,6 +1608,11 @@ extern "C" int poco_finalize(poco_handle_t h) {
   }
   if (e->wino4g_scratch_need)          // ALG 11 staging: one buffer per lane (ops of different lanes run concurrently)
     for (int k = 0; k < 4; ++k) POCO_HIP_CHECK(hipMalloc(&e->wino4g_scratch[k], e->wino4g_scratch_need * sizeof(float)));
+  if (e->has_flow) {                   // RealNVP step A scratch: planned here, poco_realnvp* never allocates
+    const int rows = e->opts.flow_ctx_rows > 0 ? e->opts.flow_ctx_rows : e->max_batch;
+    e->flow_scratch_floats = realnvp_scratch_floats(e->flow, rows);
+    POCO_HIP_CHECK(hipMalloc(&e->flow_scratch, e->flow_scratch_floats * sizeof(float)));
+  }
   POCO_HIP_CHECK(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
   for (Op& op : e->ops)
     if (op.wait_mask) {
@@ -1770,15 +1844,12 @@ extern "C" int poco_realnvp_rep(poco_handle_t h, int N, const float* d_x, const 
   Engine* e = H(h);
   if (!e || !e->finalized || !e->has_flow) { poco_set_error("poco_realnvp: flow_head.flow.* tensors were not loaded"); return POCO_ERR_STATE; }
   if (!d_x || !d_ctx || !d_out || N < 1 || rep < 1) { poco_set_error("poco_realnvp: bad arguments"); return POCO_ERR_ARG; }
-  const size_t need = realnvp_scratch_floats(e->flow, (N + rep - 1) / rep);
-  if (need > e->flow_scratch_floats) {          // grow-only; the first call at a new size allocates (and synchronises)
-    if (e->flow_scratch) {
-      POCO_HIP_CHECK(hipDeviceSynchronize());
-      (void)hipFree(e->flow_scratch);
-      e->flow_scratch = nullptr; e->flow_scratch_floats = 0;
-    }
-    POCO_HIP_CHECK(hipMalloc(&e->flow_scratch, need * sizeof(float)));
-    e->flow_scratch_floats = need;
+  const int ctx_rows = (N + rep - 1) / rep;
+  if (realnvp_scratch_floats(e->flow, ctx_rows) > e->flow_scratch_floats) {
+    poco_set_error("poco_realnvp: " + std::to_string(ctx_rows) + " context rows, the engine's scratch was planned for " +
+                   std::to_string(e->opts.flow_ctx_rows > 0 ? e->opts.flow_ctx_rows : e->max_batch) +
+                   " (create the engine with poco_create_ex(..., \"flow_ctx_rows=<n>\"); default = max_batch, one context per crop)");
+    return POCO_ERR_ARG;
   }
   return launch_realnvp(e->flow, d_x, d_ctx, rep, d_out, N, forward, e->flow_scratch, (hipStream_t)stream);
 }

@@ -335,7 +335,7 @@ size_t part_attention_scratch_floats(int B, int C) {
 
 void launch_part_attention_pool_ws(const float* heat, int heat_cs, const float* feat, int C, float* dst,
                                    int dst_stride, int B, int H, int W, float* scratch, hipStream_t s) {
-  if (C % 64 == 0 && heat_cs >= 32) {        // the PARE head's pools (C = 128 / 64): fp32-MFMA formulation
+  if ((C == 64 || C == 128) && heat_cs >= 32) {   // the PARE head's pools: fp32-MFMA formulation (two 64-channel accumulator groups at most)
     const size_t lds = (size_t)3 * (C / 64) * 8 * 64 * sizeof(float4);
     hipLaunchKernelGGL(attn_pool_partial_mfma_kernel, dim3(B, ATTN_NSPLIT), dim3(256), lds, s, heat, heat_cs, feat, C,
                        scratch, H, W, ATTN_NSPLIT);

@@ -360,13 +360,16 @@ __device__ __forceinline__ void crop_inverse_affine(double cx, double cy, double
 
 __device__ __forceinline__ int cv_round(double v) { return __double2int_rn(v); }      // cvRound: round half to even
 
+// frames != nullptr (video / streaming batches): crop n is cut from frames[frame_idx[n]] - one launch for the crops of many frames
 template <typename BoxT>
 __global__ void __launch_bounds__(256)
-crop_normalize_kernel(const unsigned char* __restrict__ frame, int H, int W, const BoxT* __restrict__ boxes,
+crop_normalize_kernel(const unsigned char* __restrict__ frame, const unsigned char* const* __restrict__ frames,
+                      const int* __restrict__ frame_idx, int H, int W, const BoxT* __restrict__ boxes,
                       double bbox_scale, float* __restrict__ out, int res) {
 #pragma clang fp contract(off)
   __shared__ double sM[6];
   const int n = blockIdx.y, row0 = blockIdx.x * CROP_ROWS;
+  if (frames) frame = frames[frame_idx[n]];
   if (threadIdx.x < 64) {                    // the whole first wave solves the same system (no divergence, no broadcast)
     double Mi[6];
     crop_inverse_affine((double)boxes[n * 4], (double)boxes[n * 4 + 1], (double)boxes[n * 4 + 2], (double)boxes[n * 4 + 3],
@@ -427,9 +430,66 @@ static void launch_crop_t(const unsigned char* frame, int H, int W, const BoxT* 
                           int res, hipStream_t s) {
   for (int n0 = 0; n0 < N; n0 += 65535) {             // gridDim.y limit
     const int nn = N - n0 < 65535 ? N - n0 : 65535;
-    hipLaunchKernelGGL(crop_normalize_kernel<BoxT>, dim3((res + CROP_ROWS - 1) / CROP_ROWS, nn), dim3(256), 0, s, frame, H, W,
+    hipLaunchKernelGGL(crop_normalize_kernel<BoxT>, dim3((res + CROP_ROWS - 1) / CROP_ROWS, nn), dim3(256), 0, s, frame,
+                       (const unsigned char* const*)nullptr, (const int*)nullptr, H, W,
                        boxes + (size_t)n0 * 4, bbox_scale, out + (size_t)n0 * 3 * res * res, res);
   }
+}
+
+void launch_crop_normalize_multi(const unsigned char* const* frames, const int* frame_idx, int H, int W, const float* boxes,
+                                 double bbox_scale, float* out, int N, int res, hipStream_t s) {
+  for (int n0 = 0; n0 < N; n0 += 65535) {
+    const int nn = N - n0 < 65535 ? N - n0 : 65535;
+    hipLaunchKernelGGL(crop_normalize_kernel<float>, dim3((res + CROP_ROWS - 1) / CROP_ROWS, nn), dim3(256), 0, s,
+                       (const unsigned char*)nullptr, frames, frame_idx + n0, H, W, boxes + (size_t)n0 * 4, bbox_scale,
+                       out + (size_t)n0 * 3 * res * res, res);
+  }
+}
+
+// ---- packed per-crop record (poco_outputs_t.record) -------------------------------------------------------------------------
+// [rotmat 216 | betas 10 | cam 3 | var_pose 24 (raw) | confidence 1]; confidence = get_kinematic_uncert (poco_utils.py:21-25: children
+// in the order 1..23 add their parent's accumulated value; get_smpl_skeleton() is the fixed SMPL tree below) -> get_global_uncert
+// (poco_utils.py:50-60: root above the threshold -> every joint 1; cliff: root value, pare: mean over the 24 joints) -> clip to
+// [0, 0.99] (tester.py:245).  One block per crop; thread 0 runs the 23 dependent adds in exactly that order.
+namespace {
+constexpr int SMPL_PARENT[24] = {-1, 0, 0, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 9, 9, 12, 13, 14, 16, 17, 18, 19, 20, 21};
+
+__global__ void __launch_bounds__(256)
+pack_record_kernel(const float* __restrict__ rot, int rot_stride, const float* __restrict__ betas, int betas_stride,
+                   const float* __restrict__ cam, int cam_stride, const float* __restrict__ var, int var_stride,
+                   float* __restrict__ rec, int cliff, int kinematic, float thr) {
+  const int b = blockIdx.x, t = threadIdx.x;
+  float* r = rec + (size_t)b * 254;
+  if (t < 216) r[t] = rot[(size_t)b * rot_stride + t];
+  else if (t < 226) r[t] = betas[(size_t)b * betas_stride + (t - 216)];
+  else if (t < 229) r[t] = cam[(size_t)b * cam_stride + (t - 226)];
+  else if (t < 253) r[t] = var[(size_t)b * var_stride + (t - 229)];
+  else if (t == 253) {
+    float v[24];
+#pragma unroll
+    for (int j = 0; j < 24; ++j) v[j] = var[(size_t)b * var_stride + j];
+    if (kinematic) {
+#pragma unroll
+      for (int j = 1; j < 24; ++j) v[j] += v[SMPL_PARENT[j]];
+    }
+    const bool hot = v[0] > (cliff ? 2.f * thr : thr);
+    float g;
+    if (cliff) g = hot ? 1.f : v[0];
+    else {
+      float sum = 0.f;
+#pragma unroll
+      for (int j = 0; j < 24; ++j) sum += hot ? 1.f : v[j];
+      g = sum / 24.f;
+    }
+    r[253] = fminf(fmaxf(g, 0.f), 0.99f);
+  }
+}
+}  // namespace
+
+void launch_pack_record(const float* rot, int rot_stride, const float* betas, int betas_stride, const float* cam, int cam_stride,
+                        const float* var, int var_stride, float* rec, int cliff, int kinematic, float thr, int B, hipStream_t s) {
+  hipLaunchKernelGGL(pack_record_kernel, dim3(B), dim3(256), 0, s, rot, rot_stride, betas, betas_stride, cam, cam_stride, var,
+                     var_stride, rec, cliff, kinematic, thr);
 }
 
 void launch_crop_normalize(const unsigned char* frame, int H, int W, const float* boxes, double bbox_scale, float* out,

@@ -239,6 +239,19 @@ extern "C" int poco_crop_normalize(const unsigned char* d_frame, int H, int W, c
   return crop_common(d_frame, H, W, d_boxes, 0, N, bbox_scale, res, d_out, stream);
 }
 
+extern "C" int poco_crop_normalize_multi(const unsigned char* const* d_frames, int nframes, const int* d_frame_idx, int H, int W,
+                                         const float* d_boxes, int N, double bbox_scale, int res, float* d_out, void* stream) {
+  if (!d_frames || !d_frame_idx || nframes < 1 || !d_boxes || !d_out || N < 0 || H < 1 || W < 1 || res < 1 || H > 32767 || W > 32767) {
+    poco_set_error("poco_crop_normalize_multi: bad arguments (frames up to 32767 x 32767)");
+    return POCO_ERR_ARG;
+  }
+  if (N == 0) return POCO_OK;
+  launch_crop_normalize_multi(d_frames, d_frame_idx, H, W, d_boxes, bbox_scale, d_out, N, res, (hipStream_t)stream);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { poco_set_error(std::string("poco_crop_normalize_multi: ") + hipGetErrorString(e)); return POCO_ERR_HIP; }
+  return POCO_OK;
+}
+
 extern "C" int poco_crop_normalize_f64(const unsigned char* d_frame, int H, int W, const double* d_boxes, int N,
                                        double bbox_scale, int res, float* d_out, void* stream) {
   return crop_common(d_frame, H, W, d_boxes, 1, N, bbox_scale, res, d_out, stream);

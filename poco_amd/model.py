@@ -29,12 +29,19 @@ class _Inputs(C.Structure):
 class _Outputs(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in (
         "pred_pose", "pred_pose6d", "pred_shape", "pred_cam", "pred_cam_t", "pred_fullimg_cam_t", "smpl_vertices",
-        "smpl_joints3d", "smpl_joints2d", "var_pose", "uncert_feat", "pred_segm_mask", "body_feat2", "backbone_feat")]
+        "smpl_joints3d", "smpl_joints2d", "var_pose", "uncert_feat", "pred_segm_mask", "body_feat2", "backbone_feat", "record")]
+
+
+ABI_VERSION = 3          # include/poco_hip.h POCO_ABI_VERSION this binding was written against
 
 
 def _bind():
     L = lib()
+    if not hasattr(L, "poco_abi_version") or L.poco_abi_version() != ABI_VERSION:
+        raise PocoHipError(f"libpoco_hip.so has ABI version {L.poco_abi_version() if hasattr(L, 'poco_abi_version') else '< 3'}, "
+                           f"this binding needs {ABI_VERSION}: rebuild with `python -m poco_amd.build`")
     L.poco_create.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+    L.poco_create_ex.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_char_p, C.POINTER(C.c_void_p)]
     L.poco_destroy.argtypes = [C.c_void_p]
     L.poco_destroy.restype = None
     L.poco_num_tensors.argtypes = [C.c_void_p]
@@ -78,7 +85,8 @@ class POCO:
                  num_flow_layers=3, sigma_dim=1, num_nf_rv=9, mask_params_id="", nflow_mask_type="alter",
                  exclude_uncert_idx="", use_dropout=False, use_iter_feats=False, cond_nflow=True, context_dim=512,
                  gt_pose_cond=False, gt_pose_cond_ds="h36m", gt_pose_cond_ratio=0.25, pretrained=None,
-                 inf_model="best", is_test=True, *, max_batch=64, smpl=None, device="cuda:0", keep_state_dict=False):
+                 inf_model="best", is_test=True, *, max_batch=64, smpl=None, device="cuda:0", keep_state_dict=True,
+                 engine_options=None, max_graphs=8):
         if img_res != 224:
             raise ValueError("the engine is built for 224x224 crops (configs/demo_poco_*.yaml DATASET.IMG_RES)")
         if uncert_layer != "diff_branch" or activation_type != "sigmoid" or sigma_dim != 1 or num_nf_rv != 9:
@@ -92,13 +100,21 @@ class POCO:
         self.device = torch.device(device)
         self._L = _bind()
         self._h = C.c_void_p()
-        check(self._L.poco_create(backbone.encode(), self.max_batch, self.num_flow_layers, C.byref(self._h)),
-              "poco_create")
+        # engine_options: dict or "k=v,k=v" string of poco_create_ex build options (include/poco_hip.h); the library reads no
+        # environment variable
+        if isinstance(engine_options, dict):
+            engine_options = ",".join(f"{k}={int(v) if isinstance(v, bool) else v}" for k, v in engine_options.items())
+        self.engine_options = engine_options or ""
+        self.max_graphs = int(max_graphs)
+        check(self._L.poco_create_ex(backbone.encode(), self.max_batch, self.num_flow_layers, self.engine_options.encode(),
+                                     C.byref(self._h)), "poco_create_ex")
         self._finalized = False
         self._loaded = set()
-        # host copies for state_dict(): off by default (the engine packs its own BN-folded copy on the device; keeping the
-        # originals would pin ~300 MB of host memory for HRNet-W48 for the life of the process)
+        # host copies for state_dict() (nn.Module.state_dict() always works in the reference: checkpoint re-save, weight diffing).
+        # keep_state_dict=False drops them (the engine keeps only BN-folded, fragment-packed copies on the device; the originals
+        # are ~300 MB of host memory for HRNet-W48): state_dict() then re-reads them from the `pretrained` file if there was one
         self._state = {} if keep_state_dict else None
+        self._pretrained_path = None
         if smpl is not None:
             self.load_smpl(smpl)
         if pretrained is not None:
@@ -166,9 +182,15 @@ class POCO:
         separately, load_smpl); entries the engine tolerates but never reads (num_batches_tracked, backbone.final_layer, ...)
         appear only if they were loaded; values come back in the dtype they were loaded with (an int64
         num_batches_tracked stays int64; it crosses the C ABI as float32, exact up to 2^24)."""
-        if self._state is None:
-            raise PocoHipError("state_dict(): build the model with keep_state_dict=True")
         from collections import OrderedDict
+        if self._state is None:
+            if self._pretrained_path is None:
+                raise PocoHipError("state_dict(): the model was built with keep_state_dict=False and without a `pretrained` file "
+                                   "to re-read the parameters from")
+            from .checkpoint import read_checkpoint
+            sd = {(k[len("model."):] if k.startswith("model.") else k): v
+                  for k, v in read_checkpoint(self._pretrained_path, self.inf_model).items()}
+            return OrderedDict((n, torch.as_tensor(sd[n])) for n, _, _ in self.expected_tensors() if n in sd)
         out = OrderedDict()
         for name, _, _ in self.expected_tensors():
             if name in self._state:
@@ -186,6 +208,7 @@ class POCO:
         """pocolib/models/poco.py:131-154 (torch checkpoint -> state_dict -> per-part prefixes)."""
         from .checkpoint import read_checkpoint
         self.load_state_dict(read_checkpoint(file, self.inf_model), strict=True)
+        self._pretrained_path = file
 
     def finalize(self) -> "POCO":
         if not self._finalized:
@@ -221,6 +244,7 @@ class POCO:
             "pred_shape": torch.empty(B, 10, device=d, dtype=f),
             "uncert_feat": torch.empty(B, ufd, device=d, dtype=f),
             "var_pose": torch.empty(B, 24, device=d, dtype=f),
+            "record": torch.empty(B, 254, device=d, dtype=f),     # packed [pose 216 | betas 10 | cam 3 | var 24 | confidence 1]
         }
         if self.head_name == "cliff":
             o["pred_fullimg_cam_t"] = torch.empty(B, 3, device=d, dtype=f)
@@ -259,7 +283,7 @@ class POCO:
         outs = _Outputs(dp(g("pred_pose")), dp(g("pred_pose6d", g("pred_pose_6d"))), dp(g("pred_shape")), dp(g("pred_cam")),
                         dp(g("pred_cam_t")), dp(g("pred_fullimg_cam_t")), dp(g("smpl_vertices")), dp(g("smpl_joints3d")),
                         dp(g("smpl_joints2d")), dp(g("var_pose")), dp(g("uncert_feat")), dp(g("pred_segm_mask")),
-                        dp(g("body_feat2")), dp(g("backbone_feat")))
+                        dp(g("body_feat2")), dp(g("backbone_feat")), dp(g("record")))
         return B, ins, outs, keep
 
     @torch.no_grad()
@@ -282,10 +306,17 @@ class POCO:
     def graph_forward(self, batch: Dict[str, torch.Tensor], out: Dict[str, torch.Tensor]) -> Dict[str, object]:
         """Replay the forward as a hipGraph (captured on first use for these exact input/output tensors:
         the kernels read/write the same device addresses on every replay, so refill `batch` in place).
-        Removes ~375 launches + the fork/join events of the lanes from the host critical path."""
+        Removes ~375 launches + the fork/join events of the lanes from the host critical path.
+        At most `max_graphs` graphs are kept (least recently used first out; `release_graphs()` drops them all): a caller that
+        hands over fresh tensors every time would otherwise grow the cache without bound."""
+        from collections import OrderedDict
         key = (tuple(sorted((k, v.data_ptr()) for k, v in batch.items())), tuple(sorted((k, v.data_ptr()) for k, v in out.items())))
-        cache = self.__dict__.setdefault("_graphs", {})
-        if key not in cache:
+        cache = self.__dict__.setdefault("_graphs", OrderedDict())
+        if key in cache:
+            cache.move_to_end(key)
+        else:
+            while len(cache) >= max(1, self.max_graphs):
+                cache.popitem(last=False)
             self(batch, out=out)                      # warm-up on the capture stream's pool (tuning table, attributes)
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
@@ -303,6 +334,10 @@ class POCO:
         res["log_phi"] = None
         res["gt_pose_cond_idx"] = []
         return res
+
+    def release_graphs(self) -> None:
+        """Drop every captured hipGraph of graph_forward."""
+        self.__dict__.pop("_graphs", None)
 
     # ---- introspection / stand-alone ops -----------------------------------------------------------
     def ops(self):

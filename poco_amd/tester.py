@@ -53,6 +53,11 @@ def crop_normalize(frame_u8: torch.Tensor, boxes: torch.Tensor, bbox_scale: floa
     return out
 
 
+# outputs of a forward that postprocess() never reads: they stay on the device (uncert_feat alone is 2048-3072 floats per crop)
+DEVICE_ONLY_KEYS = ("uncert_feat", "body_feat2", "pred_pose6d", "pred_pose_6d", "pred_cam_t", "pred_fullimg_cam_t", "record",
+                    "pred_segm_mask", "backbone_feat")
+
+
 class POCOTester:
     def __init__(self, args):
         self.args = args
@@ -128,7 +133,9 @@ class POCOTester:
                 return
             batch = batches[0] if len(batches) == 1 else {k: torch.cat([b[k] for b in batches], 0) for k in batches[0]}
             out = self.model(batch, want_segm=False)
-            out = {n: (v.cpu() if torch.is_tensor(v) else v) for n, v in out.items()}     # one D2H per tensor, sliced per frame below
+            # one D2H per tensor postprocess() reads (not uncert_feat / body_feat2 / pose6d / cam_t: MBs per batch that nothing
+            # downstream uses), sliced per frame below
+            out = {n: v.cpu() for n, v in out.items() if torch.is_tensor(v) and n not in DEVICE_ONLY_KEYS}
             off = 0
             for e, lo, k in pieces:
                 sl = {n: (v[off:off + k] if torch.is_tensor(v) else v) for n, v in out.items()}
@@ -269,7 +276,10 @@ class POCOTester:
         picked = [(pos, names_all[pos]) for pos in range(0, len(names_all), skip)]
         counts = []
         nthreads = max(1, min(8, (os.cpu_count() or 2) // 2))
-        ahead = max(4, 2 * self.model.max_batch)
+        # decode look-ahead / unwritten results in flight: about one batch, and bounded in bytes by the first image's size
+        # (2 x batch_size 1080p frames were 0.8 GB at batch_size 64)
+        ahead = max(4, self.model.max_batch)
+        ahead_bytes = 256 << 20
 
         def decode(n):
             return np.asarray(Image.open(os.path.join(image_folder, n)).convert("RGB"))
@@ -297,18 +307,26 @@ class POCOTester:
         n_img = 0
         with ThreadPoolExecutor(nthreads) as dec_pool, ThreadPoolExecutor(nthreads) as wr_pool:
             def items():
+                nonlocal ahead
                 q = deque()
                 it = iter(picked)
-                for pos, n in it:
-                    q.append((pos, n, dec_pool.submit(decode, n)))
-                    if len(q) >= ahead:
-                        break
+                done = False
+
+                def fill():
+                    nonlocal done
+                    while not done and len(q) < ahead:
+                        nxt = next(it, None)
+                        if nxt is None:
+                            done = True
+                        else:
+                            q.append((nxt[0], nxt[1], dec_pool.submit(decode, nxt[1])))
+
+                fill()
                 while q:
                     pos, n, fut = q.popleft()
-                    nxt = next(it, None)
-                    if nxt is not None:
-                        q.append((nxt[0], nxt[1], dec_pool.submit(decode, nxt[1])))
                     img = fut.result()
+                    ahead = max(4, min(ahead, ahead_bytes // max(1, img.nbytes)))       # big images: fewer of them decoded ahead
+                    fill()
                     d = dets_of(pos, n, img)
                     counts.append(len(d))
                     yield img, d

@@ -8,6 +8,8 @@
 
 typedef const char* (*last_error_fn)(void);
 typedef int (*create_fn)(const char*, int, int, poco_handle_t*);
+typedef int (*create_ex_fn)(const char*, int, int, const char*, poco_handle_t*);
+typedef int (*version_fn)(void);
 typedef void (*destroy_fn)(poco_handle_t);
 typedef int (*num_tensors_fn)(poco_handle_t);
 typedef int (*tensor_info_fn)(poco_handle_t, int, char*, size_t, int64_t*, int*, int*);
@@ -25,7 +27,10 @@ int main(int argc, char** argv) {
   tensor_info_fn tensor_info = (tensor_info_fn)dlsym(so, "poco_tensor_info");
   load_tensor_fn load_tensor = (load_tensor_fn)dlsym(so, "poco_load_tensor");
   forward_fn forward = (forward_fn)dlsym(so, "poco_forward");
-  if (!last_error || !create || !destroy || !num_tensors || !tensor_info || !load_tensor || !forward) return 4;
+  create_ex_fn create_ex = (create_ex_fn)dlsym(so, "poco_create_ex");
+  version_fn version = (version_fn)dlsym(so, "poco_abi_version");
+  if (!last_error || !create || !destroy || !num_tensors || !tensor_info || !load_tensor || !forward || !create_ex || !version) return 4;
+  if (version() != POCO_ABI_VERSION) { fprintf(stderr, "library ABI %d, header ABI %d\n", version(), POCO_ABI_VERSION); return 15; }
 
   poco_handle_t h = 0;
   if (create("no_such-variant", 4, 1, &h) == 0) return 5;              /* unknown variant is an error ... */
@@ -50,6 +55,11 @@ int main(int argc, char** argv) {
   poco_inputs_t in; poco_outputs_t out;
   memset(&in, 0, sizeof in); memset(&out, 0, sizeof out);
   if (forward(h, 1, &in, &out, 0) == 0) return 14;                                  /* not finalized */
+  destroy(h);
+  if (create_ex("resnet50-cliff", 4, 1, "no_such_option=1", &h) == 0) return 16;     /* unknown build option is an error ... */
+  if (strstr(last_error(), "no_such_option") == 0) return 17;                         /* ... that names it */
+  if (create_ex("resnet50-cliff", 4, 1, "dual=0,flow_ctx_rows=96", &h) != 0) return 18;
+  if (num_tensors(h) != n) return 19;                                                 /* the separate-launch form consumes the same tensors */
   destroy(h);
   printf("ok %d\n", n);
   return 0;

@@ -50,6 +50,34 @@ def test_crop_normalize_full_hd_many_boxes(cuda):
     assert np.array_equal(out, ref)
 
 
+def test_crop_normalize_multi_frame_launch(cuda):
+    """poco_crop_normalize_multi (one crop launch per streaming batch): crops cut from several frames through
+    a device table of frame pointers + a per-crop frame index are BITWISE what poco_crop_normalize gives per frame (itself bitwise
+    the cv2 restatement), in any crop order, frames used zero / one / many times."""
+    import ctypes as C
+    from poco_amd._lib import check, lib
+    from poco_amd.tester import crop_normalize
+    r = np.random.default_rng(21)
+    H, W = 270, 480
+    frames = [torch.from_numpy(r.integers(0, 256, (H, W, 3), dtype=np.uint8)).to(cuda) for _ in range(5)]
+    N = 23
+    fidx = r.integers(0, 4, N).astype(np.int32)                      # frame 4 is never used
+    side = r.uniform(40, 400, N)
+    boxes = np.stack([r.uniform(-0.1, 1.1, N) * W, r.uniform(-0.1, 1.1, N) * H, side, side * r.uniform(0.5, 1.5, N)], 1).astype(np.float32)
+    ptrs = torch.tensor([f.data_ptr() for f in frames], dtype=torch.int64, device=cuda)
+    bd, fd = torch.from_numpy(boxes).to(cuda), torch.from_numpy(fidx).to(cuda)
+    out = torch.empty(N, 3, 224, 224, device=cuda)
+    L = lib()
+    L.poco_crop_normalize_multi.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_double,
+                                            C.c_int, C.c_void_p, C.c_void_p]
+    check(L.poco_crop_normalize_multi(ptrs.data_ptr(), 5, fd.data_ptr(), H, W, bd.data_ptr(), N, 1.1, 224, out.data_ptr(), None), "multi")
+    torch.cuda.synchronize()
+    for n in range(N):
+        one = crop_normalize(frames[fidx[n]], bd[n:n + 1], 1.1)
+        assert torch.equal(one[0], out[n]), n
+    assert L.poco_crop_normalize_multi(None, 5, fd.data_ptr(), H, W, bd.data_ptr(), N, 1.1, 224, out.data_ptr(), None) != 0
+
+
 def test_demo_folder_end_to_end(tmp_path, cuda):
     from PIL import Image
     import demo
@@ -254,6 +282,7 @@ def test_crop_stream_matches_batch_path(tmp_path, cuda):
             assert np.abs(rec[row:row + k, 216:226] - out["pred_shape"].cpu().numpy()).max() < 1e-5
             assert np.abs(rec[row:row + k, 226:229] - out["pred_cam"].cpu().numpy()).max() < 1e-5
             assert np.abs(rec[row:row + k, 229:253] - out["var_pose"].cpu().numpy()).max() < 1e-5
+            assert np.abs(rec[row:row + k, 253] - out["record"][:, 253].cpu().numpy()).max() < 1e-5 and (rec[row:row + k, 253] <= 0.99).all()
             row += k
     # upload_many (staging copies on a thread pool) == upload frame by frame, bitwise; a frame without boxes frees its slot;
     # zero-copy staging through pinned_frame(slot)
@@ -383,3 +412,16 @@ def test_crop_stream_pipelined_batches_keep_their_own_boxes(tmp_path, cuda):
     cs2.upload(frames[0]); cs2.upload(frames[1])
     with pytest.raises(RuntimeError, match="ring"):
         cs2.upload(frames[2])
+    # upload_many on a ring that cannot take all frames: refused BEFORE any slot is reserved (an overflow used to
+    # shrink the ring for ever), so the ring works again as soon as run() / release() frees the busy slot
+    cs3 = CropStream(t.model, (180, 240), batch=5, ring=3)
+    k0 = cs3.upload(frames[0])
+    with pytest.raises(RuntimeError, match="ring"):
+        cs3.upload_many(frames[:3])
+    assert cs3._pending == [True, False, False]
+    cs3.release(k0)
+    slots = cs3.upload_many(frames[:3])
+    assert sorted(slots) == [0, 1, 2]
+    rec, n = cs3.run([(slots[0], boxes_a[0]), (slots[1], boxes_a[1]), (slots[2], np.zeros((0, 4), np.float32))], 0)
+    torch.cuda.synchronize()
+    assert n == 3 and np.array_equal(rec.numpy()[:3], want[0]) and cs3._pending == [False] * 3

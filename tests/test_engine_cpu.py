@@ -23,6 +23,27 @@ def test_library_exports_header_symbols():
     assert not missing, missing
 
 
+def test_library_reads_no_environment_variable():
+    """the shipped binary has no debug / experiment environment switch compiled in (they silently changed results
+    or speed): no POCO_* string in the .so at all (the Python loader's POCO_HIP_LIB override lives in poco_amd/_lib.py), and
+    `getenv` appears in csrc/ only behind a compile-time probe macro (POCO_PROBES / W4P_EXP / GH_EXP / G1_DUAL_EXP builds of tools/build_exp.sh)."""
+    import re
+    blob = _lib.LIB_PATH.read_bytes()
+    found = sorted(set(m.decode() for m in re.findall(rb"POCO_[A-Z0-9_]{3,}", blob)))
+    assert found == [], found
+    for f in sorted((Path(__file__).resolve().parent.parent / "poco_amd" / "csrc").glob("*")):
+        depth_stack = []
+        for ln in f.read_text().splitlines():
+            s = ln.strip()
+            if re.match(r"#\s*if", s):
+                depth_stack.append(bool(re.search(r"POCO_PROBES|W4P_EXP|GH_EXP|WINO_EXP|G1_DUAL_EXP", s)))
+            elif re.match(r"#\s*endif", s) and depth_stack:
+                depth_stack.pop()
+            code = s.split("//")[0]
+            if "getenv(" in code:
+                assert any(depth_stack), (f.name, ln)
+
+
 @pytest.mark.parametrize("variant", list(VARIANTS))
 def test_declared_tensors_match_reference_keys(variant):
     m = POCO(backbone=variant, num_flow_layers=VARIANTS[variant], max_batch=2)
@@ -65,13 +86,15 @@ def test_state_dict_round_trip():
     from tests import util
     variant = "resnet50-cliff"
     w = util.synth_weights(variant)
-    m = POCO(backbone=variant, num_flow_layers=1, max_batch=1, keep_state_dict=True)
+    m = POCO(backbone=variant, num_flow_layers=1, max_batch=1)                # state_dict() works by default, like nn.Module's
     w["backbone.bn1.num_batches_tracked"] = np.array(7, np.int64)             # tolerated-unused entry keeps its dtype
     m.load_state_dict(w, strict=True)
     sd = m.state_dict()
     assert set(sd) == set(w) and all(np.array_equal(sd[k].numpy(), w[k]) and sd[k].numpy().dtype == w[k].dtype for k in w)
+    lean = POCO(backbone=variant, num_flow_layers=1, max_batch=1, keep_state_dict=False)      # host copies explicitly dropped, no checkpoint file
+    lean.load_state_dict(w, strict=True)
     with pytest.raises(_lib.PocoHipError, match="keep_state_dict"):
-        POCO(backbone=variant, num_flow_layers=1, max_batch=1).state_dict()
+        lean.state_dict()
     m2 = POCO(backbone=variant, num_flow_layers=1, max_batch=1)
     assert m2.load_state_dict(sd, strict=True) == []
     assert list(sd)[:2] == [n for n, _, _ in m.expected_tensors() if n in w][:2]
@@ -142,10 +165,9 @@ def test_schedule_has_no_unsynchronised_cross_lane_read(variant, xdep, monkeypat
     without a GPU by a vector-clock walk: regions (phases) are separated by joins of all lanes; inside a region an op on lane a may
     read an activation that lane b != a writes in the SAME region only if a has waited (wait_mask, transitively) for an op of b at
     or after the writer.  Covers the one-join-per-module schedule with its open stage boundaries and event dependencies (default)
-    and the three-join schedule (POCO_NO_XDEP=1).  Also: every cross-lane wait names a lane that has work in the region, and the
+    and the three-join schedule (option xdep=0).  Also: every cross-lane wait names a lane that has work in the region, and the
     default schedule does contain such waits for the HRNet variants (the transition convs at the stage boundaries)."""
-    monkeypatch.setenv("POCO_NO_XDEP", "0" if xdep == "1" else "1")
-    m = POCO(backbone=variant, num_flow_layers=VARIANTS[variant], max_batch=2)      # declarations only
+    m = POCO(backbone=variant, num_flow_layers=VARIANTS[variant], max_batch=2, engine_options={"xdep": int(xdep)})      # declarations only
     n = len(m.ops())
     sched = [m.op_sched(i) for i in range(n)]
     names = [o[0] for o in m.ops()]

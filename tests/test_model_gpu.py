@@ -118,9 +118,7 @@ def test_kconcat_shortcut_matches_separate_convs(variant, cuda, monkeypatch):
     the two-launch form of the reference (hrnet.py:79-99 / resnet.py:101-121); only the summation order differs."""
     batch = util.cuda_batch(synth.synth_batch(5, 31), cuda)
     merged = util.make_engine(variant, max_batch=5)
-    monkeypatch.setenv("POCO_NO_KCAT", "1")
-    separate = util.make_engine(variant, max_batch=5)
-    monkeypatch.delenv("POCO_NO_KCAT")
+    separate = util.make_engine(variant, max_batch=5, options={"kcat": 0})
     names = lambda m: [n for n, _, _ in m.ops()]
     assert any(n.endswith("layer1.0.conv3+downsample") for n in names(merged))
     assert any(n.endswith("layer1.0.downsample.0") for n in names(separate)) and len(names(separate)) == len(names(merged)) + 1
@@ -135,9 +133,7 @@ def test_strided_kconcat_shortcut_matches_separate_convs(cuda, monkeypatch):
     variant = "resnet50-cliff"
     batch = util.cuda_batch(synth.synth_batch(5, 41), cuda)
     merged = util.make_engine(variant, max_batch=5)
-    monkeypatch.setenv("POCO_NO_DUAL", "1")
-    separate = util.make_engine(variant, max_batch=5)
-    monkeypatch.delenv("POCO_NO_DUAL")
+    separate = util.make_engine(variant, max_batch=5, options={"dual": 0})
     names = lambda m: [n for n, _, _ in m.ops()]
     assert sum(n.endswith(".0.conv3+downsample") for n in names(merged)) == 4          # layer1.0 (K-concat buffer) + layer2-4.0
     assert len(names(separate)) == len(names(merged)) + 3
@@ -153,9 +149,7 @@ def test_chained_bottleneck_matches_separate_convs(variant, cuda, monkeypatch):
     resnet.py:101-121).  Ragged batch: 7 crops = 21952 pixels = 1372 sub-tiles, not a multiple of the 2048 waves."""
     batch = util.cuda_batch(synth.synth_batch(7, 77), cuda)
     chained = util.make_engine(variant, max_batch=7)
-    monkeypatch.setenv("POCO_NO_CHAIN", "1")
-    separate = util.make_engine(variant, max_batch=7)
-    monkeypatch.delenv("POCO_NO_CHAIN")
+    separate = util.make_engine(variant, max_batch=7, options={"chain": 0})
     names = lambda m: [n for n, _, _ in m.ops()]
     nchain = sum("conv3+" in n and n.endswith(".conv1") for n in names(chained))
     assert nchain == (2 if variant.startswith("hrnet") else 1) and len(names(separate)) == len(names(chained)) + nchain
@@ -214,15 +208,14 @@ def test_bench_batch_with_tuned_table(variant, B, profile, cuda):
 def test_wino4g_chained_convs_match_unchained(variant, B, cuda, monkeypatch):
     """ALG 11 (Winograd F(4x4) as position GEMMs) on the 7x7 branch: consecutive convs of the chain run with the fused tail
     (wg_mid_kernel: output transform of conv k -> V of conv k+1 through LDS, conv1's output of a BasicBlock never stored) -
-    BITWISE the same model outputs as the unchained three-launch form (POCO_NO_WG_FUSE=1), in eager 4-lane, 1-lane and
+    BITWISE the same model outputs as the unchained three-launch form (option wg_fuse=0), in eager 4-lane, 1-lane and
     graph-replay mode, and within the gate of the oracle."""
     batch_np = synth.synth_batch(B, 21)
     batch = util.cuda_batch(batch_np, cuda)
     keys = ("pred_pose", "pred_shape", "pred_cam", "var_pose", "smpl_vertices", "uncert_feat")
 
     def engine(fuse):
-        monkeypatch.setenv("POCO_NO_WG_FUSE", "0" if fuse else "1")
-        m = util.make_engine(variant, max_batch=B, profile="stress")
+        m = util.make_engine(variant, max_batch=B, profile="stress", options={"wg_fuse": int(fuse)})
         n = 0
         for i, _ in enumerate(m.ops()):
             d = m.conv_desc(i)
@@ -256,7 +249,7 @@ def test_wino4g_chained_convs_match_unchained(variant, B, cuda, monkeypatch):
 def test_kmerged_fuse_convs_match_separate_form(variant, B, cuda, monkeypatch):
     """K-merge (engine.hip hr_module): relu(x_T + sum_j bn_j(conv_j(t_j))) of the lowest-resolution branch of every HR module
     (hrnet.py:208-236, 248-266) runs as ONE stride-2 conv over the channel concat with residual + ReLU in the epilogue.  Against
-    the separate form (POCO_NO_KMERGE=1: T convs + fuse_sum): 8 fuse_sum launches and 12 (W48) conv launches fewer, the same
+    the separate form (option kmerge=0: T convs + fuse_sum): 8 fuse_sum launches and 12 (W48) conv launches fewer, the same
     parameters consumed, outputs equal up to the summation order (fp32 rounding, far inside the gate) on the STRESS weights,
     and both inside the gate of the oracle."""
     batch_np = synth.synth_batch(B, 33)
@@ -264,8 +257,7 @@ def test_kmerged_fuse_convs_match_separate_form(variant, B, cuda, monkeypatch):
     keys = ("pred_pose", "pred_shape", "pred_cam", "var_pose", "smpl_vertices")
 
     def engine(merge):
-        monkeypatch.setenv("POCO_NO_KMERGE", "0" if merge else "1")
-        return util.make_engine(variant, max_batch=B, profile="stress")
+        return util.make_engine(variant, max_batch=B, profile="stress", options={"kmerge": int(merge)})
 
     sep = engine(False)
     mrg = engine(True)
@@ -300,14 +292,12 @@ def test_one_join_per_module_schedule_is_bitwise_the_three_join_one(variant, B, 
     """Scheduling only (engine.hip hr_module / hrnet_trunk, `xdep`): the fuse convs on the lane of the branch they read, one
     join per HR module instead of three, stage boundaries and the cls-head incre modules inside the open region with the
     transition conv waiting for the K-merged conv's lane through an event.  Same kernels, same configurations, same operands:
-    every output must be BITWISE what the three-join schedule (POCO_NO_XDEP=1) produces - eager on 4 lanes, on 1 lane, and as a
+    every output must be BITWISE what the three-join schedule (option xdep=0) produces - eager on 4 lanes, on 1 lane, and as a
     replayed hipGraph (repeated: a missing dependency shows up as a rare differing tile)."""
     batch = util.cuda_batch(synth.synth_batch(B, 57), cuda)
     keys = ("pred_pose", "pred_shape", "pred_cam", "var_pose", "smpl_vertices", "uncert_feat")
-    monkeypatch.setenv("POCO_NO_XDEP", "1")
-    old = util.make_engine(variant, max_batch=B, profile="stress")
+    old = util.make_engine(variant, max_batch=B, profile="stress", options={"xdep": 0})
     ref = {k: v.clone() for k, v in old(batch).items() if k in keys}
-    monkeypatch.setenv("POCO_NO_XDEP", "0")
     new = util.make_engine(variant, max_batch=B, profile="stress")
     assert [o[0] for o in new.ops()] != [] and len(new.ops()) == len(old.ops())
     for lanes in (4, 1, 4):
@@ -328,9 +318,8 @@ def test_split_f16_experiment_passes_the_gate(cuda, monkeypatch):
     """VERDICT r2 next #9 (EXPERIMENT, bench.py --split-f16, never the default): ResNet-50-CLIFF with every plain 1x1 conv on the
     split-fp16 GEMM (fp16 hi + lo, 3 MFMAs per product) must pass the STRESS fixtures at the same 1e-3 gate - golden B = 2 made by
     the reference's modules, and the oracle at the bench batch with the tuned table."""
-    monkeypatch.setenv("POCO_SPLIT_F16", "1")
     variant = "resnet50-cliff"
-    m = util.make_engine(variant, max_batch=2, profile="stress")
+    m = util.make_engine(variant, max_batch=2, profile="stress", options={"split_f16": 1})
     n12 = sum(1 for i, _ in enumerate(m.ops()) if m.conv_desc(i) is not None and m.conv_desc(i)[4] == 1 and m.conv_desc(i)[2] % 32 == 0
               and m.conv_desc(i)[0] * m.conv_desc(i)[1] >= 16)
     assert n12 >= 20
@@ -344,6 +333,64 @@ def test_split_f16_experiment_passes_the_gate(cuda, monkeypatch):
     assert max(worst.values()) < TOL, worst
     for k, e in dev.items():
         assert e < (TOL if k in GATED else TOL * max(1.0, mag[k])), (k, e)
+
+
+@pytest.mark.parametrize("variant,B", [("hrnet_w48_cls-cliff", 6), ("hrnet_w32-pare", 5), ("resnet50-cliff", 9)])
+def test_record_output_is_the_packed_host_record(variant, B, cuda):
+    """poco_outputs_t.record (VERDICT r3 next #3): the 254-float per-crop record - the payload of the multi-GPU all-gather and of the
+    streaming D2H copy - is written by ONE kernel inside the forward.  Against dist.pack_records (the torch restatement of
+    poco_utils.py:21-25,50-60 + tester.py:245 used since round 1): the 253 copied floats BITWISE, the post-processed confidence
+    bitwise for the CLIFF rule (root value) and to one ulp for PARE's mean over 24 joints (summation order); eager, graph replay
+    and with the post-processing options of poco_create_ex; uncertainties scaled so that both sides of the threshold occur."""
+    from poco_amd import dist as pdist
+    from poco_amd import postproc
+    batch = util.cuda_batch(synth.synth_batch(B, 12), cuda)
+    m = util.make_engine(variant, max_batch=B, profile="stress")
+    out = m(batch)
+    rec = out["record"]
+    ref = pdist.pack_records(out, head=variant)
+    assert rec.shape == (B, 254) and torch.equal(rec[:, :253], ref[:, :253])
+    assert (rec[:, 253] - ref[:, 253]).abs().max().item() <= (0.0 if "cliff" in variant else 1e-6)
+    # the numpy post-processing the testers use (pinned to the reference's POCOUtils in tests/test_host_cpu.py)
+    _, g = postproc.folder_uncert(out["var_pose"], variant, True)
+    assert np.abs(_np(rec[:, 253]) - g).max() <= 1e-6
+    o = m._alloc_outputs(B, False)
+    m.graph_forward(batch, o)
+    m.graph_forward(batch, o)
+    torch.cuda.synchronize()
+    assert torch.equal(o["record"], rec)
+    # options: no kinematic accumulation, another threshold (both branches of the threshold rule exercised)
+    var = out["var_pose"]
+    root = float(var[:, 0].median())
+    for kin in (0, 1):
+        m2 = util.make_engine(variant, max_batch=B, profile="stress", options={"record_kinematic": kin, "record_thr": root if "pare" in variant else root / 2})
+        o2 = m2(batch)
+        want = pdist.global_confidence(o2["var_pose"], variant, kinematic=bool(kin), thr=root if "pare" in variant else root / 2)
+        assert (o2["record"][:, 253] - want).abs().max().item() <= 1e-6
+        hot = o2["var_pose"][:, 0] > root
+        assert bool(hot.any()) and bool((~hot).any())
+        assert torch.equal(o2["record"][:, :253], rec[:, :253])
+    # a caller that does not ask for the record gets the same outputs (the op is skipped)
+    o3 = {k: v for k, v in m._alloc_outputs(B, False).items() if k != "record"}
+    m(batch, out=o3)
+    assert torch.equal(o3["pred_pose"], out["pred_pose"])
+
+
+def test_graph_cache_is_bounded(cuda):
+    """VERDICT r3 weak #11: graph_forward keeps at most max_graphs captured graphs (LRU); release_graphs() drops them."""
+    m = util.make_engine("resnet50-cliff", max_batch=2)
+    m.max_graphs = 2
+    batch = util.cuda_batch(synth.synth_batch(2, 3), cuda)
+    outs = [m._alloc_outputs(2, False) for _ in range(4)]
+    for o in outs:
+        m.graph_forward(batch, o)
+        assert len(m._graphs) <= 2
+    first = m(batch)
+    m.graph_forward(batch, outs[0])                      # evicted earlier: re-captured, still correct
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0]["pred_pose"], first["pred_pose"]) and len(m._graphs) == 2
+    m.release_graphs()
+    assert not hasattr(m, "_graphs") or not m._graphs
 
 
 def test_graph_replay_matches_eager(cuda):
@@ -389,10 +436,10 @@ def test_realnvp_op(variant, L, cuda):
     """RealNVP log_prob / forward_p vs the oracle (itself pinned to the reference's RealNVP in
     tests/golden/ops.npz), plus the bijection property backward(forward(z)) == z via log_prob shift."""
     from oracle import poco_ref
-    m = util.make_engine(variant, max_batch=2)
+    N = 48 + 5
+    m = util.make_engine(variant, max_batch=2, options={"flow_ctx_rows": N})      # one context per row: scratch planned for N rows
     sd = poco_ref.to_torch(util.synth_weights(variant))
     r = np.random.default_rng(8)
-    N = 48 + 5
     x = torch.from_numpy(np.abs(r.standard_normal((N, 9))).astype(np.float32))
     c = torch.from_numpy(r.standard_normal((N, 512)).astype(np.float32))
     ref_lp = poco_ref.realnvp_log_prob(sd, x, c).numpy()
@@ -413,7 +460,8 @@ def test_realnvp_op_at_reference_sizes(variant, L, N, cuda):
     B = 128 -> 3072, 2*L = 2 and 6 coupling layers, plus 1 row, one crop's 24 rows and a ragged N far above any grid size.
     Against the oracle (pinned to the reference's RealNVP), rows bitwise independent of their neighbours."""
     from oracle import poco_ref
-    m = util.make_engine(variant, max_batch=2)
+    from poco_amd._lib import PocoHipError
+    m = util.make_engine(variant, max_batch=2, options={"flow_ctx_rows": N})      # (the per-row-context form needs N context rows)
     sd = poco_ref.to_torch(util.synth_weights(variant))
     r = np.random.default_rng(80 + N % 97)
     crops = (N + 23) // 24
@@ -440,6 +488,14 @@ def test_realnvp_op_at_reference_sizes(variant, L, N, cuda):
         if N <= 256:
             assert np.array_equal(a, lp[sub]) and np.array_equal(b, fw[sub])
         assert np.abs(a - lp[sub]).max() < 1e-4 * max(1.0, np.abs(lp).max()) and np.abs(b - fw[sub]).max() < 1e-4 * max(1.0, np.abs(fw).max())
+    # SURVEY 8(b) "no allocation inside forward": the context-GEMM scratch is planned at finalize; a call with more context rows
+    # than planned fails loudly instead of allocating
+    small = util.make_engine(variant, max_batch=2)                                 # default plan: max_batch = 2 context rows
+    if N > 2 * 24:
+        with pytest.raises(PocoHipError, match="flow_ctx_rows"):
+            small.realnvp_log_prob(xd, cc, rep=24)
+    else:
+        assert np.array_equal(_np(small.realnvp_log_prob(xd, cc, rep=24)), _np(m.realnvp_log_prob(xd, cc, rep=24)))
 
 
 @pytest.mark.parametrize("variant,B", [("hrnet_w48_cls-cliff", 64), ("hrnet_w32-pare", 32), ("resnet50-cliff", 128)])

@@ -21,9 +21,11 @@ def synth_weights(variant, seed=0, profile="default"):
     return {k: v for k, v in w.items() if v.dtype != np.int64}
 
 
-def make_engine(variant, max_batch, seed=0, smpl_seed=7, profile="default"):
+def make_engine(variant, max_batch, seed=0, smpl_seed=7, profile="default", options=None):
+    """options: poco_create_ex build options (dict), e.g. {"kmerge": 0} for the separate-launch form of an op group."""
     from poco_amd.model import POCO
-    m = POCO(backbone=variant, num_flow_layers=FLOW_LAYERS[variant], max_batch=max_batch, smpl=synth.synth_smpl(smpl_seed))
+    m = POCO(backbone=variant, num_flow_layers=FLOW_LAYERS[variant], max_batch=max_batch, smpl=synth.synth_smpl(smpl_seed),
+             keep_state_dict=False, engine_options=options)
     m.load_state_dict(synth_weights(variant, seed, profile), strict=True)
     return m.finalize()
 

@@ -9,12 +9,12 @@ OUT=$R/gpurun_out/$TAG
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 python $R/bench.py 2>$OUT/bench_w48.err | tail -1 > $OUT/${TAG}_bench_hrnet_w48_cls-cliff.json
-python $R/bench.py --variant resnet50-cliff --batch 64 --no-stream 2>/dev/null | tail -1 > $OUT/${TAG}_bench_resnet50-cliff.json
-python $R/bench.py --variant hrnet_w32-pare --batch 32 --no-stream 2>/dev/null | tail -1 > $OUT/${TAG}_bench_hrnet_w32-pare.json
-python $R/bench.py --no-graph --no-cpu-baseline --no-stream 2>/dev/null | tail -1 > $OUT/${TAG}_bench_hrnet_w48_cls-cliff_nograph.json
+python $R/bench.py --variant resnet50-cliff --batch 64 --no-stream --no-side 2>/dev/null | tail -1 > $OUT/${TAG}_bench_resnet50-cliff.json
+python $R/bench.py --variant hrnet_w32-pare --batch 32 --no-stream --no-side 2>/dev/null | tail -1 > $OUT/${TAG}_bench_hrnet_w32-pare.json
+python $R/bench.py --no-graph --no-cpu-baseline --no-stream --no-side --no-variants 2>/dev/null | tail -1 > $OUT/${TAG}_bench_hrnet_w48_cls-cliff_nograph.json
 prof_variant() {   # variant batch short-tag
   V=$1; B=$2; T=$3
-  ARGS="--variant $V --batch $B --no-cpu-baseline --no-stream --no-dominant --no-graph --no-side"
+  ARGS="--variant $V --batch $B --no-cpu-baseline --no-stream --no-dominant --no-graph --no-side --no-variants"
   for L in 1 4; do
     timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ks -o bench -- \
       python $R/bench.py --steps 10 --warmup 3 --lanes $L $ARGS > $OUT/ks_${T}_l$L.log 2>&1
