@@ -53,6 +53,9 @@ struct W4PParams {
   int act, res_after_act;
   int uoff, voff, xoff;  // float4 offsets of the U ring, the V double buffer and the exchange area in LDS (raw ring at 0)
   FastDiv dPW, dSlab, dBands, dTX, dTslab;
+  // FLAT items (cfg.NI == 0, see flat_geo): TY tile rows per image, ntiles = B * TX * TY tiles in all, fragW = 4 TX + 2
+  int TY, ntiles, fragW;
+  FastDiv dTY, dFragW;
 };
 
 #ifndef W4P_EXP
@@ -117,7 +120,37 @@ __device__ __forceinline__ Walk item_walk(const W4PParams& p) {
 
 // tile of lane idx (0..15) in group grp of an item: validity, window top-left in the patch, output coordinates
 struct Tile { bool valid; int base, b, oy0, tx; };
+// FLAT items (round 4): an item is 32 CONSECUTIVE tiles of the flattened (image, tile row, tile column) order, so every one of the
+// 32 MFMA tile columns of a block carries a tile whatever the plane width is (rectangular items use 28 of 32 on 56x56 / 28x28
+// planes: 2 x 14 and 4 x 7 tiles).  Its patch is a STRIP of 6 rows: the item's tile-row fragments laid side by side, each with its
+// own 2-column halo - fragment 0 = tiles tx0.. of the first tile row (4 (TX - tx0) + 2 columns), fragments r >= 1 = whole tile rows
+// (fragW = 4 TX + 2 columns each, the last one used as far as the item reaches): PW = 128 + 2 Fmax columns, window (k, c) of a tile at
+// base + k PW + c exactly as in a rectangular patch.
+struct FlatItem { int gr0, tx0, w0; };
+__device__ __forceinline__ FlatItem flat_item(const W4PParams& p, int item) {
+  const uint32_t T0 = (uint32_t)(item % p.nblocks_m) * 32u;
+  FlatItem f;
+  f.gr0 = (int)fdiv(T0, p.dTX);
+  f.tx0 = (int)(T0 - (uint32_t)f.gr0 * (uint32_t)p.TX);
+  f.w0 = 4 * (p.TX - f.tx0) + 2;
+  return f;
+}
+template <bool FLAT>
 __device__ __forceinline__ Tile tile_of(const W4PParams& p, int item, int grp, int idx) {
+  if constexpr (FLAT) {
+    const FlatItem f = flat_item(p, item);
+    const uint32_t T = (uint32_t)(item % p.nblocks_m) * 32u + (uint32_t)(grp * 16 + idx);
+    const uint32_t gr = fdiv(T, p.dTX);
+    Tile t;
+    t.tx = (int)(T - gr * (uint32_t)p.TX);
+    t.b = (int)fdiv(gr, p.dTY);
+    t.oy0 = 4 * (int)(gr - (uint32_t)t.b * (uint32_t)p.TY);
+    t.valid = T < (uint32_t)p.ntiles;
+    const int r = (int)gr - f.gr0;
+    t.base = r == 0 ? 4 * (t.tx - f.tx0) : f.w0 + (r - 1) * p.fragW + 4 * t.tx;
+    if (!t.valid) { t.b = 0; t.oy0 = 0; t.tx = 0; t.base = 0; }
+    return t;
+  }
   const int s0 = (item % p.nblocks_m) * p.NI;
   const uint32_t tidx = (uint32_t)(grp * 16 + idx);
   const uint32_t sl = fdiv(tidx, p.dTslab);
@@ -168,8 +201,45 @@ __host__ __device__ constexpr int w4p_nu(int q, int i) {
 
 // ---- staging (LDS-DMA) shared by whoever issues it: `nw` waves take pieces w, w + nw, ... -------------------------------
 // global float offsets of this wave's raw-patch pieces (lane = slot inside the piece), -1 = padding / beyond the patch
-template <int MAXP>
+template <int MAXP, bool FLAT>
 __device__ __forceinline__ void raw_piece_offsets(const W4PParams& p, int item, int w, int nw, int lane, int* goff) {
+  if constexpr (FLAT) {
+    // strip position -> (fragment, column) -> (image, row, column); slots are skewed by pos / 16 here (a 6-row strip of up to 146
+    // columns has to fit the raw ring next to NT = 3 U slots: 840 positions -> 896 slots with pos / 16, 960 with pos / 8)
+    const FlatItem f = flat_item(p, item);
+    const uint32_t Tend = min((uint32_t)(item % p.nblocks_m) * 32u + 31u, (uint32_t)p.ntiles - 1u);
+    const uint32_t gr_end = fdiv(Tend, p.dTX);
+    const int r_end = (int)gr_end - f.gr0, tx_end = (int)(Tend - gr_end * (uint32_t)p.TX);
+#pragma unroll
+    for (int k = 0; k < MAXP; ++k) {
+      goff[k] = -1;
+      const uint32_t slot = (uint32_t)((w + nw * k) * 64 + lane);
+      const uint32_t k17 = __umulhi(slot, 252645136u);               // slot / 17 (exact for slot < 2^28)
+      const uint32_t r17 = slot - 17 * k17;
+      uint32_t pos = 16 * k17 + r17;
+      asm volatile("" : "+v"(pos));                                    // (see below: keeps the item-invariant part out of the K loop's registers)
+      if (r17 < 16 && pos < (uint32_t)p.npos) {
+        const uint32_t prow = fdiv(pos, p.dPW);
+        const int col = (int)(pos - prow * (uint32_t)p.PW);
+        int r, cx, txs;
+        if (col < f.w0) { r = 0; cx = col; txs = f.tx0; }
+        else {
+          const uint32_t c2 = (uint32_t)(col - f.w0);
+          const uint32_t q = fdiv(c2, p.dFragW);
+          r = 1 + (int)q; cx = (int)(c2 - q * (uint32_t)p.fragW); txs = 0;
+        }
+        const uint32_t gr = (uint32_t)(f.gr0 + r);
+        const uint32_t pb = fdiv(gr, p.dTY);
+        const int ty = (int)(gr - pb * (uint32_t)p.TY);
+        const int iy = 4 * ty - 1 + (int)prow, ix = 4 * txs + cx - 1;
+        // columns the item's tiles of this fragment do not read are left out of the DMA (they stay zero)
+        const bool used = r < r_end || (r == r_end && cx < 4 * (tx_end - txs + 1) + 2);
+        if (used && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
+          goff[k] = (int)((pb * (uint32_t)p.H + (uint32_t)iy) * (uint32_t)p.in_rs) + ix * 16;
+      }
+    }
+    return;
+  }
   const int s0g = (item % p.nblocks_m) * p.NI;
 #pragma unroll
   for (int k = 0; k < MAXP; ++k) {
@@ -206,7 +276,7 @@ __device__ __forceinline__ void raw_piece_offsets(const W4PParams& p, int item, 
 // MFMA waves (they also issue the LDS-DMA of the coming slices in the shadow of their MFMAs: a wave that is stuck behind a
 // busy MFMA pipe issues vector-memory instructions for free, while a producer wave needs ~60 clk per such instruction)
 // ---------------------------------------------------------------------------------------------------------------------
-template <int NT, int Q>
+template <int NT, int Q, bool FLAT>
 __device__ __forceinline__ void w4p_consumer(const W4PParams& p, float4* smem, int grp, int lane, int wave) {
   // this wave's nine positions: w4p_row / w4p_nu (transform rows RA(Q) and RA(Q) + 1)
   const int idx = lane & 15, g = lane >> 4;
@@ -218,10 +288,10 @@ __device__ __forceinline__ void w4p_consumer(const W4PParams& p, float4* smem, i
   const Walk wk = item_walk(p);
   for (int item = wk.first; item < wk.end; item += wk.step) {
     const int nt0 = (item / p.nblocks_m) * NT;
-    const Tile tl = tile_of(p, item, grp, idx);
+    const Tile tl = tile_of<FLAT>(p, item, grp, idx);
     // ---- staging duties of this wave: raw pieces wave, wave + 8 and U pieces wave, wave + 8, ... ------------------------------
     int goff[W4P_MAXP];
-    raw_piece_offsets<W4P_MAXP>(p, item, wave, W4P_NCONS, lane, goff);
+    raw_piece_offsets<W4P_MAXP, FLAT>(p, item, wave, W4P_NCONS, lane, goff);
     bool live[W4P_MAXP];                                    // pieces with at least one in-image position (wave-uniform)
 #pragma unroll
     for (int k = 0; k < W4P_MAXP; ++k) live[k] = __ballot(goff[k] >= 0) != 0ull;
@@ -398,7 +468,7 @@ __device__ __forceinline__ void w4p_consumer(const W4PParams& p, float4* smem, i
 // ---------------------------------------------------------------------------------------------------------------------
 // producer waves: LDS-DMA of the raw patch + U fragments, input transform V = B^T d B for rows 3 RH .. 3 RH + 2
 // ---------------------------------------------------------------------------------------------------------------------
-template <int NT, int RH>
+template <int NT, int RH, bool FLAT>
 __device__ __forceinline__ void w4p_producer(const W4PParams& p, float4* smem, int pw, int lane) {
   const int grp = pw >> 1;
   const int idx = lane >> 2, g = lane & 3;   // transform lane order: 8 tiles x 4 channels per 32-lane half (see w4p_sigma)
@@ -414,7 +484,7 @@ __device__ __forceinline__ void w4p_producer(const W4PParams& p, float4* smem, i
   auto prefetch_item = [&](int item) __attribute__((always_inline)) {
     constexpr int MAXP = 4;                                 // raw pieces pw, pw + 4, ... (rawF4 <= 1024 slots)
     int goff[MAXP];
-    raw_piece_offsets<MAXP>(p, item, pw, W4P_NPROD, lane, goff);
+    raw_piece_offsets<MAXP, FLAT>(p, item, pw, W4P_NPROD, lane, goff);
     const int nt0 = (item / p.nblocks_m) * NT;
 #pragma unroll
     for (int k = 0; k < MAXP; ++k) {
@@ -463,7 +533,7 @@ __device__ __forceinline__ void w4p_producer(const W4PParams& p, float4* smem, i
   for (int item = wk.first; item < wk.end; item += wk.step) {
     const int nt0 = (item / p.nblocks_m) * NT;
     // ---- this lane's (tile, channel) pair: float offsets of its 36 window elements in a raw slot -----------------------
-    const Tile tl = tile_of(p, item, grp, idx);
+    const Tile tl = tile_of<FLAT>(p, item, grp, idx);
     // pos(k, 0) is even (patch width and tile origins are even), so the columns (2c, 2c + 1) of a window row never straddle a
     // multiple of 8 in the skewed slot order: their slots are neighbours (16 B apart) and ONE ds_read2_b32 fetches the pair
     // into a 64-bit register pair = one operand of the packed-fp32 transform below.  18 addresses / reads instead of 36.
@@ -473,7 +543,7 @@ __device__ __forceinline__ void w4p_producer(const W4PParams& p, float4* smem, i
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
         const int pos = tl.base + k * p.PW + 2 * c;
-        woff[k][c] = (pos + (pos >> 3)) * 4 + g;
+        woff[k][c] = (pos + (pos >> (FLAT ? 4 : 3))) * 4 + g;
       }
     f32x2 d[6][3];                                            // the window of the slice that is transformed next (column pairs)
     auto load_window = [&](int rslot) {
@@ -568,7 +638,7 @@ __device__ __forceinline__ void w4p_producer(const W4PParams& p, float4* smem, i
   }
 }
 
-template <int NT>
+template <int NT, bool FLAT>
 __global__ void __launch_bounds__(768)
 conv_wino4p_kernel(const W4PParams p) {
   extern __shared__ float4 smem[];
@@ -576,21 +646,42 @@ conv_wino4p_kernel(const W4PParams p) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   if (wave < W4P_NCONS) {
     const int grp = wave >> 2, q = wave & 3;
-    if (q == 0) w4p_consumer<NT, 0>(p, smem, grp, lane, wave);
-    else if (q == 1) w4p_consumer<NT, 1>(p, smem, grp, lane, wave);
-    else if (q == 2) w4p_consumer<NT, 2>(p, smem, grp, lane, wave);
-    else w4p_consumer<NT, 3>(p, smem, grp, lane, wave);
+    if (q == 0) w4p_consumer<NT, 0, FLAT>(p, smem, grp, lane, wave);
+    else if (q == 1) w4p_consumer<NT, 1, FLAT>(p, smem, grp, lane, wave);
+    else if (q == 2) w4p_consumer<NT, 2, FLAT>(p, smem, grp, lane, wave);
+    else w4p_consumer<NT, 3, FLAT>(p, smem, grp, lane, wave);
   } else {
     const int pw = wave - W4P_NCONS;
-    if (pw & 1) w4p_producer<NT, 1>(p, smem, pw, lane);
-    else w4p_producer<NT, 0>(p, smem, pw, lane);
+    if (pw & 1) w4p_producer<NT, 1, FLAT>(p, smem, pw, lane);
+    else w4p_producer<NT, 0, FLAT>(p, smem, pw, lane);
   }
 }
 
 struct W4PLayout { int uoff, voff, xoff, totalF4; };
-bool w4p_geo(const ConvDesc& d, const ConvCfg& cfg, w4::Geo* g, W4PLayout* L) {
+// FLAT items (cfg.NI == 0, cfg.R == 4): 32 consecutive tiles per item, strip patch (see tile_of).  Geo fields reused: TX, PW, npos,
+// rawF4 (skew pos / 16), S = number of items along m; R = 4, PR = 6; tps / nbands / NI unused.
+struct FlatGeo { int TY, ntiles, fragW; };
+bool flat_geo(const ConvDesc& d, const ConvCfg& cfg, w4::Geo* g, FlatGeo* f) {
+  if (cfg.R != 4 || cfg.NI != 0) return false;
+  g->TX = (d.W + 3) / 4;
+  f->TY = (d.H + 3) / 4;
+  if ((long)d.B * g->TX * f->TY >= (1L << 24)) return false;       // (fdiv is exact for n * d < 2^32)
+  f->ntiles = d.B * g->TX * f->TY;
+  f->fragW = 4 * g->TX + 2;
+  const int fmax = (g->TX - 1 + 32 + g->TX - 1) / g->TX;        // tile-row fragments of an item that starts in the last column
+  g->R = 4; g->NI = 0; g->nbands = f->TY; g->PR = 6; g->tps = g->TX;
+  g->PW = 128 + 2 * fmax;
+  g->npos = 6 * g->PW;
+  g->rawF4 = (g->npos + g->npos / 16 + 1 + 63) & ~63;
+  g->S = (f->ntiles + 31) / 32;
+  if ((long)d.B * d.H * d.W * std::max(std::max(d.in_cs, d.out_cs), d.res_cs) >= (1L << 31)) return false;
+  return true;
+}
+bool w4p_geo(const ConvDesc& d, const ConvCfg& cfg, w4::Geo* g, W4PLayout* L, FlatGeo* fg = nullptr) {
   if (d.ks != 3 || d.stride != 1 || cfg.NT < 1 || cfg.NT > 3 || cfg.WM != 2 || cfg.WN != 4 || d.Cin % 16 || d.Cout % 16) return false;
-  if (!w4::geo(d, cfg, 32, g)) return false;
+  FlatGeo ftmp;
+  if (cfg.NI == 0) { if (!flat_geo(d, cfg, g, fg ? fg : &ftmp)) return false; }
+  else if (!w4::geo(d, cfg, 32, g)) return false;
   if (g->rawF4 > W4P_NCONS * W4P_MAXP * 64) return false;
   const int uF4 = cfg.NT * W4P_UBLK, vF4 = 2 * W4P_UBLK;
   L->uoff = 3 * g->rawF4;
@@ -642,9 +733,12 @@ size_t conv_wino4p_lds_bytes(const ConvDesc& d, const ConvCfg& cfg) {
 int conv_wino4p_launch(const ConvDesc& d, const ConvCfg& cfg, hipStream_t stream) {
   w4::Geo g;
   W4PLayout L;
-  if (!w4p_geo(d, cfg, &g, &L) || !d.wfrag_wino4p) {
+  FlatGeo fg{};
+  const bool flat = cfg.NI == 0;
+  if (!w4p_geo(d, cfg, &g, &L, &fg) || !d.wfrag_wino4p) {
     poco_set_error("conv(winograd 4x4, specialised waves): needs ks = 3, stride 1, NT 1..3, WM = 2, WN = 4, R % 4 == 0, "
-                   "NI*(R/4)*ceil(W/4) <= 32 tiles, a patch of <= 1024 slots and the ALG 8 weight fragments");
+                   "NI*(R/4)*ceil(W/4) <= 32 tiles (or R = 4, NI = 0: flat items), a patch of <= 1024 slots that fits the LDS next "
+                   "to the U ring, and the ALG 8 weight fragments");
     return POCO_ERR_ARG;
   }
   if (d.act == 3 || d.act == 2) { poco_set_error("conv(winograd 4x4): activation must be none or ReLU"); return POCO_ERR_ARG; }
@@ -661,7 +755,11 @@ int conv_wino4p_launch(const ConvDesc& d, const ConvCfg& cfg, hipStream_t stream
   p.uoff = L.uoff; p.voff = L.voff; p.xoff = L.xoff;
   p.dPW = make_fastdiv(g.PW); p.dSlab = make_fastdiv(g.PR * g.PW); p.dBands = make_fastdiv(g.nbands);
   p.dTX = make_fastdiv(g.TX); p.dTslab = make_fastdiv(g.tps);
-  p.nblocks_m = (g.S + g.NI - 1) / g.NI; p.nb_n = (p.nT16 + cfg.NT - 1) / cfg.NT;
+  p.nblocks_m = flat ? g.S : (g.S + g.NI - 1) / g.NI; p.nb_n = (p.nT16 + cfg.NT - 1) / cfg.NT;
+  if (flat) {
+    p.TY = fg.TY; p.ntiles = fg.ntiles; p.fragW = fg.fragW;
+    p.dTY = make_fastdiv(fg.TY); p.dFragW = make_fastdiv(fg.fragW);
+  }
   // balanced persistent grid: every block walks the same number of items (one block per CU)
   // cfg.MT = CU share divisor: the grid is sized for (CUs of the device) / MT.  A block needs a whole CU (LDS), all blocks of a launch run
   // their K loops (MFMA-bound, HBM nearly idle) and their store phases (HBM-write-bound, MFMA idle) in lockstep; two launches
@@ -677,13 +775,14 @@ int conv_wino4p_launch(const ConvDesc& d, const ConvCfg& cfg, hipStream_t stream
   long g4 = (items + rounds - 1) / rounds;
   if (g4 > 8) g4 = std::min(cus, (g4 + 7) / 8 * 8);            // multiple of 8 for the XCD-aware walk
   const size_t lds = (size_t)L.totalF4 * sizeof(float4);
-  auto fn = cfg.NT == 3 ? conv_wino4p_kernel<3> : cfg.NT == 2 ? conv_wino4p_kernel<2> : conv_wino4p_kernel<1>;
+  auto fn = flat ? (cfg.NT == 3 ? conv_wino4p_kernel<3, true> : cfg.NT == 2 ? conv_wino4p_kernel<2, true> : conv_wino4p_kernel<1, true>)
+                 : (cfg.NT == 3 ? conv_wino4p_kernel<3, false> : cfg.NT == 2 ? conv_wino4p_kernel<2, false> : conv_wino4p_kernel<1, false>);
   if (lds > 64 * 1024) {
-    static thread_local bool configured[4] = {false, false, false, false};
-    if (!configured[cfg.NT]) {
+    static thread_local bool configured[8] = {};
+    if (!configured[cfg.NT + (flat ? 4 : 0)]) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       if (e != hipSuccess) { poco_set_error(std::string("hipFuncSetAttribute: ") + hipGetErrorString(e)); return POCO_ERR_HIP; }
-      configured[cfg.NT] = true;
+      configured[cfg.NT + (flat ? 4 : 0)] = true;
     }
   }
   hipLaunchKernelGGL(fn, dim3((unsigned)g4, 1), dim3(768), lds, stream, p);

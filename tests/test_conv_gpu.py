@@ -398,6 +398,41 @@ def test_conv_winograd_f4x4(case, nt, alg, cuda):
     assert np.abs(out - ref).max() <= 2e-4 * max(1.0, np.abs(ref).max())
 
 
+@pytest.mark.parametrize("nt", [1, 2, 3])
+@pytest.mark.parametrize("case", WINO4 + [(64, 28, 28, 16, 32, True), (9, 56, 56, 16, 16, False), (33, 14, 14, 32, 32, True)],
+                         ids=lambda c: "x".join(map(str, c)))
+def test_conv_winograd_f4x4_flat_items(case, nt, cuda):
+    """ALG 8 with FLAT items (round 4, cfg R = 4, NI = 0): a block's 32 MFMA tile columns carry 32 CONSECUTIVE tiles of the flattened
+    (image, tile row, tile column) order instead of a rectangle of 2 x 14 / 4 x 7 tiles, the patch is a 6-row strip of tile-row
+    fragments.  Items start anywhere in a tile row, span up to nine fragments and two images, the last item is partial; planes whose
+    strip does not fit the LDS next to the U ring at this NT must be refused, everything else must equal the fp64 conv."""
+    from poco_amd import ops
+    B, H, W, Cin, Cout, has_res = case
+    cfg = (1, nt, 2, 4, 4, 0, 8)
+    TX = (W + 3) // 4
+    fmax = (TX - 1 + 32 + TX - 1) // TX
+    npos = 6 * (128 + 2 * fmax)
+    raw = (npos + npos // 16 + 1 + 63) // 64 * 64
+    fits = raw <= 1024 and (3 * raw + 3 * nt * 576 + 4 * 576) * 16 <= 160 * 1024
+    rng = np.random.default_rng(B * 131 + Cin + Cout + nt)
+    x = rng.standard_normal((B, H, W, Cin)).astype(np.float32)
+    w = (rng.standard_normal((Cout, Cin, 3, 3)) / np.sqrt(9 * Cin)).astype(np.float32)
+    scale = rng.uniform(0.5, 1.5, Cout).astype(np.float32)
+    shift = rng.uniform(-0.5, 0.5, Cout).astype(np.float32)
+    res = rng.standard_normal((B, H, W, Cout)).astype(np.float32) if has_res else None
+    args = (torch.from_numpy(x).to(cuda), w, scale, shift, 1, None if res is None else torch.from_numpy(res).to(cuda), True)
+    if not fits:
+        with pytest.raises(RuntimeError):
+            ops.conv2d_nhwc(*args, cfg=cfg)
+        return
+    out = ops.conv2d_nhwc(*args, cfg=cfg).cpu().numpy()
+    ref = _ref(x, w, scale, shift, 1, res, True)
+    assert np.abs(out - ref).max() <= 2e-4 * max(1.0, np.abs(ref).max()), np.abs(out - ref).max()
+    # bitwise the rectangular-item result: same arithmetic per tile, only the assignment of tiles to blocks differs
+    rect = ops.conv2d_nhwc(*args, cfg=_wino4_cfg(H, W, nt, 8)).cpu().numpy()
+    assert np.array_equal(out, rect)
+
+
 # ------------------------------------------------------------------------------------------------------------
 # Table-driven: every (shape, cfg) pair the engine actually runs at the bench batch sizes
 # ------------------------------------------------------------------------------------------------------------
