@@ -51,8 +51,7 @@ struct W4PParams {
   int R, NI, S, nbands, TX, PR, PW, npos, rawF4, tiles_per_slab;
   int nblocks_m, nb_n;   // work items walked by the persistent blocks: slab groups x n-tile groups
   int act, res_after_act;
-  int uoff, voff, xoff;  // float4 offsets of the U ring, V buffer 0 and the exchange area in LDS (raw ring at 0)
-  int v1off;             // V buffer 1: never overlaid by the exchange area (the producers write the NEXT item's V(0) into it during the rounds)
+  int uoff, voff, xoff;  // float4 offsets of the U ring, the V double buffer and the exchange area in LDS (raw ring at 0)
   FastDiv dPW, dSlab, dBands, dTX, dTslab;
   // FLAT items (cfg.NI == 0, see flat_geo): TY tile rows per image, ntiles = B * TX * TY tiles in all, fragW = 4 TX + 2
   int TY, ntiles, fragW;
@@ -292,10 +291,7 @@ __device__ __forceinline__ void w4p_consumer(const W4PParams& p, float4* smem, i
     const Tile tl = tile_of<FLAT>(p, item, grp, idx);
     // ---- staging duties of this wave: raw pieces wave, wave + 8 and U pieces wave, wave + 8, ... ------------------------------
     int goff[W4P_MAXP];
-    // raw pieces go to the waves in REVERSE order (rw = 7 - wave): the U pieces give waves 0-2 one piece more than the others, the raw
-    // pieces waves 7, 6, ... - every SIMD (waves w and w + 4) then issues the same number of MFMA-blocking DMA pieces per slice
-    const int rw = W4P_NCONS - 1 - wave;
-    raw_piece_offsets<W4P_MAXP, FLAT>(p, item, rw, W4P_NCONS, lane, goff);
+    raw_piece_offsets<W4P_MAXP, FLAT>(p, item, wave, W4P_NCONS, lane, goff);
     bool live[W4P_MAXP];                                    // pieces with at least one in-image position (wave-uniform)
 #pragma unroll
     for (int k = 0; k < W4P_MAXP; ++k) live[k] = __ballot(goff[k] >= 0) != 0ull;
@@ -307,7 +303,7 @@ __device__ __forceinline__ void w4p_consumer(const W4PParams& p, float4* smem, i
       const unsigned sb = lds_base + (unsigned)(slot * rawF4) * 16u;
 #pragma unroll
       for (int k = 0; k < W4P_MAXP; ++k) {
-        const int piece = rw + W4P_NCONS * k;
+        const int piece = wave + W4P_NCONS * k;
         if (piece < npieces_raw && live[k]) {
           if (goff[k] >= 0)
             w4::dma16_sv(sbase, (unsigned)goff[k] * 4u, (unsigned)__builtin_amdgcn_readfirstlane((int)(sb + (unsigned)piece * 1024u)));
@@ -343,11 +339,8 @@ __device__ __forceinline__ void w4p_consumer(const W4PParams& p, float4* smem, i
     unsigned long long tr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
     W4P_T(c_a);
-    // Round 4: the producers fetched raw(0..2) and U(0) of this item during the previous item's exchange rounds AND transformed its
-    // slice 0 into V buffer 1 (which the exchange area never touches) between the last two barriers of those rounds, with the window
-    // of slice 1 already in their registers: an item starts with ONE barrier instead of fetch-wait -> B0 -> window + transform -> B1
-    // (~1.5 us per item of ~25; only a launch's first item still pays B0).  U(1) is requested now and awaited at the end of slice 0.
-    if (item == wk.first) __syncthreads();                  // B0 (first item of the launch only): its first fetches have landed
+    // (the producers fetched raw(0..2), U(0) during the previous item's exchange rounds and U(1) just now)
+    __syncthreads();                                        // B0: the first fetches have landed (and the padding slots are zero)
     __syncthreads();                                        // B1: V(0) is written; the windows of slices 0 and 1 are in the producers' registers
     if (S > 3) issue_raw(3, 0);
     W4P_T(c_b);
@@ -358,7 +351,7 @@ __device__ __forceinline__ void w4p_consumer(const W4PParams& p, float4* smem, i
       const int r1 = ring == 2 ? 0 : ring + 1, r2 = r1 == 2 ? 0 : r1 + 1;
       int nvm = 0;
       const float4* U = smem + p.uoff + ring * uF4 + (2 * Q) * 64 + lane;
-      const float4* V = smem + ((s & 1) ? p.voff : p.v1off) + grp * W4P_UBLK + (2 * Q) * 64 + vlane;      // V(s) lives in buffer (s + 1) & 1
+      const float4* V = smem + p.voff + (s & 1) * (2 * W4P_UBLK) + grp * W4P_UBLK + (2 * Q) * 64 + vlane;
       const bool noread = (W4P_EXP & 8) != 0;
       const float4 vq0 = noread ? make_float4(1.f, 2.f, 3.f, (float)s) : V[0], vq1 = noread ? make_float4(1.f, 2.f, 3.f, 4.f) : V[64];
       const float vs = noread ? 2.f : reinterpret_cast<const float*>(V - (2 * Q) * 64 - vlane + 512)[Q * 64 + vlane];
@@ -537,13 +530,14 @@ __device__ __forceinline__ void w4p_producer(const W4PParams& p, float4* smem, i
   // With a higher issue priority the producer's instructions slot in between their MFMAs and its stalls cost nothing.
   if (!(W4P_EXP & 32)) __builtin_amdgcn_s_setprio(3);
 
-  // ---- this lane's (tile, channel) pair of an item: float offsets of its 36 window elements in a raw slot --------------------
-  // pos(k, 0) is even (patch width and tile origins are even), so the columns (2c, 2c + 1) of a window row never straddle a
-  // multiple of 8 (16) in the skewed slot order: their slots are neighbours (16 B apart) and ONE ds_read2_b32 fetches the pair
-  // into a 64-bit register pair = one operand of the packed-fp32 transform below.  18 addresses / reads instead of 36.
-  int woff[6][3];
-  auto setup_item = [&](int item) __attribute__((always_inline)) {
+  for (int item = wk.first; item < wk.end; item += wk.step) {
+    const int nt0 = (item / p.nblocks_m) * NT;
+    // ---- this lane's (tile, channel) pair: float offsets of its 36 window elements in a raw slot -----------------------
     const Tile tl = tile_of<FLAT>(p, item, grp, idx);
+    // pos(k, 0) is even (patch width and tile origins are even), so the columns (2c, 2c + 1) of a window row never straddle a
+    // multiple of 8 in the skewed slot order: their slots are neighbours (16 B apart) and ONE ds_read2_b32 fetches the pair
+    // into a 64-bit register pair = one operand of the packed-fp32 transform below.  18 addresses / reads instead of 36.
+    int woff[6][3];
 #pragma unroll
     for (int k = 0; k < 6; ++k)
 #pragma unroll
@@ -551,75 +545,66 @@ __device__ __forceinline__ void w4p_producer(const W4PParams& p, float4* smem, i
         const int pos = tl.base + k * p.PW + 2 * c;
         woff[k][c] = (pos + (pos >> (FLAT ? 4 : 3))) * 4 + g;
       }
-  };
-  f32x2 d[6][3];                                            // the window of the slice that is transformed next (column pairs)
-  auto load_window = [&](int rslot) __attribute__((always_inline)) {
-    const float* rawf = reinterpret_cast<const float*>(smem + rslot * rawF4);
+    f32x2 d[6][3];                                            // the window of the slice that is transformed next (column pairs)
+    auto load_window = [&](int rslot) {
+      const float* rawf = reinterpret_cast<const float*>(smem + rslot * rawF4);
 #pragma unroll
-    for (int k = 0; k < 6; ++k)
+      for (int k = 0; k < 6; ++k)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const float* w = rawf + woff[k][c];
+          d[k][c] = (f32x2){w[0], w[4]};
+        }
+    };
+    // V = B^T d B in packed fp32 (v_pk_fma_f32 / v_pk_add_f32: half the issue slots of scalar VALU, and fp32 MFMAs share the
+    // vector ALUs with it).  Stage 1 (down the window columns) works on the column pairs as they were read; stage 2 (along a
+    // row) produces the pairs (nu0, nu5), (nu1, nu3), (nu2, nu4): 18 + 21 packed instructions for this wave's 18 positions.
+    auto transform = [&](int vbuf) {                          // d -> rows 3 RH .. 3 RH + 2 of V (18 positions) of group grp
+      f32x2 t[3][3];
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
-        const float* w = rawf + woff[k][c];
-        d[k][c] = (f32x2){w[0], w[4]};
+        const f32x2 d0 = d[0][c], d1 = d[1][c], d2 = d[2][c], d3 = d[3][c], d4 = d[4][c], d5 = d[5][c];
+        if constexpr (RH == 0) {
+          t[0][c] = pk_fma(d0, 4.f, pk_fma(d2, -5.f, d4));                       // 4 d0 - 5 d2 + d4
+          const f32x2 a = pk_fma(d2, -4.f, d4), cc = pk_fma(d1, 4.f, -d3);       // rows 1, 2 = (d4 - 4 d2) -+ (4 d1 - d3)
+          t[1][c] = a - cc;
+          t[2][c] = a + cc;
+        } else {
+          const f32x2 b = d4 - d2, e = d1 - d3;                                  // rows 3, 4 = (d4 - d2) -+ 2 (d1 - d3)
+          t[0][c] = pk_fma(e, -2.f, b);
+          t[1][c] = pk_fma(e, 2.f, b);
+          t[2][c] = pk_fma(d1, 4.f, pk_fma(d3, -5.f, d5));                       // 4 d1 - 5 d3 + d5
+        }
       }
-  };
-  // V = B^T d B in packed fp32 (v_pk_fma_f32 / v_pk_add_f32: half the issue slots of scalar VALU, and fp32 MFMAs share the
-  // vector ALUs with it).  Stage 1 (down the window columns) works on the column pairs as they were read; stage 2 (along a
-  // row) produces the pairs (nu0, nu5), (nu1, nu3), (nu2, nu4): 18 + 21 packed instructions for this wave's 18 positions.
-  auto transform = [&](int vbuf) __attribute__((always_inline)) {      // d -> rows 3 RH .. 3 RH + 2 of V (18 positions) of group grp, into V buffer vbuf
-    f32x2 t[3][3];
+      f32x2 A[3], Bp[3], Cp[3];                               // per row: (v0, v5), (v1, v3), (v2, v4)
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      const f32x2 d0 = d[0][c], d1 = d[1][c], d2 = d[2][c], d3 = d[3][c], d4 = d[4][c], d5 = d[5][c];
-      if constexpr (RH == 0) {
-        t[0][c] = pk_fma(d0, 4.f, pk_fma(d2, -5.f, d4));                       // 4 d0 - 5 d2 + d4
-        const f32x2 a = pk_fma(d2, -4.f, d4), cc = pk_fma(d1, 4.f, -d3);       // rows 1, 2 = (d4 - 4 d2) -+ (4 d1 - d3)
-        t[1][c] = a - cc;
-        t[2][c] = a + cc;
-      } else {
-        const f32x2 b = d4 - d2, e = d1 - d3;                                  // rows 3, 4 = (d4 - d2) -+ 2 (d1 - d3)
-        t[0][c] = pk_fma(e, -2.f, b);
-        t[1][c] = pk_fma(e, 2.f, b);
-        t[2][c] = pk_fma(d1, 4.f, pk_fma(d3, -5.f, d5));                       // 4 d1 - 5 d3 + d5
+      for (int r = 0; r < 3; ++r) {
+        const f32x2 T0 = t[r][0], T1 = t[r][1], T2 = t[r][2];
+        A[r] = pk_fma(T0, 4.f, pk_fma(T1, -5.f, T2));                            // 4 t0 - 5 t2 + t4 | 4 t1 - 5 t3 + t5
+        const f32x2 ab = pk_fma2(T1.xx, (f32x2){-4.f, -1.f}, T2.xx);             // t4 - 4 t2 | t4 - t2
+        const f32x2 cf = pk_fma2(T0.yy, (f32x2){4.f, 2.f}, T1.yy * (f32x2){-1.f, -2.f});   // 4 t1 - t3 | 2 t1 - 2 t3
+        Bp[r] = ab - cf;
+        Cp[r] = ab + cf;
       }
-    }
-    f32x2 A[3], Bp[3], Cp[3];                               // per row: (v0, v5), (v1, v3), (v2, v4)
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-      const f32x2 T0 = t[r][0], T1 = t[r][1], T2 = t[r][2];
-      A[r] = pk_fma(T0, 4.f, pk_fma(T1, -5.f, T2));                            // 4 t0 - 5 t2 + t4 | 4 t1 - 5 t3 + t5
-      const f32x2 ab = pk_fma2(T1.xx, (f32x2){-4.f, -1.f}, T2.xx);             // t4 - 4 t2 | t4 - t2
-      const f32x2 cf = pk_fma2(T0.yy, (f32x2){4.f, 2.f}, T1.yy * (f32x2){-1.f, -2.f});   // 4 t1 - t3 | 2 t1 - 2 t3
-      Bp[r] = ab - cf;
-      Cp[r] = ab + cf;
-    }
-    // slot order of the MFMA waves q = 2 RH and 2 RH + 1: see w4p_nu
-    float4* Vg = smem + (vbuf ? p.v1off : p.voff) + grp * W4P_UBLK;
-    float* Vs = reinterpret_cast<float*>(Vg + 512);
-    constexpr int qa = 2 * RH, qb = 2 * RH + 1;
-    Vg[(2 * qa) * 64 + vlane] = make_float4(A[0].x, A[0].y, Bp[0].x, Bp[0].y);
-    Vg[(2 * qa + 1) * 64 + vlane] = make_float4(Cp[0].x, Cp[0].y, A[1].x, A[1].y);
-    Vs[qa * 64 + vlane] = Bp[1].x;
-    Vs[qb * 64 + vlane] = Bp[1].y;
-    Vg[(2 * qb) * 64 + vlane] = make_float4(Cp[1].x, Cp[1].y, A[2].x, A[2].y);
-    Vg[(2 * qb + 1) * 64 + vlane] = make_float4(Bp[2].x, Bp[2].y, Cp[2].x, Cp[2].y);
-  };
-  const int S = p.nC4;
-  // front of an item: V(0) -> buffer 1, window of slice 1 into the registers (its raw(0..2) have landed and are visible)
-  auto item_front = [&](int item) __attribute__((always_inline)) {
-    setup_item(item);
-    load_window(0);
-    transform(1);
-    if (S > 1) load_window(1);
-  };
-  if (wk.first < wk.end) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();                                        // B0 of the launch's first item: raw(0..2), U(0) have landed
-    item_front(wk.first);
-  }
+      // slot order of the MFMA waves q = 2 RH and 2 RH + 1: see w4p_nu
+      float4* Vg = smem + p.voff + vbuf * (2 * W4P_UBLK) + grp * W4P_UBLK;
+      float* Vs = reinterpret_cast<float*>(Vg + 512);
+      constexpr int qa = 2 * RH, qb = 2 * RH + 1;
+      Vg[(2 * qa) * 64 + vlane] = make_float4(A[0].x, A[0].y, Bp[0].x, Bp[0].y);
+      Vg[(2 * qa + 1) * 64 + vlane] = make_float4(Cp[0].x, Cp[0].y, A[1].x, A[1].y);
+      Vs[qa * 64 + vlane] = Bp[1].x;
+      Vs[qb * 64 + vlane] = Bp[1].y;
+      Vg[(2 * qb) * 64 + vlane] = make_float4(Cp[1].x, Cp[1].y, A[2].x, A[2].y);
+      Vg[(2 * qb + 1) * 64 + vlane] = make_float4(Bp[2].x, Bp[2].y, Cp[2].x, Cp[2].y);
+    };
 
-  for (int item = wk.first; item < wk.end; item += wk.step) {
-    if (S > 1) issue_u1(item);                              // (its ring slot lies under the exchange area, free since the last barrier)
+    const int S = p.nC4;
+    if (S > 1) issue_u1(item);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                        // B0: raw(0..2), U(0..1) have landed
+    load_window(0);
+    transform(0);
+    if (S > 1) load_window(1);
     __syncthreads();                                        // B1 (the compiler waits for this wave's LDS accesses before a barrier)
     int ring = 0;                                           // s % 3
 #if W4P_TRACE
@@ -629,13 +614,12 @@ __device__ __forceinline__ void w4p_producer(const W4PParams& p, float4* smem, i
     for (int s = 0; s < S; ++s) {
       const int r1 = ring == 2 ? 0 : ring + 1, r2 = r1 == 2 ? 0 : r1 + 1;
       W4P_T(q0);
-      // V(s+1) (-> buffer s & 1) from the window fetched during the previous iteration, then the window of slice s+2 (raw(s+2)
-      // landed before the barrier that ended iteration s-1)
-      if (s + 1 < S && !(W4P_EXP & 17)) transform(s & 1);
+      // V(s+1) from the window fetched during the previous iteration, then the window of slice s+2 (raw(s+2) landed before the
+      // barrier that ended iteration s-1)
+      if (s + 1 < S && !(W4P_EXP & 17)) transform((s + 1) & 1);
       W4P_T(q1);
       if (s + 2 < S && !(W4P_EXP & (17 | 128))) load_window(r2);
       W4P_T(q4);
-      if (s == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // U(1), requested at the top of the item
       ring = r1;
       __syncthreads();
       W4P_T(q6);
@@ -647,17 +631,10 @@ __device__ __forceinline__ void w4p_producer(const W4PParams& p, float4* smem, i
       g_w4p_trace[32 + 4 * pw] = tr[0]; g_w4p_trace[33 + 4 * pw] = tr[3]; g_w4p_trace[34 + 4 * pw] = tr[5];
     }
 #endif
-    // ... while the MFMA waves exchange and store: fetch the next item's first slices, and between the last two barriers of the
-    // rounds (2 NT + 1 in all) turn its slice 0 into V(0) (buffer 1 is not under the exchange area) and read the window of slice 1
-    const bool has_next = item + wk.step < wk.end;
-    if (has_next) prefetch_item(item + wk.step);
-    constexpr int NB = 2 * NT + 1;
+    if (item + wk.step < wk.end) prefetch_item(item + wk.step);          // ... while the MFMA waves exchange and store
 #pragma unroll
-    for (int j = 0; j < NB; ++j) {
-      if (j == NB - 2 && has_next) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's share of the fetches has landed ...
-      __syncthreads();                                                                   // ... everybody's is visible after this barrier
-      if (j == NB - 2 && has_next) item_front(item + wk.step);
-    }
+    for (int n = 0; n < NT; ++n) { __syncthreads(); __syncthreads(); }   // the MFMA waves' exchange rounds
+    __syncthreads();
   }
 }
 
@@ -680,7 +657,7 @@ conv_wino4p_kernel(const W4PParams p) {
   }
 }
 
-struct W4PLayout { int uoff, voff, xoff, v1off, totalF4; };
+struct W4PLayout { int uoff, voff, xoff, totalF4; };
 // FLAT items (cfg.NI == 0, cfg.R == 4): 32 consecutive tiles per item, strip patch (see tile_of).  Geo fields reused: TX, PW, npos,
 // rawF4 (skew pos / 16), S = number of items along m; R = 4, PR = 6; tps / nbands / NI unused.
 struct FlatGeo { int TY, ntiles, fragW; };
@@ -709,12 +686,11 @@ bool w4p_geo(const ConvDesc& d, const ConvCfg& cfg, w4::Geo* g, W4PLayout* L, Fl
   const int uF4 = cfg.NT * W4P_UBLK, vF4 = 2 * W4P_UBLK;
   L->uoff = 3 * g->rawF4;
   L->voff = L->uoff + 3 * uF4;
-  // the exchange area overlays U ring slots 1, 2 and (part of) V buffer 0 (slot 0 and the raw ring receive the next item's first
-  // fetches during the exchange rounds); V buffer 1 sits behind whichever ends later, because the producers write the next item's
-  // V(0) into it while the rounds are still running
+  const int end = L->voff + 2 * vF4;
+  // the exchange area overlays U ring slots 1, 2 and the V buffers (slot 0 and the raw ring may receive the next item's
+  // first fetches during the exchange rounds) and extends past them when they are smaller than 64 KiB (NT = 1)
   L->xoff = L->uoff + uF4;
-  L->v1off = std::max(L->voff + vF4, L->xoff + W4P_XCH);
-  L->totalF4 = L->v1off + vF4;
+  L->totalF4 = std::max(end, L->xoff + W4P_XCH);
   return (size_t)L->totalF4 * sizeof(float4) <= 160 * 1024;
 }
 
@@ -776,7 +752,7 @@ int conv_wino4p_launch(const ConvDesc& d, const ConvCfg& cfg, hipStream_t stream
   p.R = g.R; p.NI = g.NI; p.S = g.S; p.nbands = g.nbands; p.TX = g.TX; p.PR = g.PR; p.PW = g.PW; p.npos = g.npos; p.rawF4 = g.rawF4;
   p.tiles_per_slab = g.tps;
   p.act = d.act; p.res_after_act = d.res_after_act;
-  p.uoff = L.uoff; p.voff = L.voff; p.xoff = L.xoff; p.v1off = L.v1off;
+  p.uoff = L.uoff; p.voff = L.voff; p.xoff = L.xoff;
   p.dPW = make_fastdiv(g.PW); p.dSlab = make_fastdiv(g.PR * g.PW); p.dBands = make_fastdiv(g.nbands);
   p.dTX = make_fastdiv(g.TX); p.dTslab = make_fastdiv(g.tps);
   p.nblocks_m = flat ? g.S : (g.S + g.NI - 1) / g.NI; p.nb_n = (p.nT16 + cfg.NT - 1) / cfg.NT;
