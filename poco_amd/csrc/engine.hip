@@ -104,6 +104,7 @@ struct EngineOpts {
   bool split_f16 = false;  // EXPERIMENT (never the default): plain 1x1 convs on the split-fp16 GEMM (gemm1x1h.hip)
   int seq_mask = 0;        // bit mask: run the tagged kind of parallel region on one lane
   std::string branch_lanes = "0123";   // HR branch i runs on lane branch_lanes[i]
+  int wg_max_plane = 8;    // ALG 11 (F(4x4) as 36 position GEMMs, V / M staged in memory) is offered for planes up to this size (<= 16)
   int flow_ctx_rows = 0;   // context rows the RealNVP scratch is planned for at finalize (0 = max_batch: one context per crop)
   int rec_kinematic = 1;   // poco_outputs_t.record: kinematic accumulation of the per-joint uncertainty (KINEMATIC_UNCERT)
   float rec_thr = 0.40f;   // ... and the sensitivity threshold of get_global_uncert (poco_utils.py:50)
@@ -134,6 +135,7 @@ static bool parse_opts(const char* str, EngineOpts* o, std::string* err) {
     else if (k == "seq_phases") o->seq_mask = atoi(v.c_str());
     else if (k == "branch_lanes") o->branch_lanes = v;
     else if (k == "flow_ctx_rows") o->flow_ctx_rows = atoi(v.c_str());
+    else if (k == "wg_max_plane") o->wg_max_plane = std::min(16, std::max(1, atoi(v.c_str())));
     else if (k == "record_kinematic") o->rec_kinematic = on;
     else if (k == "record_thr") o->rec_thr = (float)atof(v.c_str());
     else { *err = "unknown engine option '" + k + "'"; return false; }
@@ -403,7 +405,7 @@ struct Builder {
           conv_wino4p_pack_weights(wp, scale.data(), Cout, Cin, Cout16, pu4.data());     // same size, other order
           op.wdev_wino4p = upload(pu4);
         }
-        if (ain.H <= 8 && ain.W <= 8 && ain.H * ain.W > 1 && actfn <= 1) {      // 7x7 planes: F(4x4,3x3) as 36 position GEMMs (ALG 11)
+        if (ain.H <= e.opts.wg_max_plane && ain.W <= e.opts.wg_max_plane && ain.H * ain.W > 1 && actfn <= 1) {      // 7x7 planes: F(4x4,3x3) as 36 position GEMMs (ALG 11)
           std::vector<float> pg(conv_wino4g_packed_floats(Cin, Cout16));
           conv_wino4g_pack_weights(wp, scale.data(), Cout, Cin, Cout16, pg.data());
           op.wdev_wino4g = upload(pg);
@@ -1779,7 +1781,7 @@ extern "C" int poco_set_conv_cfg(poco_handle_t h, int op_index, int B, const int
       ((c.ALG == 3 || c.ALG == 4) && (op.actfn == 3 || op.actfn == 2)) ||
       (c.ALG == 7 && ((op.wdev_wino4 == nullptr && e->finalized) || ai.H < 28 || ai.W < 28 || op.actfn >= 2)) ||
       (c.ALG == 8 && ((op.wdev_wino4p == nullptr && e->finalized) || ai.H < 14 || ai.W < 14 || op.actfn >= 2)) ||
-      (c.ALG == 11 && ((op.wdev_wino4g == nullptr && e->finalized) || ai.H > 8 || ai.W > 8 || ai.H * ai.W <= 1 || op.actfn >= 2))) {     // (its scratch is sized for max_batch; poco_forward refuses larger batches)
+      (c.ALG == 11 && ((op.wdev_wino4g == nullptr && e->finalized) || ai.H > e->opts.wg_max_plane || ai.W > e->opts.wg_max_plane || ai.H * ai.W <= 1 || op.actfn >= 2))) {     // (its scratch is sized for max_batch; poco_forward refuses larger batches)
     poco_set_error("poco_set_conv_cfg: configuration does not fit op '" + op.name + "' at this batch size");
     return POCO_ERR_ARG;
   }

@@ -154,6 +154,14 @@ def candidates(B, H, W, Cin, Cout, ks, stride, lds_cap=150 * 1024) -> List[Tuple
                     tot = max(3 * raw + 3 * u + 2 * v, 3 * raw + u + 4096)
                     if raw <= 1024 and tot * 16 <= 160 * 1024:
                         out.add((1, NT, 2, 4, R, ni, 8))
+            # ALG 8 with FLAT items (R = 4, NI = 0; round 4): 32 consecutive tiles of the flattened (image, tile row, tile column)
+            # order per item, 6-row strip patch with slots skewed by pos / 16
+            fmax = (TX4 - 1 + 32 + TX4 - 1) // TX4
+            npos = 6 * (128 + 2 * fmax)
+            raw = (npos + npos // 16 + 1 + 63) // 64 * 64
+            u, v = NT * 576, 2 * 576
+            if raw <= 1024 and max(3 * raw + 3 * u + 2 * v, 3 * raw + u + 4096) * 16 <= 160 * 1024:
+                out.add((1, NT, 2, 4, 4, 0, 8))
     return sorted(out)
 
 
