@@ -66,3 +66,29 @@ for t, kind, i in pts:
 print("wall time with exactly one kernel resident, by kernel:")
 for n, v in sorted(solo.items(), key=lambda kv: -kv[1])[:22]:
     print(f"  {v / 1e3:8.1f} us  {n}")
+
+# CU demand over time (round 4): a launch with w workgroups wants min(w, 256) CUs (every kernel of the forward that matters keeps
+# one workgroup per CU: LDS-bound or persistent); demand < 256 = CUs idle because the resident kernels are too narrow (or absent)
+import re as _re
+def _wg(n):
+    m = _re.search(r"\[(\d+) wg\]", n)
+    return min(256, int(m.group(1))) if m else 256
+pts = sorted([(s, _wg(n)) for s, e, n, q in fw] + [(e, -_wg(n)) for s, e, n, q in fw])
+cur, last = 0, t0
+hist = {"0": 0, "1-127": 0, "128-255": 0, "256-383": 0, ">=384": 0}
+idle_cu_us = 0.0
+for t, dlt in pts:
+    dt = t - last
+    key = "0" if cur == 0 else "1-127" if cur < 128 else "128-255" if cur < 256 else "256-383" if cur < 384 else ">=384"
+    hist[key] += dt
+    idle_cu_us += max(0, 256 - cur) * dt / 1e3
+    cur += dlt; last = t
+print("CU demand of the resident kernels (fraction of wall time):", {k: round(v / tot, 3) for k, v in hist.items()})
+print(f"idle CU capacity: {idle_cu_us / 256:.0f} us-equivalents of the whole chip out of {tot / 1e3:.0f} us wall")
+cut = defaultdict(float)
+for s, e, n, q in fw:
+    cut[n[:60]] += (e - s) / 1e3 * _wg(n) / 256
+print("CU time by kernel (duration x min(workgroups, 256) / 256, us-equivalents of the whole chip):")
+for n, v in sorted(cut.items(), key=lambda kv: -kv[1])[:16]:
+    print(f"  {v:8.0f}  {n}")
+print(f"  total {sum(cut.values()):.0f}")
