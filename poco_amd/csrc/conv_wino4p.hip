@@ -56,7 +56,21 @@ struct W4PParams {
   // FLAT items (cfg.NI == 0, see flat_geo): TY tile rows per image, ntiles = B * TX * TY tiles in all, fragW = 4 TX + 2
   int TY, ntiles, fragW;
   FastDiv dTY, dFragW;
+  // MOSAIC (flat items, cfg.R = 4 MS): MS x MS images form one virtual plane of MS (H + 1) - 1 rows x MS (W + 1) - 1 columns in which
+  // neighbouring images share their one-pixel zero border (3x3 conv, pad 1: exactly what the convolution pads with).  A 14 x 14
+  // plane alone needs 4 x 4 tiles of 4 x 4 outputs (23 % of them padding); 4 x 4 images side by side need 15 x 15 tiles instead of
+  // 16 x 16.  TX / TY / ntiles then count the tiles of the virtual planes; Tile::b is the mosaic index, oy0 / tx are virtual.
+  int MS, Hp1, Wp1;
+  FastDiv dHp1, dWp1;
 };
+
+// virtual coordinate v of a mosaic axis -> (image index along the axis, coordinate inside the image); the border lines between
+// images map to coordinate H (W), i.e. "outside"
+__device__ __forceinline__ void mosaic_split(uint32_t v, int p1, FastDiv d, int* img, int* c) {
+  const uint32_t q = fdiv(v, d);
+  *img = (int)q;
+  *c = (int)(v - q * (uint32_t)p1);
+}
 
 #ifndef W4P_EXP
 #define W4P_EXP 0     // timing probes (tools/build_exp.sh conv_wino4p.hip W4P_EXP n; results are then garbage): 1 producers skip the
@@ -135,7 +149,7 @@ __device__ __forceinline__ FlatItem flat_item(const W4PParams& p, int item) {
   f.w0 = 4 * (p.TX - f.tx0) + 2;
   return f;
 }
-template <bool FLAT>
+template <int FLAT>
 __device__ __forceinline__ Tile tile_of(const W4PParams& p, int item, int grp, int idx) {
   if constexpr (FLAT) {
     const FlatItem f = flat_item(p, item);
@@ -201,7 +215,7 @@ __host__ __device__ constexpr int w4p_nu(int q, int i) {
 
 // ---- staging (LDS-DMA) shared by whoever issues it: `nw` waves take pieces w, w + nw, ... -------------------------------
 // global float offsets of this wave's raw-patch pieces (lane = slot inside the piece), -1 = padding / beyond the patch
-template <int MAXP, bool FLAT>
+template <int MAXP, int FLAT>
 __device__ __forceinline__ void raw_piece_offsets(const W4PParams& p, int item, int w, int nw, int lane, int* goff) {
   if constexpr (FLAT) {
     // strip position -> (fragment, column) -> (image, row, column); slots are skewed by pos / 16 here (a 6-row strip of up to 146
@@ -231,11 +245,22 @@ __device__ __forceinline__ void raw_piece_offsets(const W4PParams& p, int item, 
         const uint32_t gr = (uint32_t)(f.gr0 + r);
         const uint32_t pb = fdiv(gr, p.dTY);
         const int ty = (int)(gr - pb * (uint32_t)p.TY);
-        const int iy = 4 * ty - 1 + (int)prow, ix = 4 * txs + cx - 1;
+        int iy = 4 * ty - 1 + (int)prow, ix = 4 * txs + cx - 1;
         // columns the item's tiles of this fragment do not read are left out of the DMA (they stay zero)
         const bool used = r < r_end || (r == r_end && cx < 4 * (tx_end - txs + 1) + 2);
-        if (used && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
-          goff[k] = (int)((pb * (uint32_t)p.H + (uint32_t)iy) * (uint32_t)p.in_rs) + ix * 16;
+        uint32_t img = pb;
+        bool inimg = true;
+        if constexpr (FLAT == 2) {                        // virtual -> (image of the mosaic, pixel); border lines and absent images read as zero
+          int my = 0, mx = 0;
+          if (iy >= 0 && ix >= 0) {
+            mosaic_split((uint32_t)iy, p.Hp1, p.dHp1, &my, &iy);
+            mosaic_split((uint32_t)ix, p.Wp1, p.dWp1, &mx, &ix);
+          }
+          img = (pb * (uint32_t)p.MS + (uint32_t)my) * (uint32_t)p.MS + (uint32_t)mx;
+          inimg = my < p.MS && mx < p.MS && img < (uint32_t)p.B;
+        }
+        if (used && inimg && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
+          goff[k] = (int)((img * (uint32_t)p.H + (uint32_t)iy) * (uint32_t)p.in_rs) + ix * 16;
       }
     }
     return;
@@ -276,7 +301,7 @@ __device__ __forceinline__ void raw_piece_offsets(const W4PParams& p, int item, 
 // MFMA waves (they also issue the LDS-DMA of the coming slices in the shadow of their MFMAs: a wave that is stuck behind a
 // busy MFMA pipe issues vector-memory instructions for free, while a producer wave needs ~60 clk per such instruction)
 // ---------------------------------------------------------------------------------------------------------------------
-template <int NT, int Q, bool FLAT>
+template <int NT, int Q, int FLAT>
 __device__ __forceinline__ void w4p_consumer(const W4PParams& p, float4* smem, int grp, int lane, int wave) {
   // this wave's nine positions: w4p_row / w4p_nu (transform rows RA(Q) and RA(Q) + 1)
   const int idx = lane & 15, g = lane >> 4;
@@ -425,13 +450,34 @@ __device__ __forceinline__ void w4p_consumer(const W4PParams& p, float4* smem, i
         const float lo = p.act == 1 ? 0.f : -INFINITY;        // ReLU as a clamp: no branch in the store loop
         const bool has_res = p.res != nullptr;
         const int ox = oxb + j;
-        const int xo = min(ox, p.W - 1) * 16;
-        const bool okx = tl.valid && ox < p.W;
+        int xo, ximg = 0;
+        bool okx;
         size_t ooff[4];
         float4 rr[4];
+        bool oky[4];
+        if constexpr (FLAT == 2) {
+          // mosaic: the tile's virtual rows / column -> (image, pixel); a tile may straddle two images and the border line between them
+          int xc;
+          mosaic_split((uint32_t)ox, p.Wp1, p.dWp1, &ximg, &xc);
+          okx = tl.valid && xc < p.W && ximg < p.MS;
+          xo = min(xc, p.W - 1) * 16;
+        } else {
+          xo = min(ox, p.W - 1) * 16;
+          okx = tl.valid && ox < p.W;
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {                         // per-row output offsets (clamped: dead pixels compute harmlessly, masked at the store)
-          const size_t orow = (size_t)tl.b * p.H + min(oyb + i, p.H - 1);
+          size_t orow;
+          if constexpr (FLAT == 2) {
+            int yimg, yc;
+            mosaic_split((uint32_t)(oyb + i), p.Hp1, p.dHp1, &yimg, &yc);
+            const int img = (tl.b * p.MS + yimg) * p.MS + ximg;
+            oky[i] = yc < p.H && yimg < p.MS && img < p.B;
+            orow = oky[i] && okx ? (size_t)img * p.H + yc : 0;
+          } else {
+            oky[i] = oyb + i < p.H;
+            orow = (size_t)tl.b * p.H + min(oyb + i, p.H - 1);
+          }
           ooff[i] = orow * p.out_rs + (size_t)(nt0 + n) * p.out_ss + g4 + xo;
           rr[i] = make_float4(0.f, 0.f, 0.f, 0.f);
           if (has_res) rr[i] = *reinterpret_cast<const float4*>(p.res + orow * p.res_rs + (size_t)(nt0 + n) * p.out_ss + g4 + xo);
@@ -448,7 +494,7 @@ __device__ __forceinline__ void w4p_consumer(const W4PParams& p, float4* smem, i
           if (p.res_after_act) { v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w; }
           // (streaming stores - __builtin_nontemporal_store - make a launch 1.5 us faster alone and the whole forward 0.5 % slower:
           // the next conv finds less of its input in the L2.  W4P_EXP & 2048: probe without the stores.)
-          if (okx && oyb + i < p.H && !((W4P_EXP & 2048) && p.B < 100000))
+          if (okx && oky[i] && !((W4P_EXP & 2048) && p.B < 100000))
             *reinterpret_cast<float4*>(p.out + ooff[i]) = make_float4(v[0], v[1], v[2], v[3]);
         }
       }
@@ -468,7 +514,7 @@ __device__ __forceinline__ void w4p_consumer(const W4PParams& p, float4* smem, i
 // ---------------------------------------------------------------------------------------------------------------------
 // producer waves: LDS-DMA of the raw patch + U fragments, input transform V = B^T d B for rows 3 RH .. 3 RH + 2
 // ---------------------------------------------------------------------------------------------------------------------
-template <int NT, int RH, bool FLAT>
+template <int NT, int RH, int FLAT>
 __device__ __forceinline__ void w4p_producer(const W4PParams& p, float4* smem, int pw, int lane) {
   const int grp = pw >> 1;
   const int idx = lane >> 2, g = lane & 3;   // transform lane order: 8 tiles x 4 channels per 32-lane half (see w4p_sigma)
@@ -638,7 +684,7 @@ __device__ __forceinline__ void w4p_producer(const W4PParams& p, float4* smem, i
   }
 }
 
-template <int NT, bool FLAT>
+template <int NT, int FLAT>      // FLAT: 0 rectangular items, 1 flat items, 2 flat items over a mosaic of images
 __global__ void __launch_bounds__(768)
 conv_wino4p_kernel(const W4PParams p) {
   extern __shared__ float4 smem[];
@@ -658,15 +704,18 @@ conv_wino4p_kernel(const W4PParams p) {
 }
 
 struct W4PLayout { int uoff, voff, xoff, totalF4; };
-// FLAT items (cfg.NI == 0, cfg.R == 4): 32 consecutive tiles per item, strip patch (see tile_of).  Geo fields reused: TX, PW, npos,
+// FLAT items (cfg.NI == 0, cfg.R = 4 MS, MS = 1 / 2 / 4 / 8 = mosaic side): 32 consecutive tiles per item, strip patch (see tile_of).  Geo fields reused: TX, PW, npos,
 // rawF4 (skew pos / 16), S = number of items along m; R = 4, PR = 6; tps / nbands / NI unused.
-struct FlatGeo { int TY, ntiles, fragW; };
+struct FlatGeo { int TY, ntiles, fragW, MS; };
 bool flat_geo(const ConvDesc& d, const ConvCfg& cfg, w4::Geo* g, FlatGeo* f) {
-  if (cfg.R != 4 || cfg.NI != 0) return false;
-  g->TX = (d.W + 3) / 4;
-  f->TY = (d.H + 3) / 4;
-  if ((long)d.B * g->TX * f->TY >= (1L << 24)) return false;       // (fdiv is exact for n * d < 2^32)
-  f->ntiles = d.B * g->TX * f->TY;
+  if (cfg.NI != 0 || (cfg.R != 4 && cfg.R != 8 && cfg.R != 16 && cfg.R != 32)) return false;
+  f->MS = cfg.R / 4;                                  // mosaic side: MS x MS images per virtual plane (1 = plain flat items)
+  const int VH = f->MS * (d.H + 1) - 1, VW = f->MS * (d.W + 1) - 1;
+  const int nmos = (d.B + f->MS * f->MS - 1) / (f->MS * f->MS);
+  g->TX = (VW + 3) / 4;
+  f->TY = (VH + 3) / 4;
+  if ((long)nmos * g->TX * f->TY >= (1L << 24) || VH >= 32768 || VW >= 32768) return false;       // (fdiv is exact for n * d < 2^32)
+  f->ntiles = nmos * g->TX * f->TY;
   f->fragW = 4 * g->TX + 2;
   const int fmax = (g->TX - 1 + 32 + g->TX - 1) / g->TX;        // tile-row fragments of an item that starts in the last column
   g->R = 4; g->NI = 0; g->nbands = f->TY; g->PR = 6; g->tps = g->TX;
@@ -759,6 +808,8 @@ int conv_wino4p_launch(const ConvDesc& d, const ConvCfg& cfg, hipStream_t stream
   if (flat) {
     p.TY = fg.TY; p.ntiles = fg.ntiles; p.fragW = fg.fragW;
     p.dTY = make_fastdiv(fg.TY); p.dFragW = make_fastdiv(fg.fragW);
+    p.MS = fg.MS; p.Hp1 = d.H + 1; p.Wp1 = d.W + 1;
+    p.dHp1 = make_fastdiv(d.H + 1); p.dWp1 = make_fastdiv(d.W + 1);
   }
   // balanced persistent grid: every block walks the same number of items (one block per CU)
   // cfg.MT = CU share divisor: the grid is sized for (CUs of the device) / MT.  A block needs a whole CU (LDS), all blocks of a launch run
@@ -775,14 +826,17 @@ int conv_wino4p_launch(const ConvDesc& d, const ConvCfg& cfg, hipStream_t stream
   long g4 = (items + rounds - 1) / rounds;
   if (g4 > 8) g4 = std::min(cus, (g4 + 7) / 8 * 8);            // multiple of 8 for the XCD-aware walk
   const size_t lds = (size_t)L.totalF4 * sizeof(float4);
-  auto fn = flat ? (cfg.NT == 3 ? conv_wino4p_kernel<3, true> : cfg.NT == 2 ? conv_wino4p_kernel<2, true> : conv_wino4p_kernel<1, true>)
-                 : (cfg.NT == 3 ? conv_wino4p_kernel<3, false> : cfg.NT == 2 ? conv_wino4p_kernel<2, false> : conv_wino4p_kernel<1, false>);
+  const int mode = !flat ? 0 : fg.MS > 1 ? 2 : 1;
+  void (*fn)(const W4PParams) =
+      mode == 2 ? (cfg.NT == 3 ? conv_wino4p_kernel<3, 2> : cfg.NT == 2 ? conv_wino4p_kernel<2, 2> : conv_wino4p_kernel<1, 2>)
+      : mode == 1 ? (cfg.NT == 3 ? conv_wino4p_kernel<3, 1> : cfg.NT == 2 ? conv_wino4p_kernel<2, 1> : conv_wino4p_kernel<1, 1>)
+                  : (cfg.NT == 3 ? conv_wino4p_kernel<3, 0> : cfg.NT == 2 ? conv_wino4p_kernel<2, 0> : conv_wino4p_kernel<1, 0>);
   if (lds > 64 * 1024) {
-    static thread_local bool configured[8] = {};
-    if (!configured[cfg.NT + (flat ? 4 : 0)]) {
+    static thread_local bool configured[12] = {};
+    if (!configured[cfg.NT + 4 * mode]) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       if (e != hipSuccess) { poco_set_error(std::string("hipFuncSetAttribute: ") + hipGetErrorString(e)); return POCO_ERR_HIP; }
-      configured[cfg.NT + (flat ? 4 : 0)] = true;
+      configured[cfg.NT + 4 * mode] = true;
     }
   }
   hipLaunchKernelGGL(fn, dim3((unsigned)g4, 1), dim3(768), lds, stream, p);

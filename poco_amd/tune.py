@@ -162,6 +162,17 @@ def candidates(B, H, W, Cin, Cout, ks, stride, lds_cap=150 * 1024) -> List[Tuple
             u, v = NT * 576, 2 * 576
             if raw <= 1024 and max(3 * raw + 3 * u + 2 * v, 3 * raw + u + 4096) * 16 <= 160 * 1024:
                 out.add((1, NT, 2, 4, 4, 0, 8))
+            # ... over a MOSAIC of MS x MS images that share their zero borders (R = 4 MS): only where it saves tiles (14 x 14 planes:
+            # 15 x 15 tiles per 4 x 4 images instead of 16 x 16)
+            for MS in (2, 4, 8):
+                TXm, TYm = (MS * (W + 1) - 1 + 3) // 4, (MS * (H + 1) - 1 + 3) // 4
+                if -(-B // (MS * MS)) * TXm * TYm >= 0.95 * B * TX4 * (Hc // 4):
+                    continue
+                fm = (TXm - 1 + 32 + TXm - 1) // TXm
+                nposm = 6 * (128 + 2 * fm)
+                rawm = (nposm + nposm // 16 + 1 + 63) // 64 * 64
+                if rawm <= 1024 and max(3 * rawm + 3 * u + 2 * v, 3 * rawm + u + 4096) * 16 <= 160 * 1024:
+                    out.add((1, NT, 2, 4, 4 * MS, 0, 8))
     return sorted(out)
 
 

@@ -49,8 +49,9 @@ for k in [kk for _ in range(npass) for kk in sorted(cost, key=lambda kk: -cost[k
     idxs = shapes[k]
     H, W, Cin, Cout = m.conv_desc(idxs[0])[:4]
     cur = tuple(m.conv_cfg(idxs[0], B))
-    nts = [cur[1]] + [n for n in (3, 2, 1) if n != cur[1]]
-    cands = [c for c in [(mt, nt, 2, 4, 4, 0, 8) for nt in nts for mt in ((1, 2) if nt == nts[0] else (1,))] if c != cur]
+    flat = [c for c in tune.candidates(B, H, W, Cin, Cout, 3, 1) if c[6] == 8 and c[5] == 0]      # flat items, plain and over mosaics
+    flat.sort(key=lambda c: (c[1] != cur[1], -c[1], c[4]))
+    cands = [c for c in flat + [(2,) + c[1:] for c in flat if c[1] == cur[1]] if c != cur]
     best, best_t = cur, cur_t
     for c in cands:
         try:

@@ -28,7 +28,7 @@ for (H, W, Cin, Cout, ks, st), cfgs in [
 print("\n".join(rows), flush=True)
 if len(sys.argv) > 2:
     from tests import util
-    for variant, Bv in (("hrnet_w48_cls-cliff", B),):
+    for variant, Bv in (("hrnet_w48_cls-cliff", B), ("hrnet_w32-pare", 32)):
         m = util.make_engine(variant, max_batch=Bv)
         batch = util.cuda_batch(synth.synth_batch(Bv, 1), dev)
         out = m._alloc_outputs(Bv, False)
