@@ -338,10 +338,24 @@ __device__ unsigned long long g_wino_trace[512 * 8 * 8];
 #ifndef WINO_EXP
 #define WINO_EXP 0     // timing experiments only (tools/build_exp.sh); non-zero values compute garbage
 #endif
-template <int NT>
+// DEPTH (round 4, cfg.MT = 3): depth of the raw and U rings.  With DEPTH 2 the fragments of slice c+1 and the patch of slice c+2 are
+// requested at the top of slice c and awaited (s_waitcnt vmcnt(0)) at the top of slice c+1: they have ONE slice time to arrive.  At
+// small batch sizes (few tiles per launch, 8 NT MFMAs x 4 k-steps = 0.3-0.5 us of MFMAs per slice) the LDS-DMA round trip of ~1.5 us
+// IS the slice time.  DEPTH 3 requests U(c+2) and raw(c+3) at slice c and waits with a COUNTED vmcnt that leaves exactly the batch
+// of the previous slice in flight: two slice times per fetch.  Costs one more raw + U buffer of LDS (NT <= 2 in practice).
+__device__ __forceinline__ void wino_wait_vm(int n) {     // s_waitcnt vmcnt(n), n wave-uniform; n > 24 -> vmcnt(0) (conservative)
+  switch (n) {
+#define W_(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
+    W_(1) W_(2) W_(3) W_(4) W_(5) W_(6) W_(7) W_(8) W_(9) W_(10) W_(11) W_(12) W_(13) W_(14) W_(15) W_(16) W_(17) W_(18) W_(19) W_(20)
+    W_(21) W_(22) W_(23) W_(24)
+#undef W_
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+  }
+}
+template <int NT, int DEPTH = 2>
 __global__ void __launch_bounds__(512)
 conv_wino2_kernel(const WinoParams p) {
-  extern __shared__ float4 smem[];   // [raw buf 0][raw buf 1][U buf 0][U buf 1]
+  extern __shared__ float4 smem[];   // [raw buf 0 .. DEPTH-1][U buf 0 .. DEPTH-1]
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -385,7 +399,7 @@ conv_wino2_kernel(const WinoParams p) {
     }
   };
   auto issue_raw = [&](int c, int it, const int* go) {
-    const unsigned rb = lds_base + (unsigned)((it & 1) * rawF4) * 16u;
+    const unsigned rb = lds_base + (unsigned)((it % DEPTH) * rawF4) * 16u;
 #pragma unroll
     for (int k = 0; k < WINO_MAXG; ++k) {
       const int grp = dw + k * dn;
@@ -400,7 +414,7 @@ conv_wino2_kernel(const WinoParams p) {
   auto issue_u = [&](int c, int it, int nt0) {
     // item i = (position xi, n-tile j) lives at ((xi*nC16 + c)*nT16 + nt) KiB of the packed buffer: a wave-uniform
     // base for the slice + a 32-bit per-item offset stepped incrementally (scalar ALU only, one v_add per DMA)
-    const unsigned ub0 = lds_base + (unsigned)(2 * rawF4 + (it & 1) * p.ubufF4) * 16u;
+    const unsigned ub0 = lds_base + (unsigned)(DEPTH * rawF4 + (it % DEPTH) * p.ubufF4) * 16u;
     const char* sb = reinterpret_cast<const char*>(p.ufrag) + (size_t)((unsigned)c * (unsigned)p.nT16) * 1024u;
     const unsigned xstride = (unsigned)(p.nC16 * p.nT16) * 1024u;
     // every block reads the SAME fragments of slice c from L2: rotate the issue order by the block index so that
@@ -444,7 +458,16 @@ conv_wino2_kernel(const WinoParams p) {
     issue_raw(0, it0, goff);
     issue_u(0, it0, nt0);
     if (p.nC16 > 1) issue_raw(1, it0 + 1, goff);
+    if constexpr (DEPTH == 3) {
+      if (p.nC16 > 1) issue_u(1, it0 + 1, nt0);
+      if (p.nC16 > 2) issue_raw(2, it0 + 2, goff);
+    }
   }
+  // DMA instructions this wave issues per slice (wave-uniform): its share of the U items and 4 planes per raw group
+  int nU = 0, nR = 0;
+  for (int i = dw; i < nuitems; i += dn) ++nU;
+#pragma unroll
+  for (int k = 0; k < WINO_MAXG; ++k) if (dw + k * dn < p.ngroups) nR += 4;
 
   for (; t < tend; t += tstep) {
     const int tn = t + tstep;
@@ -489,7 +512,7 @@ conv_wino2_kernel(const WinoParams p) {
     auto kloop = [&](auto HC) {
       constexpr int HALF = decltype(HC)::value;
       auto load_transform = [&](int it, float4* vout) {
-        const float4* pl = smem + (it & 1) * rawF4 + g * p.planeF4 + base + HALF;
+        const float4* pl = smem + (it % DEPTH) * rawF4 + g * p.planeF4 + base + HALF;
         float4 d[4][3];
 #pragma unroll
         for (int r = 0; r < 4; ++r)
@@ -517,7 +540,12 @@ conv_wino2_kernel(const WinoParams p) {
           // also retires this wave's output stores of the previous tile, long since written
           [[maybe_unused]] const unsigned long long t0 = TR_NOW();
           TR_ADD(1, tB, t0);           // 1: slice body (window reads, transform, MFMAs, DMA issue)
-          if (c > 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          if constexpr (DEPTH == 3) {
+            // everything but the batch requested at slice c-1 (U(c+1), raw(c+2)) has landed: U(c) and raw(c+1) are there
+            if (c > 0) wino_wait_vm((c + 1 < p.nC16 ? nU : 0) + (c + 2 < p.nC16 ? nR : 0));
+          } else {
+            if (c > 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          }
           [[maybe_unused]] const unsigned long long t1 = TR_NOW();
           TR_ADD(2, t0, t1);           // 2: waiting for this wave's own DMA
           tB = t1;
@@ -536,10 +564,10 @@ conv_wino2_kernel(const WinoParams p) {
         auto issue_slice = [&]() {
 #if !(WINO_EXP & 4)
 #if !(WINO_EXP & 16)
-          if (c + 1 < p.nC16) issue_u(c + 1, it + 1, nt0);
+          if (c + DEPTH - 1 < p.nC16) issue_u(c + DEPTH - 1, it + DEPTH - 1, nt0);      // (into the slot of U(c-1): consumed before this slice's barrier)
 #endif
 #if !(WINO_EXP & 32)
-          if (c + 2 < p.nC16) issue_raw(c + 2, it + 2, goff);
+          if (c + DEPTH < p.nC16) issue_raw(c + DEPTH, it + DEPTH, goff);               // (into the slot of raw(c): its window was read during slice c-1)
 #endif
 #endif
         };
@@ -557,7 +585,7 @@ conv_wino2_kernel(const WinoParams p) {
 #else
         load_transform(it + 1, vnext);   // past the last slice this reads stale LDS and is never used
 #endif
-        const float4* ul = smem + 2 * rawF4 + (it & 1) * p.ubufF4 + (2 * HALF * NT) * 64 + lane;
+        const float4* ul = smem + DEPTH * rawF4 + (it % DEPTH) * p.ubufF4 + (2 * HALF * NT) * 64 + lane;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           if constexpr (LATE_ISSUE) { if (r == ISSUE_AT) issue_slice(); }
@@ -614,11 +642,15 @@ conv_wino2_kernel(const WinoParams p) {
       issue_raw(0, itn, goffN);
       issue_u(0, itn, (tn / p.nblocks_m) * NT);
       if (p.nC16 > 1) issue_raw(1, itn + 1, goffN);
+      if constexpr (DEPTH == 3) {
+        if (p.nC16 > 1) issue_u(1, itn + 1, (tn / p.nblocks_m) * NT);
+        if (p.nC16 > 2) issue_raw(2, itn + 2, goffN);
+      }
     }
     // Output stage, split between the halves: the lower half finishes the upper pixel row of every 2x2 block
     // (k = 0,1), the upper half the lower row (k = 2,3); each hands the partial sums of the OTHER row to its
     // partner through LDS (the last slice's U buffer is dead): [wave][n][2][lane].
-    float4* xch = smem + 2 * rawF4 + (itl & 1) * p.ubufF4;
+    float4* xch = smem + DEPTH * rawF4 + (itl % DEPTH) * p.ubufF4;
     {
       const int ks = half == 0 ? 2 : 0;                 // the row this half gives away
 #pragma unroll
@@ -652,7 +684,7 @@ conv_wino2_kernel(const WinoParams p) {
 #pragma unroll
       for (int k = 0; k < WINO_MAXG; ++k) goff[k] = goffN[k];
     }
-    it0 = itn;
+    it0 = itn % DEPTH;
     [[maybe_unused]] const unsigned long long tD = TR_NOW();
     TR_ADD(4, tC, tD);                 // 4: end-of-tile stage (barriers, exchange, next tile's first issue, stores)
   }
@@ -695,8 +727,11 @@ bool wgeo(const ConvDesc& d, const ConvCfg& c, WGeo* g) {
 size_t conv_wino_lds_bytes(const ConvDesc& d, const ConvCfg& cfg) {
   WGeo g;
   if (!wgeo(d, cfg, &g)) return 0;
-  if (cfg.ALG == 4)   // 2 raw buffers + 2 U buffers (the exchange area at the end reuses the U buffers)
-    return ((size_t)8 * g.planeF4 + (size_t)2 * 16 * cfg.NT * 64) * sizeof(float4);
+  if (cfg.ALG == 4) { // DEPTH raw buffers + DEPTH U buffers (the exchange area at the end reuses a U buffer); DEPTH = 3 with cfg.MT = 3
+    if (cfg.MT != 1 && cfg.MT != 3) return 0;
+    const size_t depth = cfg.MT == 3 ? 3 : 2;
+    return (depth * 4 * g.planeF4 + depth * 16 * cfg.NT * 64) * sizeof(float4);
+  }
   return ((size_t)4 * g.planeF4 + (size_t)2 * 16 * cfg.WN * cfg.NT * 64) * sizeof(float4);
 }
 
@@ -758,13 +793,17 @@ int conv_wino_launch(const ConvDesc& d, const ConvCfg& cfg, hipStream_t stream) 
     long g4 = (tiles4 + rounds4 - 1) / rounds4;
     if (g4 > 8) g4 = std::min(cap4, (g4 + 7) / 8 * 8);      // multiple of 8 for the XCD-aware walk
     dim3 grid4((unsigned)g4, 1);
-    auto fn4 = cfg.NT == 3 ? conv_wino2_kernel<3> : cfg.NT == 2 ? conv_wino2_kernel<2> : conv_wino2_kernel<1>;
+    const bool deep = cfg.MT == 3;
+    if (lds4 == 0) { poco_set_error("conv(winograd/half): MT must be 1 (2-deep rings) or 3 (3-deep rings)"); return POCO_ERR_ARG; }
+    void (*fn4)(const WinoParams) =
+        deep ? (cfg.NT == 3 ? conv_wino2_kernel<3, 3> : cfg.NT == 2 ? conv_wino2_kernel<2, 3> : conv_wino2_kernel<1, 3>)
+             : (cfg.NT == 3 ? conv_wino2_kernel<3, 2> : cfg.NT == 2 ? conv_wino2_kernel<2, 2> : conv_wino2_kernel<1, 2>);
     if (lds4 > 64 * 1024) {
-      static thread_local bool configured4[4] = {false, false, false, false};
-      if (!configured4[cfg.NT]) {
+      static thread_local bool configured4[8] = {};
+      if (!configured4[cfg.NT + (deep ? 4 : 0)]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn4), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) { poco_set_error(std::string("hipFuncSetAttribute: ") + hipGetErrorString(e)); return POCO_ERR_HIP; }
-        configured4[cfg.NT] = true;
+        configured4[cfg.NT + (deep ? 4 : 0)] = true;
       }
     }
     hipLaunchKernelGGL(fn4, grid4, dim3(nw * 64), lds4, stream, p);

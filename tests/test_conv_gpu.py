@@ -130,6 +130,42 @@ def test_conv_parity_winograd(case, alg, nt, cuda):
     assert np.abs(out - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max())
 
 
+@pytest.mark.parametrize("nt", [1, 2, 3])
+@pytest.mark.parametrize("case", [(1, 7, 7, 384, 384, True), (1, 14, 14, 192, 192, True), (16, 7, 7, 64, 48, False), (5, 14, 14, 16, 32, True),
+                                  (2, 28, 28, 96, 96, True), (37, 56, 56, 32, 64, True), (3, 13, 9, 48, 16, False), (1, 14, 14, 32, 32, False)],
+                         ids=lambda c: "x".join(map(str, c)))
+def test_conv_winograd_half_deep_rings(case, nt, cuda):
+    """ALG 4 with 3-deep raw / U rings (round 4, cfg.MT = 3): the fragments of slice c+2 and the patch of slice c+3 are requested at
+    slice c and awaited with a counted s_waitcnt vmcnt that leaves one batch in flight (small-batch latency).  Same MFMAs in the same
+    order as the 2-deep kernel: BITWISE its result, for 1 ... 24 slices (K = 16 ... 384), one tile per block and persistent blocks that
+    walk several; configurations whose rings do not fit the LDS are refused."""
+    from poco_amd import ops
+    B, H, W, Cin, Cout, use_res = case
+    rng = np.random.default_rng(B * 7 + Cin + Cout)
+    x = rng.standard_normal((B, H, W, Cin)).astype(np.float32)
+    w = (rng.standard_normal((Cout, Cin, 3, 3)) / np.sqrt(Cin * 9)).astype(np.float32)
+    shift = rng.uniform(-0.5, 0.5, Cout).astype(np.float32)
+    res = rng.standard_normal((B, H, W, Cout)).astype(np.float32) if use_res else None
+    TX, Hc = (W + 1) // 2, (H + 1) // 2 * 2
+    R = 2
+    while R + 2 <= Hc and ((R + 2) // 2) * TX <= 64:
+        R += 2
+    tiles = (R // 2) * TX
+    WM = -(-tiles // 16)
+    NI = min(B, max(1, (WM * 16) // tiles)) if R >= H else 1
+    args = (torch.from_numpy(x).to(cuda), w, None, shift, 1, torch.from_numpy(res).to(cuda) if use_res else None, True)
+    two = ops.conv2d_nhwc(*args, cfg=(1, nt, WM, 2, R, NI, 4)).cpu().numpy()
+    plane = (NI * (R + 2) * (2 * TX + 2) + 63) // 64 * 64
+    if (3 * 4 * plane + 3 * 16 * nt * 64) * 16 > 160 * 1024:
+        with pytest.raises(RuntimeError):
+            ops.conv2d_nhwc(*args, cfg=(3, nt, WM, 2, R, NI, 4))
+        return
+    three = ops.conv2d_nhwc(*args, cfg=(3, nt, WM, 2, R, NI, 4)).cpu().numpy()
+    ref = _ref(x, w, None, shift, 1, res, True)
+    assert np.abs(two - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max())
+    assert np.array_equal(two, three)
+
+
 @pytest.mark.parametrize("cfg", TILES + [t + (1,) for t in TILES] + [t + (2,) for t in TILES])
 def test_conv_explicit_tiles(cfg, cuda):
     """Every tile decomposition must give the same answer (asymmetric weights catch transposes)."""
