@@ -201,6 +201,31 @@ def test_linear_small_m(case, wm, cuda):
     assert np.abs(out - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max())
 
 
+@pytest.mark.parametrize("wm", [1, 4, 16])
+@pytest.mark.parametrize("case", [(1, 7, 7, 384, 384, 1, True), (1, 14, 14, 192, 192, 1, True), (4, 28, 28, 96, 96, 1, False), (1, 56, 56, 48, 48, 1, True),
+                                  (1, 56, 56, 48, 96, 2, False), (3, 28, 28, 96, 192, 2, True), (2, 14, 14, 192, 384, 2, False), (1, 13, 9, 32, 16, 1, True),
+                                  (2, 15, 15, 32, 48, 2, False), (1, 1, 1, 16, 16, 1, False), (5, 7, 7, 16, 32, 2, True)],
+                         ids=lambda c: "x".join(map(str, c)))
+def test_conv3x3_split_k_small_batch(case, wm, cuda):
+    """ALG 5 for 3x3 convs (round 4, csrc/linear_mfma.hip conv3x3_splitk_kernel): the direct conv as a GEMM over K = 9 Cin / 16 steps
+    dealt to the wm waves of a block, one LDS reduction in a fixed order - the small-batch form of hrnet.py:42-58 (BasicBlock convs)
+    and :208-236 (stride-2 fuse convs).  Exact fp32 fma chains: same tolerance as the direct kernels."""
+    from poco_amd import ops
+    B, H, W, Cin, Cout, stride, use_res = case
+    rng = np.random.default_rng(B * 31 + Cin + Cout + stride)
+    x = rng.standard_normal((B, H, W, Cin)).astype(np.float32)
+    w = (rng.standard_normal((Cout, Cin, 3, 3)) / np.sqrt(Cin * 9)).astype(np.float32)
+    scale = rng.uniform(0.5, 1.5, Cout).astype(np.float32)
+    shift = rng.uniform(-0.5, 0.5, Cout).astype(np.float32)
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    res = rng.standard_normal((B, Ho, Wo, Cout)).astype(np.float32) if use_res else None
+    ref = _ref(x, w, scale, shift, stride, res, True)
+    out = ops.conv2d_nhwc(torch.from_numpy(x).to(cuda), w, scale, shift, stride, torch.from_numpy(res).to(cuda) if use_res else None,
+                          True, cfg=(1, 1, wm, 1, 1, 1, 5)).cpu().numpy()
+    assert out.shape == ref.shape
+    assert np.abs(out - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max()), np.abs(out - ref).max()
+
+
 @pytest.mark.parametrize("wm", [1, 2, 4, 8])
 @pytest.mark.parametrize("case", [(2, 56, 56, 64, 256), (3, 14, 14, 192, 144), (5, 7, 7, 384, 336), (1, 13, 9, 32, 16)],
                          ids=lambda c: "x".join(map(str, c)))
