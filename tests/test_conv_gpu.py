@@ -564,7 +564,7 @@ def _conv_fp64_gpu(x, w, shift, stride, res, relu):
 ALG_TOL = {3: 1e-4, 4: 1e-4, 7: 2e-4, 8: 2e-4, 11: 2e-4}     # Winograd F(2x2): transforms amplify fp32 rounding ~5x, F(4x4) ~10x
 
 
-@pytest.mark.parametrize("batch", [32, 64, 128])
+@pytest.mark.parametrize("batch", [1, 4, 16, 32, 64, 128])
 def test_tuned_table_entries(batch, cuda):
     """EVERY distinct (shape, cfg) of poco_amd/tuned/gfx950.json at the bench batch sizes goes
     through poco_op_conv2d at that batch size against an fp64 conv (all crops, all pixels), so a wrong tile in a tuned
