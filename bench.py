@@ -237,7 +237,7 @@ def streaming_leg(variant, device, batch=128, people=4, batches=20):
     dt = time.perf_counter() - t0
     del cs, m
     return {"workload": f"{variant} streaming: {H}x{W} uint8 frames over PCIe, {people} people/frame, GPU crop+normalise, "
-                        f"hipGraph forward bs={batch}, 253-float records back (BASELINE config #5 shape, 1 GPU, synthetic frames)",
+                        f"hipGraph forward bs={batch}, 254-float records back (BASELINE config #5 shape, 1 GPU, synthetic frames)",
             "frames_per_s": round(batches * fpb / dt, 1), "crops_per_s": round(batches * batch / dt, 1),
             "ms_per_batch": round(dt / batches * 1e3, 2), "pcie_in_MB_per_batch": round(fpb * H * W * 3 / 1e6, 1)}
 
