@@ -72,7 +72,8 @@ class POCOTester:
         torch.cuda.set_device(self.device)
         kw = model_kwargs(self.model_cfg)
         self.model = POCO(**kw, pretrained=args.ckpt, inf_model=getattr(args, "inf_model", "best"),
-                          max_batch=max(int(args.batch_size), 1), smpl=args.smpl, device=str(self.device)).finalize()
+                          max_batch=max(int(args.batch_size), 1), smpl=args.smpl, device=str(self.device),
+                          keep_state_dict=False).finalize()     # (state_dict() re-reads the checkpoint file on demand)
         self.faces = None                       # triangle list for --save_obj, if the body-model file carries one
         if isinstance(args.smpl, str) and os.path.isfile(args.smpl):
             with np.load(args.smpl) as z:
