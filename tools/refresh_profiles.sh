@@ -6,12 +6,16 @@
 TAG=${1:-r03}
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/$TAG
-rm -rf $OUT; mkdir -p $OUT
+[ -n "$ONLY" ] || rm -rf $OUT
+mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
+# ONLY=<short tag> (w48cliff | resnet50cliff | w32pare): re-take the kernel stats / PMC passes of one variant, keep the rest
+[ -n "$ONLY" ] || {
 python $R/bench.py 2>$OUT/bench_w48.err | tail -1 > $OUT/${TAG}_bench_hrnet_w48_cls-cliff.json
 python $R/bench.py --variant resnet50-cliff --batch 64 --no-stream --no-side 2>/dev/null | tail -1 > $OUT/${TAG}_bench_resnet50-cliff.json
 python $R/bench.py --variant hrnet_w32-pare --batch 32 --no-stream --no-side 2>/dev/null | tail -1 > $OUT/${TAG}_bench_hrnet_w32-pare.json
 python $R/bench.py --no-graph --no-cpu-baseline --no-stream --no-side --no-variants 2>/dev/null | tail -1 > $OUT/${TAG}_bench_hrnet_w48_cls-cliff_nograph.json
+}
 prof_variant() {   # variant batch short-tag
   V=$1; B=$2; T=$3
   ARGS="--variant $V --batch $B --no-cpu-baseline --no-stream --no-dominant --no-graph --no-side --no-variants"
@@ -33,7 +37,7 @@ prof_variant() {   # variant batch short-tag
     rm -rf $OUT/p
   fi
 }
-prof_variant hrnet_w48_cls-cliff 64 w48cliff $2
-prof_variant resnet50-cliff 64 resnet50cliff $2
-prof_variant hrnet_w32-pare 32 w32pare $2
+[ -n "$ONLY" ] && [ "$ONLY" != w48cliff ] || prof_variant hrnet_w48_cls-cliff 64 w48cliff $2
+[ -n "$ONLY" ] && [ "$ONLY" != resnet50cliff ] || prof_variant resnet50-cliff 64 resnet50cliff $2
+[ -n "$ONLY" ] && [ "$ONLY" != w32pare ] || prof_variant hrnet_w32-pare 32 w32pare $2
 ls $OUT; cat $OUT/*bench*.json | cut -c1-300
