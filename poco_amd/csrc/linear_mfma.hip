@@ -124,6 +124,14 @@ linear_mfma_kernel(const LinParams p) {
 // fragments: the regime is bound by the weight stream), all loads of a wave's 4 steps in flight before its first MFMA, one LDS
 // reduction in a fixed order, epilogue by the first waves.  Zero padding as in gemm3x3.hip: a lane whose tap falls outside the image
 // loads its centre pixel and the value is replaced by zero.
+// v where `ok`, zeros elsewhere - as a MULTIPLICATION by 1 / 0, which the optimiser cannot turn back into a predicated load.  A lane
+// whose tap is padding loaded the CENTRE pixel of its own window: a finite value whenever the true output is finite (that pixel
+// contributes to the same output through the centre tap), so 0 * v is an exact zero in every case that matters.
+__device__ __forceinline__ float4 select_or_zero(float4 v, bool ok) {
+  const float k = ok ? 1.f : 0.f;
+  return make_float4(v.x * k, v.y * k, v.z * k, v.w * k);
+}
+
 struct Lin3Params {
   LinParams l;
   int H, Wi, Ho, Wo, stride;   // input plane H x Wi, output plane Ho x Wo (l.W = Wo, l.P = B*Ho*Wo)
@@ -175,14 +183,22 @@ conv3x3_splitk_kernel(const Lin3Params q) {
       a[u] = wl[(size_t)c * wstride];
 #pragma unroll
       for (int m = 0; m < LIN_MB; ++m) {
+        // the value is zeroed where it is CONSUMED (opaque select below): with `ok ? v : 0` here hipcc predicates the load
+        // (s_cbranch_execz around every gather), stops counting the loads in flight and waits for each group of a K step before it
+        // requests the next one - one step in flight instead of four
         const bool ok = (vmask[m] >> tap) & 1;
-        const float4 v = *reinterpret_cast<const float4*>(xc[m] + (ok ? toff : 0) + (size_t)c16 * p.in_ss);
-        b[u][m] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        b[u][m] = *reinterpret_cast<const float4*>(xc[m] + (ok ? toff : 0) + (size_t)c16 * p.in_ss);
       }
     }
 #pragma unroll
     for (int u = 0; u < LIN_UNROLL; ++u) {
       if (c0 + u * nwaves < q.nK) {
+        {
+          const int c = c0 + u * nwaves;
+          const int tap = p.nC16 == 1 ? c : (int)__umulhi((uint32_t)c, q.nc_magic);
+#pragma unroll
+          for (int m = 0; m < LIN_MB; ++m) b[u][m] = select_or_zero(b[u][m], (vmask[m] >> tap) & 1);
+        }
         const float av[4] = {a[u].x, a[u].y, a[u].z, a[u].w};
 #pragma unroll
         for (int j = 0; j < 4; ++j)
