@@ -33,9 +33,10 @@ const char* poco_last_error(void);
 
 /* Version of this ABI: bumped whenever a struct layout or the meaning / type of an argument of an existing entry point changes
  * (2: poco_crop_normalize takes bbox_scale as double; 3: poco_outputs_t gained `record`, poco_create_ex, poco_crop_normalize_multi,
- * RealNVP scratch planned at finalize).  A binding compiled against another header must refuse to run:
+ * RealNVP scratch planned at finalize; 4: poco_inputs_t / poco_outputs_t start with `struct_size`, see below).  A binding
+ * compiled against another header must refuse to run:
  *     if (poco_abi_version() != POCO_ABI_VERSION) fail;                                                                          */
-#define POCO_ABI_VERSION 3
+#define POCO_ABI_VERSION 4
 int poco_abi_version(void);
 
 /* ---- the engine: POCO(backbone=..., pretrained=ckpt) + model(batch) ---------------------------
@@ -44,9 +45,18 @@ int poco_abi_version(void);
 
 typedef struct poco_engine* poco_handle_t;
 
+/* Both I/O structs are SELF-DESCRIBING (ABI 4): the first member is the size in bytes of the struct the CALLER compiled or
+ * declared (`x.struct_size = sizeof x;`).  The library reads exactly that many bytes:
+ *   - members beyond `struct_size` (added by a later header) read as NULL = "not wanted / not given";
+ *   - a `struct_size` that is 0, not a multiple of 8, smaller than the size word plus one pointer, or larger than 4096 is
+ *     POCO_ERR_ARG (that is what a struct written from an older header - whose first member is a pointer - or an
+ *     uninitialised one looks like), and so is a non-NULL member beyond what THIS library knows;
+ * so a binding whose field list is shorter than this header's can no longer make the engine read past its struct. */
+
 /* batch dict of pocolib/core/tester.py:205-212 (device pointers, fp32).  bbox_info/focal_length/
  * scale/center/orig_shape are only read by the *-cliff variants (poco.py:102-111). */
 typedef struct {
+  uint64_t struct_size;      /* = sizeof(poco_inputs_t) as the caller sees it           */
   const float* img;          /* [B,3,224,224] NCHW, ImageNet-normalised crop            */
   const float* bbox_info;    /* [B,3]   image_utils.py:171-183                           */
   const float* focal_length; /* [B]     image_utils.py:185-187                           */
@@ -58,6 +68,7 @@ typedef struct {
 /* output dict of POCO.forward.  Any pointer may be NULL = not wanted
  * (pred_cam_t / smpl_joints2d / pred_fullimg_cam_t are computed into scratch then). */
 typedef struct {
+  uint64_t struct_size;      /* = sizeof(poco_outputs_t) as the caller sees it          */
   float* pred_pose;          /* [B,24,3,3] rotation matrices                             */
   float* pred_pose6d;        /* [B,144]    ('pred_pose6d' pare / 'pred_pose_6d' cliff)   */
   float* pred_shape;         /* [B,10]                                                   */

@@ -77,6 +77,15 @@ __device__ __forceinline__ void mosaic_split(uint32_t v, int p1, FastDiv d, int*
 #endif                // transform, 2 no LDS-DMA inside the K loop, 4 MFMA waves skip the MFMAs, 8 ... skip their operand reads,
                       // 16 no per-slice barrier work at all in the producers (neither DMA nor transform), 128 producers skip the window
                       // reads only, 512 / 1024 no U / no patch LDS-DMA inside the K loop
+#ifndef W4P_EPI
+#define W4P_EPI 7     // round 5 epilogue / item-start restructure (bit mask; 0 = the round-4 kernel, for same-box A/B builds):
+#endif                //  1: the exchange area sits at the END of the LDS (over U slot 2 + V) instead of over U slots 1, 2: U(1) of the next item
+                      //     is fetched together with U(0) during the exchange rounds, no exposed fetch at the item start
+                      //  2: bias / residual loads of round n+1 are issued BEFORE the stores of round n and awaited before them (round 0's after
+                      //     its Z is written): no vmcnt wait of a round covers the stores of the previous round any more
+                      //  4: no barrier in front of exchange round 0 (the last slice barrier already separates the last operand reads from the
+                      //     exchange writes), and the producers deal the next item's first fetches over the 2 NT barrier gaps of the exchange
+                      //     instead of issuing all of them in front of its first barrier (where the eight MFMA waves waited for them)
 #ifndef W4P_TRACE
 #define W4P_TRACE 0   // 1: block 0 accumulates s_memtime phase sums of its 8 MFMA waves and 4 producer waves (tools/w4p_trace.py; reading the
                       // counter drains lgkmcnt, so a phase that ends with LDS reads in flight includes their latency)
@@ -85,7 +94,7 @@ __device__ __forceinline__ void mosaic_split(uint32_t v, int p1, FastDiv d, int*
 #define W4P_TRACE_ITEM 0   // which item of block 0's walk is traced (0 = the first, cold one)
 #endif
 #if W4P_TRACE
-__device__ unsigned long long g_w4p_trace[64];
+__device__ unsigned long long g_w4p_trace[96];
 #define W4P_T(var) const unsigned long long var = __builtin_readcyclecounter()
 #define W4P_ACC(slot, a, b) do { if (trace) tr[slot] += (b) - (a); } while (0)
 #else
@@ -361,7 +370,7 @@ __device__ __forceinline__ void w4p_consumer(const W4PParams& p, float4* smem, i
 
 #if W4P_TRACE
     const bool trace = blockIdx.x == 0 && item == wk.first + W4P_TRACE_ITEM * wk.step;
-    unsigned long long tr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tr[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
     W4P_T(c_a);
     // (the producers fetched raw(0..2), U(0) during the previous item's exchange rounds and U(1) just now)
@@ -411,13 +420,77 @@ __device__ __forceinline__ void w4p_consumer(const W4PParams& p, float4* smem, i
     }
     W4P_T(c_e0);
 
+#if W4P_EPI & 2
     // ---- Z = M A (partial over this wave's columns), exchanged one n-tile at a time; wave Q finishes output column Q --------
-    // exchange area [8 waves][2 rows][4 cols][64] float4 (64 KiB) over ring slots that are dead now
+    // exchange area [8 waves][2 rows][4 cols][64] float4 (64 KiB) over ring slots that are dead now.
+    // Round 5: what a round waits for.  Round 4 requested bias and residual of round n after its second barrier and consumed them
+    // right away: loads and stores share the one in-order VM counter on gfx9, so that wait (vmcnt(0)) also covered the four stores of
+    // round n-1 - issued a few hundred clocks earlier by all 256 CUs at once - and every round paid a store round trip under burst
+    // load (s_memtime: 4.5 k clk per round for ~110 instructions per wave).  Now the loads of round n+1 go out BEFORE the stores of
+    // round n and are awaited before them too (an empty asm that "uses" the registers pins hipcc's wait there: newest operations,
+    // so vmcnt(0) at that point covers only stores issued a whole round ago), and round 0's go out as soon as its Z is written
+    // (36 accumulators dead).  The store geometry of the wave's column does not depend on the n-tile and is computed once.
     const int oyb = tl.oy0, oxb = 4 * tl.tx;
     float4* xch = smem + p.xoff;
+    const int g4 = g * 4;
+    const float lo = p.act == 1 ? 0.f : -INFINITY;            // ReLU as a clamp: no branch in the store loop
+    const bool has_res = p.res != nullptr;
+    constexpr int jc = Q;
+    const int ox = oxb + jc;
+    int xo, ximg = 0;
+    bool okx;
+    if constexpr (FLAT == 2) {
+      // mosaic: the tile's virtual rows / column -> (image, pixel); a tile may straddle two images and the border line between them
+      int xc;
+      mosaic_split((uint32_t)ox, p.Wp1, p.dWp1, &ximg, &xc);
+      okx = tl.valid && xc < p.W && ximg < p.MS;
+      xo = min(xc, p.W - 1) * 16;
+    } else {
+      xo = min(ox, p.W - 1) * 16;
+      okx = tl.valid && ox < p.W;
+    }
+    // per-lane 32-bit BYTE offsets of the wave's four output rows (clamped: dead pixels compute harmlessly and are masked at the
+    // store); the n-tile's channel slice is added to the wave-uniform base, so every access is SGPR base + VGPR offset and no
+    // 64-bit address lives in (or is spilled from) the vector registers
+    unsigned ooff[4], roff[4];
+    bool oky[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int orow;
+      if constexpr (FLAT == 2) {
+        int yimg, yc;
+        mosaic_split((uint32_t)(oyb + i), p.Hp1, p.dHp1, &yimg, &yc);
+        const int img = (tl.b * p.MS + yimg) * p.MS + ximg;
+        oky[i] = yc < p.H && yimg < p.MS && img < p.B;
+        orow = oky[i] && okx ? img * p.H + yc : 0;
+      } else {
+        oky[i] = oyb + i < p.H;
+        orow = tl.b * p.H + min(oyb + i, p.H - 1);
+      }
+      ooff[i] = ((unsigned)orow * (unsigned)p.out_rs + (unsigned)(g4 + xo)) * 4u;
+      roff[i] = has_res ? ((unsigned)orow * (unsigned)p.res_rs + (unsigned)(g4 + xo)) * 4u : 0u;
+    }
+    // bias + residual of n-tile nt0 + nn (clamped into the tensor: the last group of an item may be partly empty).  Without a
+    // residual the four loads read the 16-byte zero page: no branch, no phi copies (hipcc waited for the loads inside the branch)
+    const unsigned boff = (unsigned)(g4 * 4);
+    auto issue_loads = [&](int nn, float4& sh, float4 (&rr)[4]) __attribute__((always_inline)) {
+      const int nt = __builtin_amdgcn_readfirstlane(min(nt0 + nn, p.nT16 - 1));
+      sh = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(p.bias + nt * 16) + boff);
+      const char* rb = has_res ? reinterpret_cast<const char*>(p.res + (size_t)nt * p.out_ss) : reinterpret_cast<const char*>(g_zero_page_w4p);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) rr[i] = *reinterpret_cast<const float4*>(rb + roff[i]);
+    };
+    auto pin = [&](float4& sh, float4 (&rr)[4]) __attribute__((always_inline)) {      // hipcc's wait for these registers goes HERE
+      asm volatile("" : "+v"(sh.x), "+v"(sh.y), "+v"(sh.z), "+v"(sh.w));
+#pragma unroll
+      for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(rr[i].x), "+v"(rr[i].y), "+v"(rr[i].z), "+v"(rr[i].w));
+    };
+    float4 sh, rr[4];
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
-      __syncthreads();                                      // previous round's reads finished everywhere
+      W4P_T(e0);
+      if (n > 0 || !(W4P_EPI & 4)) __syncthreads();         // previous round's reads finished everywhere (round 0: the last slice barrier did that)
+      W4P_T(e1);
 #pragma unroll
       for (int r = 0; r < 2; ++r)
 #pragma unroll
@@ -430,7 +503,108 @@ __device__ __forceinline__ void w4p_consumer(const W4PParams& p, float4* smem, i
           }
           xch[((wave * 2 + r) * 4 + j) * 64 + lane] = make_float4(z[0], z[1], z[2], z[3]);
         }
+      if (n == 0) issue_loads(0, sh, rr);
+      W4P_T(e2);
       __syncthreads();
+      W4P_T(e3);
+      W4P_ACC(8, e0, e1); W4P_ACC(9, e1, e2); W4P_ACC(10, e2, e3);
+      // the next round's loads: right behind the barrier when the registers allow it (<= 36 accumulators still live), else after
+      // this round's output transform (NT = 3, round 0: their latency is exposed once per item)
+      const bool early = (NT - 1 - n) <= 1;
+      float4 shn, rrn[4];
+      if (n + 1 < NT && early) issue_loads(n + 1, shn, rrn);
+      // Every wave finishes one output COLUMN j = Q of the 4x4 blocks: Y[i][Q] = sum_k A^T[i][k] Z[k][Q] needs the six rows of Z
+      // for that one column only = 8 exchange reads (rows 1 and 4 are split between two waves) instead of the 32 an output
+      // row would need (the exchange rounds are LDS-bandwidth-bound: 8 KiB written + 8 KiB read per wave and round).
+      // rows of Z: 0 = q0.r0 | 1 = q0.r1 + q1.r0 | 2 = q1.r1 | 3 = q2.r0 | 4 = q2.r1 + q3.r0 | 5 = q3.r1
+      const int w0 = grp * 4;
+      auto ld = [&](int q, int r) {
+        const float4 z = xch[(((w0 + q) * 2 + r) * 4 + jc) * 64 + lane];
+        return (f32x4){z.x, z.y, z.z, z.w};
+      };
+      f32x4 zr[6];
+      zr[0] = ld(0, 0); zr[1] = ld(0, 1) + ld(1, 0); zr[2] = ld(1, 1);
+      zr[3] = ld(2, 0); zr[4] = ld(2, 1) + ld(3, 0); zr[5] = ld(3, 1);
+      f32x4 y[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        f32x4 v = (f32x4){sh.x, sh.y, sh.z, sh.w};
+#pragma unroll
+        for (int k = 0; k < 6; ++k)
+          if (at_c(i, k) != 0.f) v += at_c(i, k) * zr[k];
+        y[i] = v;
+      }
+      // residual before the activation (BasicBlock, hrnet.py:42-58) or behind it (hrnet_cls.py:475-477): a wave-uniform BRANCH - as
+      // two selects per value (what hipcc makes of `if (flag) v += r` on both sides of the clamp) it was 32 v_cndmask per round
+      if (p.res_after_act) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float4 r = rr[i];
+          f32x4 v = y[i];
+          v[0] = fmaxf(v[0], lo) + r.x; v[1] = fmaxf(v[1], lo) + r.y; v[2] = fmaxf(v[2], lo) + r.z; v[3] = fmaxf(v[3], lo) + r.w;
+          y[i] = v;
+          asm volatile("" : "+v"(y[i][0]), "+v"(y[i][1]), "+v"(y[i][2]), "+v"(y[i][3]));
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float4 r = rr[i];
+          f32x4 v = y[i];
+          v[0] = fmaxf(v[0] + r.x, lo); v[1] = fmaxf(v[1] + r.y, lo); v[2] = fmaxf(v[2] + r.z, lo); v[3] = fmaxf(v[3] + r.w, lo);
+          y[i] = v;
+          asm volatile("" : "+v"(y[i][0]), "+v"(y[i][1]), "+v"(y[i][2]), "+v"(y[i][3]));      // (computed here, not sunk behind the wait below)
+        }
+      }
+      W4P_T(e4);
+      if (n + 1 < NT) {
+        if (!early) issue_loads(n + 1, shn, rrn);
+        pin(shn, rrn);
+      }
+      W4P_T(e5);
+      if (nt0 + n < p.nT16) {
+        char* ob = reinterpret_cast<char*>(p.out + (size_t)(nt0 + n) * p.out_ss);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          // (streaming stores - __builtin_nontemporal_store - make a launch 1.5 us faster alone and the whole forward 0.5 % slower:
+          // the next conv finds less of its input in the L2.  W4P_EXP & 2048: probe without the stores.)
+          if (okx && oky[i] && !((W4P_EXP & 2048) && p.B < 100000))
+            *reinterpret_cast<float4*>(ob + ooff[i]) = make_float4(y[i][0], y[i][1], y[i][2], y[i][3]);
+        }
+      }
+      W4P_T(e6);
+      W4P_ACC(11, e3, e4); W4P_ACC(12, e4, e5); W4P_ACC(13, e5, e6);
+      if (n + 1 < NT) {
+        sh = shn;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) rr[i] = rrn[i];
+      }
+    }
+#else
+    // ---- Z = M A (partial over this wave's columns), exchanged one n-tile at a time; wave Q finishes output column Q --------
+    // exchange area [8 waves][2 rows][4 cols][64] float4 (64 KiB) over ring slots that are dead now
+    const int oyb = tl.oy0, oxb = 4 * tl.tx;
+    float4* xch = smem + p.xoff;
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      W4P_T(e0);
+      if (n > 0 || !(W4P_EPI & 4)) __syncthreads();         // previous round's reads finished everywhere
+      W4P_T(e1);
+#pragma unroll
+      for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          f32x4 z = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int i = 0; i < 9; ++i) {
+            const int nu = w4p_nu(Q, i);
+            if (w4p_row(Q, i) == r && at_c(j, nu) != 0.f) z += at_c(j, nu) * acc[i][n];
+          }
+          xch[((wave * 2 + r) * 4 + j) * 64 + lane] = make_float4(z[0], z[1], z[2], z[3]);
+        }
+      W4P_T(e2);
+      __syncthreads();
+      W4P_T(e3);
+      W4P_ACC(8, e0, e1); W4P_ACC(9, e1, e2); W4P_ACC(10, e2, e3);
       if (nt0 + n < p.nT16) {
         // Every wave finishes one output COLUMN j = Q of the 4x4 blocks: Y[i][Q] = sum_k A^T[i][k] Z[k][Q] needs the six rows of Z
         // for that one column only = 8 exchange reads (rows 1 and 4 are split between two waves) instead of the 32 an output
@@ -498,7 +672,10 @@ __device__ __forceinline__ void w4p_consumer(const W4PParams& p, float4* smem, i
             *reinterpret_cast<float4*>(p.out + ooff[i]) = make_float4(v[0], v[1], v[2], v[3]);
         }
       }
+      W4P_T(e6);
+      W4P_ACC(11, e3, e6);
     }
+#endif
     __syncthreads();                                        // the exchange area is free again (next item's rings / V)
 #if W4P_TRACE
     W4P_T(c_e1);
@@ -506,6 +683,7 @@ __device__ __forceinline__ void w4p_consumer(const W4PParams& p, float4* smem, i
     if (trace && lane == 0) {
       if (wave == 0) { for (int k = 0; k < 4; ++k) g_w4p_trace[k] = tr[k]; g_w4p_trace[4] = (unsigned long long)p.nC4; }
       g_w4p_trace[16 + 2 * wave] = tr[1]; g_w4p_trace[17 + 2 * wave] = tr[2]; g_w4p_trace[48 + wave] = tr[4];
+      if (wave == 0 || wave == 5) for (int k = 0; k < 6; ++k) g_w4p_trace[(wave == 0 ? 56 : 64) + k] = tr[8 + k];
     }
 #endif
   }
@@ -555,6 +733,45 @@ __device__ __forceinline__ void w4p_producer(const W4PParams& p, float4* smem, i
         const int n = i / 9, j = i - n * 9;
         const float4* src = p.ufrag + (((size_t)0 * p.nT16 + min(nt0 + n, p.nT16 - 1)) * 9 + j) * 64;
         w4::dma16_sv(src, (unsigned)lane * 16u, (unsigned)__builtin_amdgcn_readfirstlane((int)(lds_base + (unsigned)(p.uoff + i * 64) * 16u)));
+        if ((W4P_EPI & 1) && p.nC4 > 1)                      // U(1) -> ring slot 1 (free during the exchange rounds in the round-5 layout)
+          w4::dma16_sv(src + (size_t)p.nT16 * 9 * 64, (unsigned)lane * 16u,
+                       (unsigned)__builtin_amdgcn_readfirstlane((int)(lds_base + (unsigned)(p.uoff + uF4 + i * 64) * 16u)));
+      }
+    }
+  };
+  // the same fetches as a list of jobs - [zero the padding slots | raw(0..2): 3 x 4 pieces | U(0), U(1): 2 x ceil(9 NT / 4) pieces] -
+  // of which part `part` of `nparts` is issued (both compile-time constants after unrolling)
+  auto prefetch_part = [&](int item, const int (&goff)[4], int part, int nparts) __attribute__((always_inline)) {
+    constexpr int NU = (9 * NT + W4P_NPROD - 1) / W4P_NPROD;
+    constexpr int NJ = 12 + 2 * NU;
+    const int lo = part * NJ / nparts, hi = (part + 1) * NJ / nparts;
+    const int nt0 = (item / p.nblocks_m) * NT;
+    if (part == 0) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int piece = pw + W4P_NPROD * k;
+        if (piece < npieces_raw && goff[k] < 0) {
+#pragma unroll
+          for (int slot = 0; slot < 3; ++slot) smem[slot * rawF4 + piece * 64 + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      if (j < lo || j >= hi) continue;
+      if (j < 12) {
+        const int c4 = j >> 2, k = j & 3;
+        const int piece = pw + W4P_NPROD * k;
+        if (piece < npieces_raw && goff[k] >= 0 && c4 < p.nC4)
+          w4::dma16_sv(p.in + (size_t)(c4 >> 2) * p.in_ss + (c4 & 3) * 4, (unsigned)goff[k] * 4u,
+                       (unsigned)__builtin_amdgcn_readfirstlane((int)(lds_base + (unsigned)(c4 * rawF4 + piece * 64) * 16u)));
+      } else {
+        const int c4 = (j - 12) / NU, i = pw + W4P_NPROD * ((j - 12) % NU);
+        if (i < 9 * NT && c4 < p.nC4 && c4 < ((W4P_EPI & 1) ? 2 : 1)) {       // (U(1) only where its slot is outside the exchange area)
+          const int n = i / 9, jj = i - n * 9;
+          const float4* src = p.ufrag + (((size_t)c4 * p.nT16 + min(nt0 + n, p.nT16 - 1)) * 9 + jj) * 64;
+          w4::dma16_sv(src, (unsigned)lane * 16u, (unsigned)__builtin_amdgcn_readfirstlane((int)(lds_base + (unsigned)(p.uoff + c4 * uF4 + i * 64) * 16u)));
+        }
       }
     }
   };
@@ -645,7 +862,7 @@ __device__ __forceinline__ void w4p_producer(const W4PParams& p, float4* smem, i
     };
 
     const int S = p.nC4;
-    if (S > 1) issue_u1(item);
+    if (!(W4P_EPI & 1) && S > 1) issue_u1(item);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                                        // B0: raw(0..2), U(0..1) have landed
     load_window(0);
@@ -677,9 +894,22 @@ __device__ __forceinline__ void w4p_producer(const W4PParams& p, float4* smem, i
       g_w4p_trace[32 + 4 * pw] = tr[0]; g_w4p_trace[33 + 4 * pw] = tr[3]; g_w4p_trace[34 + 4 * pw] = tr[5];
     }
 #endif
-    if (item + wk.step < wk.end) prefetch_item(item + wk.step);          // ... while the MFMA waves exchange and store
+    const bool more = item + wk.step < wk.end;
+    if constexpr ((W4P_EPI & 4) != 0) {
+      // the next item's first fetches, dealt over the 2 NT gaps between the barriers of the exchange rounds (no barrier in front of
+      // round 0): ~5 LDS-DMA instructions (~60 clk each) per gap, so that this wave is never the last one at a barrier
+      int goffn[4];
+      if (more) raw_piece_offsets<4, FLAT>(p, item + wk.step, pw, W4P_NPROD, lane, goffn);
 #pragma unroll
-    for (int n = 0; n < NT; ++n) { __syncthreads(); __syncthreads(); }   // the MFMA waves' exchange rounds
+      for (int gap = 0; gap < 2 * NT; ++gap) {
+        if (gap > 0) __syncthreads();
+        if (more) prefetch_part(item + wk.step, goffn, gap, 2 * NT);
+      }
+    } else {
+      if (more) prefetch_item(item + wk.step);                           // ... while the MFMA waves exchange and store
+#pragma unroll
+      for (int n = 0; n < NT; ++n) { __syncthreads(); __syncthreads(); }   // the MFMA waves' exchange rounds
+    }
     __syncthreads();
   }
 }
@@ -736,9 +966,11 @@ bool w4p_geo(const ConvDesc& d, const ConvCfg& cfg, w4::Geo* g, W4PLayout* L, Fl
   L->uoff = 3 * g->rawF4;
   L->voff = L->uoff + 3 * uF4;
   const int end = L->voff + 2 * vF4;
-  // the exchange area overlays U ring slots 1, 2 and the V buffers (slot 0 and the raw ring may receive the next item's
-  // first fetches during the exchange rounds) and extends past them when they are smaller than 64 KiB (NT = 1)
-  L->xoff = L->uoff + uF4;
+  // Round 4: the exchange area overlaid U ring slots 1, 2 and the V buffers (slot 0 and the raw ring received the next item's
+  // first fetches during the exchange rounds), so U(1) could only be requested at the item start and its whole round trip was
+  // exposed there.  Round 5 (W4P_EPI & 1): the area starts behind U slot 1 - at NT = 3 with flat items U slot 2 + V + the spare KiB
+  // are exactly 64 KiB and the block uses exactly 160 KiB - so both U(0) and U(1) travel during the exchange rounds.
+  L->xoff = L->uoff + ((W4P_EPI & 1) ? 2 : 1) * uF4;
   L->totalF4 = std::max(end, L->xoff + W4P_XCH);
   return (size_t)L->totalF4 * sizeof(float4) <= 160 * 1024;
 }
@@ -846,6 +1078,6 @@ int conv_wino4p_launch(const ConvDesc& d, const ConvCfg& cfg, hipStream_t stream
 
 #if W4P_TRACE
 extern "C" int poco_w4p_trace(unsigned long long* host_out, int n) {
-  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_w4p_trace), sizeof(unsigned long long) * (size_t)std::min(n, 64)) == hipSuccess ? 0 : 1;
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_w4p_trace), sizeof(unsigned long long) * (size_t)std::min(n, 96)) == hipSuccess ? 0 : 1;
 }
 #endif

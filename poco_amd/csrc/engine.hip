@@ -1683,13 +1683,43 @@ static int enqueue_program(Engine* e, int B, const IO& io, hipStream_t main) {
   return POCO_OK;
 }
 
+// ABI 4: the caller's I/O structs say how many bytes they have (include/poco_hip.h).  Copy exactly those into a zeroed struct of
+// THIS library's layout: members the caller's header does not have read as NULL, a non-NULL member this library does not know is
+// refused, and a size no header of this ABI could have produced (0, not 8-byte granular, a pointer's bit pattern) is refused - a
+// binding written from an older field list cannot make the engine read past its struct any more.
+template <class T>
+static int sized_struct_copy(const T* src, T* dst, const char* what) {
+  uint64_t sz;
+  std::memcpy(&sz, src, sizeof sz);
+  if (sz < 2 * sizeof(void*) || (sz & 7) || sz > 4096) {
+    poco_set_error(std::string(what) + ".struct_size = " + std::to_string(sz) + " is not the size of any " + what +
+                   " of ABI " + std::to_string(POCO_ABI_VERSION) + " (set it to sizeof(" + what + "); a struct laid out for ABI <= 3 starts with a pointer)");
+    return POCO_ERR_ARG;
+  }
+  std::memset(dst, 0, sizeof(T));
+  std::memcpy(dst, src, (size_t)std::min<uint64_t>(sz, sizeof(T)));
+  const unsigned char* extra = reinterpret_cast<const unsigned char*>(src);
+  for (uint64_t off = sizeof(T); off < sz; ++off)
+    if (extra[off]) {
+      poco_set_error(std::string(what) + " carries a non-NULL member at byte " + std::to_string(off) + ", beyond the " +
+                     std::to_string(sizeof(T)) + " bytes this library knows: it was built from an older header");
+      return POCO_ERR_ARG;
+    }
+  dst->struct_size = sizeof(T);
+  return POCO_OK;
+}
+
 extern "C" int poco_forward(poco_handle_t h, int B, const poco_inputs_t* in, const poco_outputs_t* out, void* stream) {
   Engine* e = H(h);
   if (!e || !in || !out) { poco_set_error("poco_forward: bad arguments"); return POCO_ERR_ARG; }
+  poco_inputs_t in_l;
+  poco_outputs_t out_l;
+  if (int rc = sized_struct_copy(in, &in_l, "poco_inputs_t")) return rc;            // (checked first: testable without a GPU)
+  if (int rc = sized_struct_copy(out, &out_l, "poco_outputs_t")) return rc;
   if (!e->finalized) { poco_set_error("poco_forward: call poco_finalize first"); return POCO_ERR_STATE; }
   if (B < 1 || B > e->max_batch) { poco_set_error("poco_forward: batch " + std::to_string(B) + " outside 1.." + std::to_string(e->max_batch)); return POCO_ERR_ARG; }
   hipStream_t caller = (hipStream_t)stream;
-  IO io{in, out};
+  IO io{&in_l, &out_l};
   int rc = enqueue_program(e, B, io, caller);
   if (rc != POCO_OK) return rc;
   hipError_t err = hipGetLastError();
@@ -1734,14 +1764,18 @@ extern "C" int poco_op_sched(poco_handle_t h, int i, int* sched, int cap) {
 extern "C" int poco_profile_ops(poco_handle_t h, int B, const poco_inputs_t* in, const poco_outputs_t* out, int iters,
                                 float* ms_per_op, int cap, void* stream) {
   Engine* e = H(h);
-  if (!e || !e->finalized || !ms_per_op) { poco_set_error("poco_profile_ops: bad state/arguments"); return POCO_ERR_ARG; }
+  if (!e || !e->finalized || !ms_per_op || !in || !out) { poco_set_error("poco_profile_ops: bad state/arguments"); return POCO_ERR_ARG; }
+  poco_inputs_t in_l;
+  poco_outputs_t out_l;
+  if (int rc = sized_struct_copy(in, &in_l, "poco_inputs_t")) return rc;
+  if (int rc = sized_struct_copy(out, &out_l, "poco_outputs_t")) return rc;
   const int n = (int)e->ops.size();
   if (cap < n) { poco_set_error("poco_profile_ops: buffer too small"); return POCO_ERR_ARG; }
   hipStream_t s = (hipStream_t)stream;
   std::vector<hipEvent_t> ev(n + 1);
   for (auto& x : ev) POCO_HIP_CHECK(hipEventCreate(&x));
   std::vector<double> acc(n, 0.0);
-  IO io{in, out};
+  IO io{&in_l, &out_l};
   for (int it = 0; it < iters + 1; ++it) {
     for (int l = 0; l < 4; ++l) e->wg_ready_act[l] = -1;
     POCO_HIP_CHECK(hipEventRecord(ev[0], s));

@@ -22,17 +22,27 @@ SMPL_KEYS = ("v_template", "shapedirs", "posedirs", "J_regressor", "J_regressor_
              "parents", "extra_vertex_ids", "joint_map")
 
 
-class _Inputs(C.Structure):
-    _fields_ = [(n, C.c_void_p) for n in ("img", "bbox_info", "focal_length", "scale", "center", "orig_shape")]
+class _SizedStruct(C.Structure):
+    """poco_inputs_t / poco_outputs_t (include/poco_hip.h, ABI 4): `struct_size` first, then the pointers, passed by keyword or
+    in header order.  The size word is always filled in here, so a field list shorter than the library's is read as NULLs
+    instead of as whatever lies behind the struct (tests/test_engine_cpu.py ties both field lists to the header)."""
+
+    def __init__(self, *ptrs, **named):
+        super().__init__(C.sizeof(type(self)), *ptrs, **named)
 
 
-class _Outputs(C.Structure):
-    _fields_ = [(n, C.c_void_p) for n in (
+class _Inputs(_SizedStruct):
+    _fields_ = [("struct_size", C.c_uint64)] + [(n, C.c_void_p) for n in (
+        "img", "bbox_info", "focal_length", "scale", "center", "orig_shape")]
+
+
+class _Outputs(_SizedStruct):
+    _fields_ = [("struct_size", C.c_uint64)] + [(n, C.c_void_p) for n in (
         "pred_pose", "pred_pose6d", "pred_shape", "pred_cam", "pred_cam_t", "pred_fullimg_cam_t", "smpl_vertices",
         "smpl_joints3d", "smpl_joints2d", "var_pose", "uncert_feat", "pred_segm_mask", "body_feat2", "backbone_feat", "record")]
 
 
-ABI_VERSION = 3          # include/poco_hip.h POCO_ABI_VERSION this binding was written against
+ABI_VERSION = 4          # include/poco_hip.h POCO_ABI_VERSION this binding was written against
 
 
 def _bind():

@@ -54,7 +54,15 @@ int main(int argc, char** argv) {
   if (load_tensor(h, "backbone.nope", w, bad_shape, 1) == 0) return 13;             /* strict names */
   poco_inputs_t in; poco_outputs_t out;
   memset(&in, 0, sizeof in); memset(&out, 0, sizeof out);
-  if (forward(h, 1, &in, &out, 0) == 0) return 14;                                  /* not finalized */
+  if (forward(h, 1, &in, &out, 0) != 1 || !strstr(last_error(), "struct_size")) return 20;   /* no size word: POCO_ERR_ARG, nothing else read */
+  in.struct_size = sizeof in; out.struct_size = sizeof out;
+  if (forward(h, 1, &in, &out, 0) != 3 || !strstr(last_error(), "finalize")) return 14;      /* well-formed, but not finalized: POCO_ERR_STATE */
+  out.struct_size = sizeof out - 4;                                                           /* a truncated struct (not pointer-granular) */
+  if (forward(h, 1, &in, &out, 0) != 1 || !strstr(last_error(), "poco_outputs_t.struct_size")) return 21;
+  out.struct_size = sizeof out - sizeof(float*);                                              /* a binding from a header without `record`: accepted */
+  if (forward(h, 1, &in, &out, 0) != 3) return 22;
+  in.struct_size = sizeof(uint64_t);                                                          /* too short to hold even `img` */
+  if (forward(h, 1, &in, &out, 0) != 1 || !strstr(last_error(), "poco_inputs_t.struct_size")) return 23;
   destroy(h);
   if (create_ex("resnet50-cliff", 4, 1, "no_such_option=1", &h) == 0) return 16;     /* unknown build option is an error ... */
   if (strstr(last_error(), "no_such_option") == 0) return 17;                         /* ... that names it */

@@ -107,6 +107,76 @@ def test_forward_before_finalize_is_an_error():
     assert rc != 0 and b"finalize" in m._L.poco_last_error()
 
 
+def _header_struct_fields(name):
+    """member names of `typedef struct { ... } <name>;` in include/poco_hip.h, in order (comments stripped)"""
+    import re
+    src = (Path(__file__).resolve().parent.parent / "include" / "poco_hip.h").read_text()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    body = re.search(r"typedef\s+struct\s*\{([^}]*)\}\s*" + name + r"\s*;", src).group(1)
+    fields = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if decl:
+            fields.append((re.sub(r"\s+", " ", decl.rsplit(None, 1)[0].replace("*", " * ")).strip(), decl.rsplit(None, 1)[1].lstrip("*")))
+    return fields
+
+
+def test_binding_field_lists_match_the_header():
+    """the INTEGRATION.md ctypes stub listed 14 outputs while poco_outputs_t had 15 - a binding copied from
+    it handed poco_forward a struct 8 bytes short.  The header is the single source: model.py's structs AND the stub in
+    INTEGRATION.md must list exactly its members, in its order, with the size word first."""
+    import re
+    from poco_amd import model
+    root = Path(__file__).resolve().parent.parent
+    doc = (root / "INTEGRATION.md").read_text()
+    assert f"ABI = {model.ABI_VERSION}" in doc and "poco_abi_version() == ABI" in doc      # the stub checks the version itself
+    header_version = int(re.search(r"#define POCO_ABI_VERSION (\d+)", (root / "include" / "poco_hip.h").read_text()).group(1))
+    assert header_version == model.ABI_VERSION
+    # the stub's two class statements are executed as written in the document
+    stub = re.search(r"^class Inputs\(C\.Structure\):.*?(?=^# struct_size)", doc, flags=re.S | re.M).group(0)
+    ns = {"C": C}
+    exec(stub, ns)
+    for cname, struct, docclass in (("poco_inputs_t", model._Inputs, "Inputs"), ("poco_outputs_t", model._Outputs, "Outputs")):
+        hf = _header_struct_fields(cname)
+        assert hf[0] == ("uint64_t", "struct_size"), hf[0]
+        assert all("float *" in t for t, _ in hf[1:]), hf
+        names = [n for _, n in hf]
+        for binding in (struct, ns[docclass]):
+            assert [n for n, _ in binding._fields_] == names, (binding, "field list != include/poco_hip.h")
+            assert binding._fields_[0][1] is C.c_uint64 and all(t is C.c_void_p for _, t in binding._fields_[1:])
+            assert C.sizeof(binding) == 8 * len(names)                 # no padding: what the library's sizeof(T) is
+        assert struct().struct_size == 8 * len(names)                  # filled in by the constructor
+
+
+def test_forward_refuses_structs_without_a_valid_size_word():
+    """the size word is checked before anything else is read (and before the finalize check, so no GPU is needed)"""
+    from poco_amd.model import _Inputs, _Outputs
+    m = POCO(backbone="resnet50-cliff", num_flow_layers=1, max_batch=1)
+    fwd, err = m._L.poco_forward, m._L.poco_last_error
+
+    class OldOutputs(C.Structure):        # an ABI-3 struct: starts with a pointer
+        _fields_ = [(n, C.c_void_p) for n, _ in _Outputs._fields_[1:]]
+    old = OldOutputs(pred_pose=0x7F0012345000)
+    assert fwd(m._h, 1, C.byref(_Inputs()), C.cast(C.byref(old), C.POINTER(_Outputs)), None) == 1 and b"struct_size" in err()
+    for bad in (0, 8, 12, 8192):
+        o = _Outputs(); o.struct_size = bad
+        assert fwd(m._h, 1, C.byref(_Inputs()), C.byref(o), None) == 1 and b"poco_outputs_t.struct_size" in err(), bad
+        i = _Inputs(); i.struct_size = bad
+        assert fwd(m._h, 1, C.byref(i), C.byref(_Outputs()), None) == 1 and b"poco_inputs_t.struct_size" in err(), bad
+
+    class Short(C.Structure):             # a binding written from a shorter field list: accepted, the rest reads as NULL
+        _fields_ = _Outputs._fields_[:-1]
+    s = Short(C.sizeof(Short))
+    assert fwd(m._h, 1, C.byref(_Inputs()), C.cast(C.byref(s), C.POINTER(_Outputs)), None) == 3 and b"finalize" in err()
+
+    class Longer(C.Structure):            # a binding from a NEWER header: fine while the unknown members are NULL ...
+        _fields_ = _Outputs._fields_ + [("future", C.c_void_p)]
+    lg = Longer(C.sizeof(Longer))
+    assert fwd(m._h, 1, C.byref(_Inputs()), C.cast(C.byref(lg), C.POINTER(_Outputs)), None) == 3
+    lg.future = 0x1000                     # ... and refused as soon as one of them is asked for
+    assert fwd(m._h, 1, C.byref(_Inputs()), C.cast(C.byref(lg), C.POINTER(_Outputs)), None) == 1 and b"beyond" in err()
+
+
 @pytest.mark.parametrize("variant", list(VARIANTS))
 def test_tuned_table_entries_are_valid_configurations(variant):
     """poco_amd/tuned/gfx950.json against the library's own validation (no GPU needed: geometry + LDS budget):
