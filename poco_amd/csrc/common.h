@@ -49,6 +49,9 @@ struct ConvCfg {
                //    groups, WN = 4 position quarters, R = output rows per slab (multiple of 4), NI slabs (<= 32 tiles)
                // 8: ALG 7's arithmetic and geometry with specialised waves (conv_wino4p.hip): 8 MFMA waves + 4 producer
                //    waves (LDS-DMA + input transform, V staged in LDS); same cfg fields as ALG 7
+               // 13: F(4x4,3x3) with WHOLE-POSITION MFMA waves (conv_wino4w.hip; round 5): a block = 2 NT MFMA waves (all 36 positions of
+               //    one 16-tile group x one n-tile each, register-only output transform: no exchange) + 2 producer waves, slice pipeline
+               //    continuous across items; NT 1..3, WM = 2, WN = 1, R / NI as ALG 8 (flat items: R = 4, NI = 0)
                // 6: 1x1 conv (stride 1|2) as a register-direct GEMM, no LDS / barriers (gemm1x1.hip):
                //    (MT,NT) in {(2,4),(4,2),(4,4),(7,2),(7,4),(8,2)}, R = operand prefetch depth (2|3), NI = load schedule 1..6
                // 9: ALG 6 with coalesced global traffic: pixel / output tiles turned into the MFMA lane order through
@@ -78,6 +81,7 @@ struct ConvDesc {
   const float* wfrag_wino;                // 3x3 stride-1 only: Winograd-transformed weights (ALG 3), nullable
   const float* wfrag_wino4 = nullptr;     // 3x3 stride-1 only: F(4x4,3x3) weight fragments, 36 positions (ALG 7), nullable
   const float* wfrag_wino4p = nullptr;    // the same weights in the LDS order of ALG 8 (conv_wino4p.hip), nullable
+  const float* wfrag_wino4w = nullptr;    // the same weights in the LDS order of ALG 13 (conv_wino4w.hip), nullable
   const float* wfrag_wino4g = nullptr;    // 3x3 stride-1 convs on planes <= 8x8: per-position GEMM fragments of ALG 11 (conv_wino4g.hip)
   const float* wfrag_h = nullptr;         // EXPERIMENT (ALG 12, gemm1x1h.hip): hi / lo fp16 halves of the 1x1 weights, nullable
   float* scratch = nullptr;               // ALG 11: V + M staging (conv_wino4g_scratch_floats), owned by the caller
@@ -148,6 +152,12 @@ size_t conv_wino4p_packed_floats(int Cin, int Cout16);
 void conv_wino4p_pack_weights(const float* w_oihw, const float* scale, int Cout, int Cin, int Cout16, float* dst);
 size_t conv_wino4p_lds_bytes(const ConvDesc& d, const ConvCfg& cfg);
 int conv_wino4p_launch(const ConvDesc& d, const ConvCfg& cfg, hipStream_t stream);
+
+// ---- Winograd F(4x4,3x3) with whole-position MFMA waves (conv_wino4w.hip), ALG 13 ---------------------
+size_t conv_wino4w_packed_floats(int Cin, int Cout16);
+void conv_wino4w_pack_weights(const float* w_oihw, const float* scale, int Cout, int Cin, int Cout16, float* dst);
+size_t conv_wino4w_lds_bytes(const ConvDesc& d, const ConvCfg& cfg);
+int conv_wino4w_launch(const ConvDesc& d, const ConvCfg& cfg, hipStream_t stream);
 
 // ---- Winograd F(2x2,3x3) variant (conv_wino.hip) --------------------------------------------------
 #include <vector>

@@ -102,6 +102,7 @@ size_t conv_lds_bytes(const ConvDesc& d, const ConvCfg& cfg) {
   if (cfg.ALG == 12) return gemm1x1h_cfg_valid(d, cfg) ? 16 : 0;
   if (cfg.ALG == 7) return conv_wino4_lds_bytes(d, cfg);
   if (cfg.ALG == 8) return conv_wino4p_lds_bytes(d, cfg);
+  if (cfg.ALG == 13) return conv_wino4w_lds_bytes(d, cfg);
   if (cfg.ALG == 3 || cfg.ALG == 4) return conv_wino_lds_bytes(d, cfg);
   Geometry g;
   if (!geometry(d, cfg, &g)) return 0;
@@ -185,6 +186,7 @@ int conv_launch(const ConvDesc& d, const ConvCfg& cfg, hipStream_t stream) {
   if (cfg.ALG == 12) return gemm1x1h_launch(d, cfg, stream);
   if (cfg.ALG == 7) return conv_wino4_launch(d, cfg, stream);
   if (cfg.ALG == 8) return conv_wino4p_launch(d, cfg, stream);
+  if (cfg.ALG == 13) return conv_wino4w_launch(d, cfg, stream);
   if (cfg.ALG == 3 || cfg.ALG == 4) {
     if (d.Cin % 16 || d.Cout % 16 || ((d.in_cs | d.in_co | d.out_cs | d.out_co | d.res_cs | d.res_co) & 3)) {
       poco_set_error("conv: channel counts/strides must be multiples of 16/4");

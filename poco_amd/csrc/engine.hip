@@ -76,6 +76,7 @@ struct Op {
   float* bdev = nullptr;
   float* wdev_wino = nullptr;   // 3x3 stride-1 convs: Winograd-transformed weights (ALG 3)
   float* wdev_wino4p = nullptr; // the same in the LDS order of ALG 8
+  float* wdev_wino4w = nullptr; // ... and in the quad order of ALG 13 (conv_wino4w.hip)
   float* wdev_wino4g = nullptr; // planes <= 8x8: per-position GEMM fragments of ALG 11 (conv_wino4g.hip)
   float* wdev_h = nullptr;      // POCO_SPLIT_F16=1 only: hi / lo fp16 halves of a plain 1x1 conv's weights (ALG 12 experiment)
   float* wdev_wino4 = nullptr;  // 3x3 stride-1 convs on planes >= 28x28: F(4x4,3x3) fragments (ALG 7)
@@ -404,6 +405,9 @@ struct Builder {
           }
           conv_wino4p_pack_weights(wp, scale.data(), Cout, Cin, Cout16, pu4.data());     // same size, other order
           op.wdev_wino4p = upload(pu4);
+          pu4.resize(conv_wino4w_packed_floats(Cin, Cout16));                             // ALG 13: whole-position waves (+ slack)
+          conv_wino4w_pack_weights(wp, scale.data(), Cout, Cin, Cout16, pu4.data());
+          op.wdev_wino4w = upload(pu4);
         }
         if (ain.H <= e.opts.wg_max_plane && ain.W <= e.opts.wg_max_plane && ain.H * ain.W > 1 && actfn <= 1) {      // 7x7 planes: F(4x4,3x3) as 36 position GEMMs (ALG 11)
           std::vector<float> pg(conv_wino4g_packed_floats(Cin, Cout16));
@@ -1360,7 +1364,7 @@ int run_op(Engine& e, Op& op, int B, const IO& io, hipStream_t s) {
       d.in = aptr(e, op.in); d.in_cs = ai.C; d.in_co = 0;
       if (op.res.act >= 0) { d.res = aptr(e, op.res); d.res_cs = e.acts[op.res.act].C; }
       d.out = aptr(e, op.out); d.out_cs = ao.C; d.out_co = 0;
-      d.wfrag = op.wdev; d.bias = op.bdev; d.wfrag_wino = op.wdev_wino; d.wfrag_wino4 = op.wdev_wino4; d.wfrag_wino4p = op.wdev_wino4p;
+      d.wfrag = op.wdev; d.bias = op.bdev; d.wfrag_wino = op.wdev_wino; d.wfrag_wino4 = op.wdev_wino4; d.wfrag_wino4p = op.wdev_wino4p; d.wfrag_wino4w = op.wdev_wino4w;
       d.wfrag_wino4g = op.wdev_wino4g; d.scratch = e.wino4g_scratch[op.lane & 3]; d.scratch_floats = e.wino4g_scratch_need;
       d.B = B; d.H = ai.H; d.W = ai.W; d.Cin = op.Cin; d.Cout = op.Cout; d.ks = op.ks; d.stride = op.stride;
       d.act = op.actfn; d.res_after_act = op.res_after; d.relu_from = op.relu_from;
@@ -1815,6 +1819,7 @@ extern "C" int poco_set_conv_cfg(poco_handle_t h, int op_index, int B, const int
       ((c.ALG == 3 || c.ALG == 4) && (op.actfn == 3 || op.actfn == 2)) ||
       (c.ALG == 7 && ((op.wdev_wino4 == nullptr && e->finalized) || ai.H < 28 || ai.W < 28 || op.actfn >= 2)) ||
       (c.ALG == 8 && ((op.wdev_wino4p == nullptr && e->finalized) || ai.H < 14 || ai.W < 14 || op.actfn >= 2)) ||
+      (c.ALG == 13 && ((op.wdev_wino4w == nullptr && e->finalized) || ai.H < 14 || ai.W < 14 || op.actfn >= 2)) ||
       (c.ALG == 11 && ((op.wdev_wino4g == nullptr && e->finalized) || ai.H > e->opts.wg_max_plane || ai.W > e->opts.wg_max_plane || ai.H * ai.W <= 1 || op.actfn >= 2))) {     // (its scratch is sized for max_batch; poco_forward refuses larger batches)
     poco_set_error("poco_set_conv_cfg: configuration does not fit op '" + op.name + "' at this batch size");
     return POCO_ERR_ARG;

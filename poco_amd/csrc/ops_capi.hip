@@ -44,7 +44,7 @@ static int conv_common(const float* d_in, int B, int H, int W, int Cin, const fl
   std::vector<float> shift(Cout16, 0.f);
   if (h_shift)
     for (int i = 0; i < Cout; ++i) shift[i] = h_shift[i];
-  DevBuf dw, db, dwu, dwu4, dwu4p, dwu4g, dscr;
+  DevBuf dw, db, dwu, dwu4, dwu4p, dwu4w, dwu4g, dscr;
   POCO_HIP_CHECK(dw.upload(packed));
   POCO_HIP_CHECK(db.upload(shift));
   ConvDesc d{};
@@ -72,6 +72,12 @@ static int conv_common(const float* d_in, int B, int H, int W, int Cin, const fl
       conv_wino4p_pack_weights(h_w, h_scale, Cout, Cin, Cout16, pu4.data());
       POCO_HIP_CHECK(dwu4p.upload(pu4));
       d.wfrag_wino4p = dwu4p.p;
+    }
+    if (cfg7 && cfg7[6] == 13) {                  // ... and in the quad order of the whole-position kernel
+      std::vector<float> pu4(conv_wino4w_packed_floats(Cin, Cout16));
+      conv_wino4w_pack_weights(h_w, h_scale, Cout, Cin, Cout16, pu4.data());
+      POCO_HIP_CHECK(dwu4w.upload(pu4));
+      d.wfrag_wino4w = dwu4w.p;
     }
     if (cfg7 && cfg7[6] == 11) {                  // F(4x4,3x3) as 36 position GEMMs: per-position fragments + V / M staging
       std::vector<float> pg(conv_wino4g_packed_floats(Cin, Cout16));
@@ -162,9 +168,9 @@ extern "C" int poco_tune_conv(int B, int H, int W, int Cin, int Cout, int ks, in
     for (auto& v : hu) v = rnd() * ws;
     POCO_HIP_CHECK(dwu.upload(hu));
     bool any7 = false;
-    for (int i = 0; i < ncfg; ++i) any7 = any7 || cfgs6[CONV_CFG_INTS * i + 6] == 7 || cfgs6[CONV_CFG_INTS * i + 6] == 8;
+    for (int i = 0; i < ncfg; ++i) any7 = any7 || cfgs6[CONV_CFG_INTS * i + 6] == 7 || cfgs6[CONV_CFG_INTS * i + 6] == 8 || cfgs6[CONV_CFG_INTS * i + 6] == 13;
     if (any7) {
-      std::vector<float> hu4((size_t)36 * Cin * Cout);
+      std::vector<float> hu4((size_t)36 * Cin * Cout + 2 * 9 * 256);          // (+ the slack ALG 13 reads behind the last n-tile)
       for (auto& v : hu4) v = rnd() * ws;
       POCO_HIP_CHECK(dwu4.upload(hu4));
     }
@@ -175,7 +181,7 @@ extern "C" int poco_tune_conv(int B, int H, int W, int Cin, int Cout, int ks, in
   POCO_HIP_CHECK(hipMalloc(&dout.p, nout * sizeof(float)));
   ConvDesc d{};
   d.in = din.p; d.in_cs = Cin; d.out = dout.p; d.out_cs = Cout; d.wfrag = dw.p; d.bias = db.p;
-  d.wfrag_wino = dwu.p; d.wfrag_wino4 = dwu4.p; d.wfrag_wino4p = dwu4.p;     // timing only: random fragments serve both orders
+  d.wfrag_wino = dwu.p; d.wfrag_wino4 = dwu4.p; d.wfrag_wino4p = dwu4.p; d.wfrag_wino4w = dwu4.p;     // timing only: random fragments serve all orders
   if (any11 && ks == 3 && stride == 1 && H <= 16 && W <= 16) {
     std::vector<float> hg(conv_wino4g_packed_floats(Cin, Cout));
     for (auto& v : hg) v = rnd() * ws;

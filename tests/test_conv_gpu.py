@@ -494,6 +494,47 @@ def test_conv_winograd_f4x4_flat_items(case, nt, cuda):
     assert np.array_equal(out, rect)
 
 
+@pytest.mark.parametrize("flat", [0, 1])
+@pytest.mark.parametrize("nt", [1, 2, 3])
+@pytest.mark.parametrize("case", WINO4 + [(64, 28, 28, 16, 32, True), (9, 56, 56, 16, 16, False), (33, 14, 14, 32, 32, True),
+                                          (64, 14, 14, 48, 112, True), (3, 56, 56, 64, 128, True)],
+                         ids=lambda c: "x".join(map(str, c)))
+def test_conv_winograd_f4x4_whole_position_waves(case, nt, flat, cuda):
+    """ALG 13 (round 5, conv_wino4w.hip): every MFMA wave owns all 36 positions of a 16-tile group for one n-tile, the output
+    transform is register-only (no exchange rounds), the slice pipeline runs on across item boundaries (ring phases, the producers'
+    windows and the padding lanes of the raw ring switch items mid-stream) and items are walked n-group-innermost.  Rectangular and
+    flat items, one to many items per block, several n-groups with a partly empty last one (112 = 7 n-tiles), ragged planes: all
+    must equal the fp64 conv; and since the arithmetic per (tile, channel) is ALG 8's up to the summation tree of the output
+    transform, the result must also agree with ALG 8 to a few ulp."""
+    from poco_amd import ops
+    B, H, W, Cin, Cout, has_res = case
+    rect = _wino4_cfg(H, W, nt, 8)
+    cfg = (1, nt, 2, 1, 4, 0, 13) if flat else rect[:3] + (1,) + rect[4:6] + (13,)
+    TX = (W + 3) // 4
+    fmax = (TX - 1 + 32 + TX - 1) // TX
+    npos = 6 * (128 + 2 * fmax)
+    raw = (npos + npos // 16 + 1 + 63) // 64 * 64
+    fits = not flat or (raw <= 1024 and (3 * raw + 3 * nt * 576 + 4 * 576) * 16 <= 160 * 1024)
+    rng = np.random.default_rng(B * 131 + Cin + Cout + nt)
+    x = rng.standard_normal((B, H, W, Cin)).astype(np.float32)
+    w = (rng.standard_normal((Cout, Cin, 3, 3)) / np.sqrt(9 * Cin)).astype(np.float32)
+    scale = rng.uniform(0.5, 1.5, Cout).astype(np.float32)
+    shift = rng.uniform(-0.5, 0.5, Cout).astype(np.float32)
+    res = rng.standard_normal((B, H, W, Cout)).astype(np.float32) if has_res else None
+    args = (torch.from_numpy(x).to(cuda), w, scale, shift, 1, None if res is None else torch.from_numpy(res).to(cuda), True)
+    if not fits:
+        with pytest.raises(RuntimeError):
+            ops.conv2d_nhwc(*args, cfg=cfg)
+        return
+    out = ops.conv2d_nhwc(*args, cfg=cfg).cpu().numpy()
+    ref = _ref(x, w, scale, shift, 1, res, True)
+    assert np.abs(out - ref).max() <= 2e-4 * max(1.0, np.abs(ref).max()), np.abs(out - ref).max()
+    a8 = ops.conv2d_nhwc(*args, cfg=rect).cpu().numpy()
+    assert np.abs(out - a8).max() <= 2e-5 * max(1.0, np.abs(ref).max()), np.abs(out - a8).max()
+    # twice the same launch: bitwise (no race between the item-crossing pipeline stages)
+    assert np.array_equal(out, ops.conv2d_nhwc(*args, cfg=cfg).cpu().numpy())
+
+
 @pytest.mark.parametrize("ms", [2, 4, 8])
 @pytest.mark.parametrize("nt", [1, 3])
 @pytest.mark.parametrize("case", [(64, 14, 14, 32, 48, True), (33, 14, 14, 16, 16, False), (5, 7, 7, 32, 16, True), (19, 13, 9, 16, 32, True),
