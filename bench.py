@@ -59,6 +59,12 @@ def csrc_digest() -> str:
             # code only: // comments and blank lines do not invalidate a profile
             code = [ln.split("//")[0].rstrip() for ln in f.read_text().splitlines()]
             h.update("\n".join(ln for ln in code if ln.strip()).encode())
+    # ... and the tile configurations the launches run with: executed MFMA flops / busy cycles / traffic are properties of
+    # (kernel, configuration), and a table-only change must make a committed profile stale too; only the `cfg` lists
+    # count, re-measured ms / tflops fields of an unchanged configuration do not
+    import json
+    table = json.loads((ROOT / "poco_amd" / "tuned" / "gfx950.json").read_text())
+    h.update(json.dumps({k: v.get("cfg") for k, v in sorted(table.items())}, sort_keys=True).encode())
     return h.hexdigest()[:16]
 
 
@@ -240,6 +246,54 @@ def streaming_leg(variant, device, batch=128, people=4, batches=20):
                         f"hipGraph forward bs={batch}, 254-float records back (BASELINE config #5 shape, 1 GPU, synthetic frames)",
             "frames_per_s": round(batches * fpb / dt, 1), "crops_per_s": round(batches * batch / dt, 1),
             "ms_per_batch": round(dt / batches * 1e3, 2), "pcie_in_MB_per_batch": round(fpb * H * W * 3 / 1e6, 1)}
+
+
+def streaming_cpu_reference(variant, people=4, frames=3, threads=(16, 32)):
+    """BASELINE config #5's "wall-clock FPS vs CPU reference": the reference's per-frame pipeline on this host's cores - per detection
+    cv2.getAffineTransform + cv2.warpAffine + ToTensor + Normalize (pocolib/core/tester.py:182-203 via vibe_image_utils.py:58-107,
+    restated in oracle/crop_np.py), then ONE forward per frame on that frame's detections (tester.py:205-213), restated in
+    oracle/poco_ref.py - on the same synthetic 1080p frames / boxes as the GPU leg.  Bounded sample: 1 warm-up frame + `frames` timed
+    frames per thread count; the best thread count is reported.  The oracle is the checker / baseline here, never the product path."""
+    from oracle import crop_np, poco_ref
+    from poco_amd import synth
+    from poco_amd.tester import calculate_bbox_info, calculate_focal_length
+    H, W = 1080, 1920
+    w = synth.synth_state_dict(load_spec(variant), 0)
+    sd = poco_ref.to_torch({k: v for k, v in w.items() if v.dtype != np.int64})
+    smpl = poco_ref.to_torch(synth.synth_smpl(7))
+    rng = np.random.default_rng(0)
+    imgs = [rng.integers(0, 256, (H, W, 3), dtype=np.uint8) for _ in range(2)]
+    boxes = np.stack([np.array([rng.uniform(0.2, 0.8) * W, rng.uniform(0.3, 0.7) * H, s, s], np.float32)
+                      for s in rng.uniform(150, 600, people)])
+
+    def one_frame(img):
+        crops = crop_np.crop_normalize_np(img, boxes)                             # [people, 3, 224, 224] float32
+        b = {"img": crops}
+        if variant.endswith("cliff"):
+            shp = np.tile(np.array([[H, W]], np.float32), (people, 1))
+            fl = np.full(people, calculate_focal_length(H, W), np.float32)
+            b.update(bbox_info=np.stack([calculate_bbox_info(boxes[i, :2], boxes[i, 2] / 200.0, (H, W)) for i in range(people)]), focal_length=fl,
+                     scale=(boxes[:, 2] / 200.0).astype(np.float32), center=boxes[:, :2].astype(np.float32), orig_shape=shp)
+        return poco_ref.poco_forward(variant, sd, smpl, poco_ref.to_torch(b))
+
+    runs = []
+    try:
+        import psutil
+        phys = psutil.cpu_count(logical=False) or os.cpu_count() or 1
+    except Exception:
+        phys = os.cpu_count() or 1
+    for th in sorted({min(t, phys) for t in threads}):
+        torch.set_num_threads(th)
+        one_frame(imgs[0])
+        t0 = time.time()
+        for i in range(frames):
+            one_frame(imgs[i & 1])
+        dt = time.time() - t0
+        runs.append({"threads": th, "frames_per_s": round(frames / dt, 3), "crops_per_s": round(frames * people / dt, 2)})
+    best = max(runs, key=lambda r: r["frames_per_s"])
+    return {"frames_per_s": best["frames_per_s"], "crops_per_s": best["crops_per_s"], "threads": best["threads"], "kind": "port",
+            "runs": runs, "sample": f"oracle/crop_np.py (OpenCV 4.5.5 fixed-point warpAffine restated) + oracle/poco_ref.py, {people} "
+                                    f"detections per 1080p frame, one forward per frame as tester.py:182-213, 1 warm-up + {frames} timed frames"}
 
 
 HBM_PEAK_TBS = 8.0      # MI355X_MICROARCH.md: HBM3E ~8 TB/s (about 6.3 achievable with a streaming kernel)
@@ -471,6 +525,30 @@ def variant_leg(variant, B, device, steps=30, warmup=10):
     return res
 
 
+def summary_of(line) -> dict:
+    """Every BASELINE config's number in < 600 characters, as the LAST key of the JSON line (a record that keeps
+    only the tail of the line lost the ResNet-50 / small-batch numbers behind the verbose baseline legs)."""
+    g = lambda d, *ks: (g(d.get(ks[0]), *ks[1:]) if len(ks) > 1 else d.get(ks[0])) if isinstance(d, dict) else None
+    r = line.get("roofline", {})
+    s = {"cps": line.get("value"), "ms": line.get("ms_per_step"), "n_gpus": line.get("n_gpus"), "frac": r.get("frac"),
+         "alg_frac": r.get("algorithmic_frac"), "dom": [g(r, "dominant", "kernel"), g(r, "dominant", "avg_us"), g(r, "dominant", "frac")]}
+    for key, tag in (("resnet50-cliff_b64", "r50_b64"), ("hrnet_w32-pare_b32", "pare_b32")):
+        v = g(line, "variants", key)
+        if v:
+            s[tag] = [v.get("value"), g(v, "roofline", "frac"), g(v, "roofline", "algorithmic_frac")]
+    sb = line.get("small_batch") or {}
+    if sb:
+        s["ms_b1_4_16"] = [g(sb, f"B{b}", "ms_per_forward") for b in (1, 4, 16)]
+        s["cps_b16"] = g(sb, "B16", "crops_per_s")
+    st = line.get("streaming_cfg5") or {}
+    if st:
+        s["stream"] = {"cps": st.get("crops_per_s"), "fps": st.get("frames_per_s"), "cpu_fps": st.get("cpu_reference_fps")}
+    cb = line.get("cpu_baseline") or {}
+    if cb:
+        s["cpu"] = [cb.get("value"), cb.get("cores")]
+    return {k: v for k, v in s.items() if v is not None}
+
+
 def spawn_ranks(args) -> int:
     """`python bench.py --gpus N` without a launcher: start N ranks of this same script, one per GPU."""
     import socket
@@ -501,7 +579,8 @@ def main():
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--split-f16", action="store_true",
                     help="EXPERIMENT (never the headline): every plain 1x1 conv on the split-fp16 GEMM (fp16 hi + lo, 3 MFMAs per "
-                         "product, csrc/gemm1x1h.hip); the line is labelled and its dtype says so")
+                         "product, csrc/exp/gemm1x1h.hip); the line is labelled and its dtype says so.  Needs the experiment build: "
+                         "python -m poco_amd.build --experiments; POCO_HIP_LIB=poco_amd/lib/exp/libpoco_hip_experiments.so")
     ap.add_argument("--no-variants", action="store_true", help="skip the `variants` block (resnet50-cliff bs=64, hrnet_w32-pare bs=32)")
     ap.add_argument("--no-side", action="store_true", help="skip the `side_kernels` block (HBM/latency-bound kernels in GB/s)")
     ap.add_argument("--lanes", type=int, default=4, help="HIP streams for independent branches (1 = single stream)")
@@ -658,6 +737,15 @@ def main():
             line["streaming_cfg5"] = streaming_leg(args.variant, device)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.variant, B)
+            if "streaming_cfg5" in line:
+                try:
+                    line["streaming_cfg5"]["cpu_reference"] = streaming_cpu_reference(args.variant)
+                    line["streaming_cfg5"]["cpu_reference_fps"] = line["streaming_cfg5"]["cpu_reference"]["frames_per_s"]
+                    line["streaming_cfg5"]["gpu_over_cpu"] = round(line["streaming_cfg5"]["frames_per_s"] /
+                                                                   max(line["streaming_cfg5"]["cpu_reference_fps"], 1e-9), 1)
+                except Exception as e:                                     # (the baseline leg must never take the bench line down)
+                    line["streaming_cfg5"]["cpu_reference"] = {"error": repr(e)[:200]}
+        line["summary"] = summary_of(line)          # LAST key: survives a driver that keeps only the tail of the line
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

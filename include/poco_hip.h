@@ -100,7 +100,8 @@ int poco_create(const char* variant, int max_batch, int num_flow_layers, poco_ha
  * variable; every alternative form is chosen here, computes the same model and is compared with the default in tests/:
  *   kcat, kmerge, chain, dual, wg_fuse = 0   the separate-launch form of a fused op group (csrc/engine.hip EngineOpts)
  *   xdep, tail_lanes, up_lanes = 0           the more conservative lane schedules;  seq_phases = <bit mask>, branch_lanes = "0123"
- *   split_f16 = 1                            EXPERIMENT: plain 1x1 convs in split fp16 (never the default)
+ *   split_f16 = 1                            EXPERIMENT, only in libraries built with `python -m poco_amd.build --experiments` (an unknown
+ *                                            key in the shipped one): plain 1x1 convs in split fp16
  *   flow_ctx_rows = <n>                      context rows poco_realnvp*'s scratch is planned for at finalize (default max_batch)
  *   record_kinematic = 0|1, record_thr = <f> post-processing of poco_outputs_t.record's confidence (defaults 1, 0.40)
  * Unknown keys are an error. */
@@ -216,7 +217,9 @@ int poco_crop_normalize_f64(const unsigned char* d_frame, int H, int W, const do
                             int res, float* d_out, void* stream);
 /* The crops of a whole batch in ONE launch when they come from several frames of the same size (video / streaming mode:
  * tester.py:399-408 crops per frame): d_frames = device array of `nframes` device pointers to uint8 [H,W,3] frames,
- * d_frame_idx [N] int32 = which of them crop n is cut from.  Same arithmetic as poco_crop_normalize (float32 boxes). */
+ * d_frame_idx [N] int32 = which of them crop n is cut from (device data: cannot be validated on the host; the kernel clamps an
+ * index into 0 .. nframes - 1, so a bad one reads the wrong frame, never a wild pointer).  Same arithmetic as poco_crop_normalize
+ * (float32 boxes). */
 int poco_crop_normalize_multi(const unsigned char* const* d_frames, int nframes, const int* d_frame_idx, int H, int W,
                               const float* d_boxes, int N, double bbox_scale, int res, float* d_out, void* stream);
 

@@ -33,8 +33,14 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found (need ROCm; set HIPCC=/path/to/hipcc)")
 
 
-def _sources() -> list[Path]:
-    return sorted(list(CSRC.glob("*.hip")) + list(CSRC.glob("*.cpp")))
+def _sources(experiments: bool = False) -> list[Path]:
+    """The shipped library is csrc/*.hip.  csrc/exp/*.hip (labelled experiments that can never be the headline: the split-fp16 1x1
+    GEMM) and the `#if POCO_EXPERIMENTS` variants (3-deep rings of ALG 4) are compiled only by `python -m poco_amd.build
+    --experiments`, into lib/exp/libpoco_hip_experiments.so (select it with POCO_HIP_LIB)."""
+    srcs = list(CSRC.glob("*.hip")) + list(CSRC.glob("*.cpp"))
+    if experiments:
+        srcs += list((CSRC / "exp").glob("*.hip"))
+    return sorted(srcs)
 
 
 def _digest(src: Path) -> str:
@@ -46,13 +52,15 @@ def _digest(src: Path) -> str:
     return h.hexdigest()
 
 
-def _compile(src: Path, force: bool) -> tuple[Path, bool]:
-    obj = OBJDIR / (src.stem + ".o")
-    stamp = OBJDIR / (src.stem + ".sha")
+def _compile(src: Path, force: bool, experiments: bool = False) -> tuple[Path, bool]:
+    objdir = OBJDIR / "exp" if experiments else OBJDIR
+    objdir.mkdir(parents=True, exist_ok=True)
+    obj = objdir / (src.stem + ".o")
+    stamp = objdir / (src.stem + ".sha")
     dig = _digest(src)
     if not force and obj.exists() and stamp.exists() and stamp.read_text() == dig:
         return obj, False
-    cmd = [_hipcc(), *FLAGS, "-x", "hip", "-c", str(src), "-o", str(obj)]
+    cmd = [_hipcc(), *FLAGS, *(["-DPOCO_EXPERIMENTS=1"] if experiments else []), "-x", "hip", "-c", str(src), "-o", str(obj)]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed for {src.name}:\n{r.stdout}\n{r.stderr}")
@@ -60,11 +68,13 @@ def _compile(src: Path, force: bool) -> tuple[Path, bool]:
     return obj, True
 
 
-def build(force: bool = False, verbose: bool = True) -> Path:
+def build(force: bool = False, verbose: bool = True, experiments: bool = False) -> Path:
     OBJDIR.mkdir(parents=True, exist_ok=True)
-    srcs = _sources()
+    srcs = _sources(experiments)
+    LIB = (LIBDIR / "exp" / "libpoco_hip_experiments.so") if experiments else globals()["LIB"]
+    LIB.parent.mkdir(parents=True, exist_ok=True)
     with ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
-        results = list(ex.map(lambda s: _compile(s, force), srcs))
+        results = list(ex.map(lambda s: _compile(s, force, experiments), srcs))
     objs = [o for o, _ in results]
     rebuilt = any(ch for _, ch in results)
     if rebuilt or not LIB.exists():
@@ -80,4 +90,4 @@ def build(force: bool = False, verbose: bool = True) -> Path:
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    build(force="--force" in sys.argv, experiments="--experiments" in sys.argv)

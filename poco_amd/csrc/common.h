@@ -56,7 +56,8 @@ struct ConvCfg {
                //    (MT,NT) in {(2,4),(4,2),(4,4),(7,2),(7,4),(8,2)}, R = operand prefetch depth (2|3), NI = load schedule 1..6
                // 9: ALG 6 with coalesced global traffic: pixel / output tiles turned into the MFMA lane order through
                //    wave-private LDS (gemm1x1t.hip): (MT,NT) in {(4,4),(7,2),(7,4),(8,2)}, R = NI = 1
-               // 12: EXPERIMENT, never chosen by the table: 1x1 conv in split fp16 (gemm1x1h.hip), POCO_SPLIT_F16=1 only
+               // 12: EXPERIMENT, -DPOCO_EXPERIMENTS=1 builds only (python -m poco_amd.build --experiments), never chosen by the table:
+               //     1x1 conv in split fp16 (exp/gemm1x1h.hip)
                // 11: Winograd F(4x4,3x3) as 36 position GEMMs with V / M staged in memory, for planes <= 16x16 (conv_wino4g.hip):
                //    three launches (input transform, GEMM, output transform); (MT,NT) in {(2,4),(4,2),(4,4),(8,2)}, R = depth 2|3
                // 10: 3x3 conv (stride 1|2) as a register-direct gather GEMM over K = 9*Cin, no LDS / barriers (gemm3x3.hip):
@@ -122,11 +123,16 @@ bool gemm1x1t_cfg_valid(const ConvDesc& d, const ConvCfg& cfg);
 size_t gemm1x1t_lds_bytes(const ConvDesc& d, const ConvCfg& cfg);
 int gemm1x1t_launch(const ConvDesc& d, const ConvCfg& cfg, hipStream_t stream);
 
-// ---- EXPERIMENT: 1x1 convs in split fp16 (hi + lo, 3 MFMAs of 16x16x32_f16 per product; gemm1x1h.hip), ALG 12 -----------
+#ifndef POCO_EXPERIMENTS
+#define POCO_EXPERIMENTS 0      // 1: also build the labelled experiments (csrc/exp/*.hip, 3-deep rings of ALG 4); not in the shipped library
+#endif
+#if POCO_EXPERIMENTS
+// ---- EXPERIMENT: 1x1 convs in split fp16 (hi + lo, 3 MFMAs of 16x16x32_f16 per product; exp/gemm1x1h.hip), ALG 12 -----------
 size_t gemm1x1h_packed_floats(int Cin, int Cout16);
 void gemm1x1h_pack_weights(const float* w_oi, const float* scale, int Cout, int Cin, int Cout16, float* dst);
 bool gemm1x1h_cfg_valid(const ConvDesc& d, const ConvCfg& cfg);
 int gemm1x1h_launch(const ConvDesc& d, const ConvCfg& cfg, hipStream_t stream);
+#endif
 
 // ---- Winograd F(4x4,3x3) as a position-batched GEMM for small planes (conv_wino4g.hip), ALG 11 --------------
 size_t conv_wino4g_packed_floats(int Cin, int Cout16);

@@ -99,7 +99,11 @@ size_t conv_lds_bytes(const ConvDesc& d, const ConvCfg& cfg) {
   if (cfg.ALG == 9) return gemm1x1t_lds_bytes(d, cfg);
   if (cfg.ALG == 10) return gemm3x3_cfg_valid(d, cfg) ? 16 : 0;     // no LDS; non-zero = "valid" for the callers
   if (cfg.ALG == 11) return conv_wino4g_cfg_valid(d, cfg) ? 16 : 0;
+#if POCO_EXPERIMENTS
   if (cfg.ALG == 12) return gemm1x1h_cfg_valid(d, cfg) ? 16 : 0;
+#else
+  if (cfg.ALG == 12) return 0;
+#endif
   if (cfg.ALG == 7) return conv_wino4_lds_bytes(d, cfg);
   if (cfg.ALG == 8) return conv_wino4p_lds_bytes(d, cfg);
   if (cfg.ALG == 13) return conv_wino4w_lds_bytes(d, cfg);
@@ -183,7 +187,11 @@ int conv_launch(const ConvDesc& d, const ConvCfg& cfg, hipStream_t stream) {
   if (cfg.ALG == 9) return gemm1x1t_launch(d, cfg, stream);
   if (cfg.ALG == 10) return gemm3x3_launch(d, cfg, stream);
   if (cfg.ALG == 11) return conv_wino4g_launch(d, cfg, stream);
+#if POCO_EXPERIMENTS
   if (cfg.ALG == 12) return gemm1x1h_launch(d, cfg, stream);
+#else
+  if (cfg.ALG == 12) { poco_set_error("conv: ALG 12 (split-fp16 experiment) is not part of this build (python -m poco_amd.build --experiments)"); return POCO_ERR_ARG; }
+#endif
   if (cfg.ALG == 7) return conv_wino4_launch(d, cfg, stream);
   if (cfg.ALG == 8) return conv_wino4p_launch(d, cfg, stream);
   if (cfg.ALG == 13) return conv_wino4w_launch(d, cfg, stream);

@@ -728,7 +728,7 @@ size_t conv_wino_lds_bytes(const ConvDesc& d, const ConvCfg& cfg) {
   WGeo g;
   if (!wgeo(d, cfg, &g)) return 0;
   if (cfg.ALG == 4) { // DEPTH raw buffers + DEPTH U buffers (the exchange area at the end reuses a U buffer); DEPTH = 3 with cfg.MT = 3
-    if (cfg.MT != 1 && cfg.MT != 3) return 0;
+    if (cfg.MT != 1 && !(POCO_EXPERIMENTS && cfg.MT == 3)) return 0;      // (the 3-deep rings: 6-8 % slower, experiment builds only)
     const size_t depth = cfg.MT == 3 ? 3 : 2;
     return (depth * 4 * g.planeF4 + depth * 16 * cfg.NT * 64) * sizeof(float4);
   }
@@ -794,10 +794,12 @@ int conv_wino_launch(const ConvDesc& d, const ConvCfg& cfg, hipStream_t stream) 
     if (g4 > 8) g4 = std::min(cap4, (g4 + 7) / 8 * 8);      // multiple of 8 for the XCD-aware walk
     dim3 grid4((unsigned)g4, 1);
     const bool deep = cfg.MT == 3;
-    if (lds4 == 0) { poco_set_error("conv(winograd/half): MT must be 1 (2-deep rings) or 3 (3-deep rings)"); return POCO_ERR_ARG; }
+    if (lds4 == 0) { poco_set_error("conv(winograd/half): MT must be 1 (2-deep rings; 3 = 3-deep rings exists in experiment builds only)"); return POCO_ERR_ARG; }
     void (*fn4)(const WinoParams) =
-        deep ? (cfg.NT == 3 ? conv_wino2_kernel<3, 3> : cfg.NT == 2 ? conv_wino2_kernel<2, 3> : conv_wino2_kernel<1, 3>)
-             : (cfg.NT == 3 ? conv_wino2_kernel<3, 2> : cfg.NT == 2 ? conv_wino2_kernel<2, 2> : conv_wino2_kernel<1, 2>);
+#if POCO_EXPERIMENTS      // the 3-deep-ring instances exist only in experiment builds (python -m poco_amd.build --experiments)
+        deep ? (cfg.NT == 3 ? conv_wino2_kernel<3, 3> : cfg.NT == 2 ? conv_wino2_kernel<2, 3> : conv_wino2_kernel<1, 3>) :
+#endif
+        (cfg.NT == 3 ? conv_wino2_kernel<3, 2> : cfg.NT == 2 ? conv_wino2_kernel<2, 2> : conv_wino2_kernel<1, 2>);
     if (lds4 > 64 * 1024) {
       static thread_local bool configured4[8] = {};
       if (!configured4[cfg.NT + (deep ? 4 : 0)]) {

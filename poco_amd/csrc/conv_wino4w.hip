@@ -38,9 +38,18 @@ using w4::at_c;
 #include "conv_wino4p_geo.h"
 
 #ifndef W4W_DMAW
-#define W4W_DMAW 0    // who requests the LDS-DMA of the coming slices (see W4WDuty)
+#define W4W_DMAW 6    // who requests the LDS-DMA of the coming slices (see W4WDuty)
 #endif
 
+#ifndef W4W_EXP
+#define W4W_EXP 0     // timing probes (results are garbage): 1 no LDS-DMA in the K loop, 2 producers skip transform + window reads, 4 MFMA waves
+#endif                // skip their operand reads, 8 MFMA waves skip the MFMAs
+#ifndef W4W_HOLD
+#define W4W_HOLD 2    // quads of a slice whose MFMAs run behind the slice barrier (see the K loop)
+#endif
+#ifndef W4W_LAYOUT
+#define W4W_LAYOUT 1
+#endif
 #ifndef W4W_TRACE
 #define W4W_TRACE 0   // 1: block 0 sums s_memtime phases of its waves over its first item (tools/w4w_trace.py)
 #endif
@@ -82,6 +91,17 @@ __device__ __forceinline__ void w4w_wait_vm(int n) {     // s_waitcnt vmcnt(n), 
     default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
   }
 #undef W4W_WVM
+}
+
+// y = A^T x for the six values x0 .. x5 of one transform row / column ([Lavin & Gray]: A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0;
+// 0 1 -1 8 -8 1]) in even / odd form: 10 operations
+__device__ __forceinline__ void w4w_at(const f32x4& x0, const f32x4& x1, const f32x4& x2, const f32x4& x3, const f32x4& x4, const f32x4& x5,
+                                       f32x4 (&y)[4]) {
+  const f32x4 s1 = x1 + x2, d1 = x1 - x2, s2 = x3 + x4, d2 = x3 - x4;
+  y[0] = x0 + s1 + s2;
+  y[1] = d1 + 2.f * d2;
+  y[2] = s1 + 4.f * s2;
+  y[3] = d1 + 8.f * d2 + x5;
 }
 
 struct W4WParams {
@@ -140,39 +160,65 @@ __device__ __forceinline__ void w4w_dma_stream(const void* sbase, const unsigned
 }
 #undef W4W_DMA1
 
-// The 9 NT + rawF4 / 64 pieces of a slice are dealt round-robin to NW duty SLOTS; a wave owns KM (issuing MFMA waves MI0 ..
-// MI0 + NMI - 1) or KP (producers) consecutive slots:
-//   mode  MFMA issuers  KM  KP   NW (NT = 3)
-//   0     2, 3           1   1    4
-//   1     all            1   0    6
-//   2     2, 3           1   0    2
-//   3     all            1   1    8
-//   4     2, 3           3   2    10
-//   5     2 .. 5         1   2    8      (NT = 3; NT < 3: as mode 0)
-template <int NT> constexpr bool w4w_all_mfma_issue() { return W4W_DMAW == 1 || W4W_DMAW == 3 || NT == 1; }
-template <int NT> constexpr int w4w_nmi() { return w4w_all_mfma_issue<NT>() ? 2 * NT : (W4W_DMAW == 5 && NT == 3) ? 4 : 2; }   // issuing MFMA waves ...
-template <int NT> constexpr int w4w_mi0() { return w4w_all_mfma_issue<NT>() ? 0 : 2; }                //  ... from this wave on
-constexpr int w4w_km() { return W4W_DMAW == 4 ? 3 : 1; }
-template <int NT> constexpr int w4w_kp() { return (W4W_DMAW == 1 || W4W_DMAW == 2) ? 0 : (W4W_DMAW == 4 || (W4W_DMAW == 5 && NT == 3)) ? 2 : 1; }
-template <int NT> constexpr int w4w_nw() { return w4w_nmi<NT>() * w4w_km() + 2 * w4w_kp<NT>(); }
+// WHO requests what (W4W_DMAW) and WHERE the producers sit (W4W_LAYOUT).  The 9 NT U pieces of a slice are dealt round-robin to
+// NWU issuers, the rawF4 / 64 patch pieces to NWR issuers; an issuer is an MFMA wave (by its MFMA index m = 0 .. 2 NT - 1) or a
+// producer.  Waves land on SIMD (wave id % 4):
+//   W4W_LAYOUT 0: MFMA waves = wave ids 0 .. 2 NT - 1, producers = the last two.  NT = 3: SIMDs 0 / 1 carry two MFMA waves, SIMDs 2 / 3
+//                 one MFMA wave + one producer.
+//   W4W_LAYOUT 1 (NT = 3 only): producers = wave ids 3 and 7, i.e. BOTH on SIMD 3, and every other SIMD carries two MFMA waves:
+//                 the MFMA work is balanced over three SIMDs (72 MFMAs = 2304 clk per slice each) and the producers' VALU / LDS /
+//                 LDS-DMA instructions have a SIMD of their own (fp32 MFMAs run on the SIMD's vector ALUs; an LDS-DMA piece blocks the
+//                 MFMA pipe of the SIMD it is issued from for ~47 clk - on SIMD 3 there is none).
+//   mode   U issuers                 raw issuers
+//   0      MFMA 2, 3 + producers     MFMA 2, 3 + producers
+//   1      all MFMA                  all MFMA
+//   6      producers                 all MFMA
+//   7      producers                 producers
+//   8      all MFMA                  producers
+struct W4WPlan { int mu0, nmu, kpu, mr0, nmr, kpr; };
+template <int NT> constexpr W4WPlan w4w_plan() {
+  constexpr int M = 2 * NT;
+  if (W4W_DMAW == 1) return {0, M, 0, 0, M, 0};
+  if (W4W_DMAW == 6) return {0, 0, 1, 0, M, 0};
+  if (W4W_DMAW == 7) return {0, 0, 1, 0, 0, 1};
+  if (W4W_DMAW == 8) return {0, M, 0, 0, 0, 1};
+  if (NT == 1) return {0, 2, 1, 0, 2, 1};
+  return {2, 2, 1, 2, 2, 1};
+}
+template <int NT> constexpr int w4w_nwu() { return w4w_plan<NT>().nmu + 2 * w4w_plan<NT>().kpu; }
+template <int NT> constexpr int w4w_nwr() { return w4w_plan<NT>().nmr + 2 * w4w_plan<NT>().kpr; }
+// wave id -> role: producer index (0 / 1) or -1; MFMA index m
+template <int NT> __device__ __forceinline__ int w4w_producer_of(int wave) {
+  if constexpr (W4W_LAYOUT == 1 && NT == 3) return (wave & 3) == 3 ? wave >> 2 : -1;
+  return wave >= 2 * NT ? wave - 2 * NT : -1;
+}
+template <int NT> __device__ __forceinline__ int w4w_mfma_index(int wave) {
+  if constexpr (W4W_LAYOUT == 1 && NT == 3) return wave - (wave >> 2);
+  return wave;
+}
 
 template <int NT, int FLAT>
 struct W4WDuty {
-  static constexpr int NW = w4w_nw<NT>();
-  static constexpr int MAXP = (16 + NW - 1) / NW;                      // raw pieces per issuer (rawF4 <= 1024 slots)
-  static constexpr int NUP = (9 * NT + NW - 1) / NW;                   // U pieces per issuer and slice
+  static constexpr int NWU = w4w_nwu<NT>(), NWR = w4w_nwr<NT>();
+  static constexpr int MAXP = (16 + NWR - 1) / NWR;                    // raw pieces per raw issuer (rawF4 <= 1024 slots)
+  static constexpr int NUP = (9 * NT + NWU - 1) / NWU;                 // U pieces per U issuer and slice
   int goff[MAXP];
   bool live[MAXP];
+  int dwu, dwr;                                                         // this wave's index among the U / raw issuers, -1 = none (wave-uniform)
   // the patch of item `it`: global float offsets of this issuer's raw pieces (lane = slot inside the piece), -1 = padding
-  __device__ __forceinline__ void setup(const W4WParams& pp, int it, int dw, int lane) {
+  __device__ __forceinline__ void setup(const W4WParams& pp, int it, int lane) {
+    if (dwr < 0) return;
     int ng;
     const int id = w4w_item_id(pp, it, &ng);
-    raw_piece_offsets<MAXP, FLAT>(pp.g, id, dw, NW, lane, goff);
+    raw_piece_offsets<MAXP, FLAT>(pp.g, id, dwr, NWR, lane, goff);
 #pragma unroll
     for (int k = 0; k < MAXP; ++k) live[k] = __ballot(goff[k] >= 0) != 0ull;
   }
   // 4-channel slice c4 of the patch -> raw ring slot; zero = also clear the padding lanes of the slot (first use by this item)
-  __device__ __forceinline__ int issue_raw(const W4PParams& p, float4* smem, int dw, int lane, int c4, int slot, bool zero) const {
+  __device__ __forceinline__ int issue_raw(const W4PParams& p, float4* smem, int lane, int c4, int slot, bool zero) const {
+    if (dwr < 0) return 0;
+    const int dw = dwr;
+    constexpr int NW = NWR;
     int cnt = 0;
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) float4*)smem;
     const float* sbase = p.in + (size_t)(c4 >> 2) * p.in_ss + (c4 & 3) * 4;
@@ -200,7 +246,10 @@ struct W4WDuty {
   // packed fragments ([c4][n-tile][9 quads][64] float4), so piece i is base + i KiB: one 64-bit scalar add per piece.  An n-group that
   // reaches beyond the tensor (Cout = 112: 7 n-tiles at NT = 3) reads on into the next slice's fragments / the slack behind the
   // last one (conv_wino4w_packed_floats) - those waves' results are never stored.
-  __device__ __forceinline__ int issue_u(const W4PParams& p, float4* smem, int dw, int lane, int nt0, int c4, int slot) const {
+  __device__ __forceinline__ int issue_u(const W4PParams& p, float4* smem, int lane, int nt0, int c4, int slot) const {
+    if (dwu < 0) return 0;
+    const int dw = dwu;
+    constexpr int NW = NWU;
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) float4*)smem;
     const unsigned dst0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds_base + (unsigned)(p.uoff + slot * NT * W4W_UBLK) * 16u + (unsigned)dw * 1024u));
     const float4* src = p.ufrag + (((size_t)c4 * p.nT16 + nt0) * 9 + dw) * 64;
@@ -226,30 +275,30 @@ struct W4WDuty {
     }
   }
   // once per block, before P0: raw(0..2), U(0), U(1) of the first item
-  __device__ __forceinline__ void prologue(const W4WParams& pp, float4* smem, int dw, int lane, int it0) {
+  __device__ __forceinline__ void prologue(const W4WParams& pp, float4* smem, int lane, int it0) {
     const W4PParams& p = pp.g;
-    setup(pp, it0, dw, lane);
+    setup(pp, it0, lane);
 #pragma unroll
     for (int c = 0; c < 3; ++c)
-      if (c < p.nC4) issue_raw(p, smem, dw, lane, c, c, true);
+      if (c < p.nC4) issue_raw(p, smem, lane, c, c, true);
     int ng0;
     (void)w4w_item_id(pp, it0, &ng0);
-    issue_u(p, smem, dw, lane, ng0 * NT, 0, 0);
-    if (p.nC4 > 1) issue_u(p, smem, dw, lane, ng0 * NT, 1, 1);
+    issue_u(p, smem, lane, ng0 * NT, 0, 0);
+    if (p.nC4 > 1) issue_u(p, smem, lane, ng0 * NT, 1, 1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
   // global slice t = (item it, slice s): U(t + 2) -> slot r2 (of U(t - 1)); raw(t + 4) -> slot r1 (of raw(t + 1), whose window was read
   // during slice t - 1) - of this item or of the next one, whose patch takes over at s = S - 4.  Returns the number of requests.
-  __device__ __forceinline__ int slice_requests(const W4WParams& pp, float4* smem, int dw, int lane, int it_next, bool hasB, int s, int r1,
+  __device__ __forceinline__ int slice_requests(const W4WParams& pp, float4* smem, int lane, int it_next, bool hasB, int s, int r1,
                                                 int r2, int nt0A, int nt0B) {
     const W4PParams& p = pp.g;
     const int S = p.nC4;
     int nvm = 0;
-    if (s + 2 < S) nvm += issue_u(p, smem, dw, lane, nt0A, s + 2, r2);
-    else if (hasB) nvm += issue_u(p, smem, dw, lane, nt0B, s + 2 - S, r2);
-    if (s + 4 == S && hasB) setup(pp, it_next, dw, lane);
-    if (s + 4 < S) nvm += issue_raw(p, smem, dw, lane, s + 4, r1, false);
-    else if (hasB) nvm += issue_raw(p, smem, dw, lane, s + 4 - S, r1, s + 4 - S < 3);
+    if (s + 2 < S) nvm += issue_u(p, smem, lane, nt0A, s + 2, r2);
+    else if (hasB) nvm += issue_u(p, smem, lane, nt0B, s + 2 - S, r2);
+    if (s + 4 == S && hasB) setup(pp, it_next, lane);
+    if (s + 4 < S) nvm += issue_raw(p, smem, lane, s + 4, r1, false);
+    else if (hasB) nvm += issue_raw(p, smem, lane, s + 4 - S, r1, s + 4 - S < 3);
     return nvm;
   }
 };
@@ -258,30 +307,25 @@ struct W4WDuty {
 // MFMA waves
 // ---------------------------------------------------------------------------------------------------------------------
 template <int NT, int FLAT>
-__device__ __forceinline__ void w4w_mfma_wave(const W4WParams& pp, float4* smem, int wave, int lane) {
+__device__ __forceinline__ void w4w_mfma_wave(const W4WParams& pp, float4* smem, int wave, int lane) {      // wave = MFMA index 0 .. 2 NT - 1
   const W4PParams& p = pp.g;
   const int grp = wave >= NT ? 1 : 0, nn = wave - grp * NT;           // (wave-uniform)
   const int idx = lane & 15, g = lane >> 4;
   const int vlane = w4p_sigma(idx, g);
-  const bool is_dma = wave >= w4w_mi0<NT>() && wave < w4w_mi0<NT>() + w4w_nmi<NT>();      // (wave-uniform)
-  constexpr int KM = w4w_km();
-  const int dw = (wave - w4w_mi0<NT>()) * KM;                         // this wave's first duty slot
+  constexpr W4WPlan plan = w4w_plan<NT>();
+  W4WDuty<NT, FLAT> duty;
+  duty.dwu = wave >= plan.mu0 && wave < plan.mu0 + plan.nmu ? wave - plan.mu0 : -1;
+  duty.dwr = wave >= plan.mr0 && wave < plan.mr0 + plan.nmr ? wave - plan.mr0 : -1;
+  const bool is_dma = duty.dwu >= 0 || duty.dwr >= 0;                  // (wave-uniform)
   const int uF4 = NT * W4W_UBLK;
   const int S = p.nC4;
   const Walk wk = item_walk(p);
   if (wk.first >= wk.end) return;                                     // (whole block: every role takes the same exit)
 
-  W4WDuty<NT, FLAT> duty[KM];
-  if (is_dma) {
-#pragma unroll
-    for (int j = 0; j < KM; ++j) duty[j].prologue(pp, smem, dw + j, lane, wk.first);
-  }
+  if (is_dma) duty.prologue(pp, smem, lane, wk.first);
   __syncthreads();                                        // P0: the first fetches have landed
   __syncthreads();                                        // P1: V(0) is written, the windows of slices 0 and 1 are in the producers' registers
-  if (is_dma && S > 3) {                                  // (the window of slice 0 has been read)
-#pragma unroll
-    for (int j = 0; j < KM; ++j) duty[j].issue_raw(p, smem, dw + j, lane, 3, 0, false);
-  }
+  if (is_dma && S > 3) duty.issue_raw(p, smem, lane, 3, 0, false);     // (the window of slice 0 has been read)
 
   int ring = 0, vb = 0;                                   // global slice t: t % 3, t & 1
   for (int it = wk.first; it < wk.end; it += wk.step) {
@@ -297,6 +341,7 @@ __device__ __forceinline__ void w4w_mfma_wave(const W4WParams& pp, float4* smem,
     for (int q = 0; q < 9; ++q)
 #pragma unroll
       for (int i = 0; i < 4; ++i) acc[q][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float4 hu[W4W_HOLD > 0 ? W4W_HOLD : 1], hv[W4W_HOLD > 0 ? W4W_HOLD : 1];       // operands of the deferred quads
 
 #if W4W_TRACE
     const bool trace = blockIdx.x == 0 && it == wk.first;
@@ -308,26 +353,46 @@ __device__ __forceinline__ void w4w_mfma_wave(const W4WParams& pp, float4* smem,
       int nvm = 0;
       const float4* U = smem + p.uoff + ring * uF4 + nn * W4W_UBLK + lane;
       const float4* V = smem + p.voff + vb * (2 * W4W_UBLK) + grp * W4W_UBLK + vlane;
-      // operands two quads ahead of the MFMAs that use them (three register sets)
-      constexpr int PF = 2;
+      // Operands two quads ahead of the MFMAs that use them.  The MFMAs of the last W4W_HOLD quads of a slice are DEFERRED ACROSS THE
+      // SLICE BARRIER: their operands are read before it (the barrier protects the ring slots against the next requests, and it is
+      // the READS that must be over), the MFMAs themselves run behind it, while the first operands of the next slice are on their way -
+      // right after a barrier every wave of the block asks the LDS for operands at once, and the MFMA pipes used to idle through that
+      // round trip (~300 clk of a ~2900-clk slice on every SIMD).  The last slice of an item keeps nothing back (its accumulators go to
+      // the epilogue).
+      constexpr int PF = 2, NH = W4W_HOLD;
       float4 ub[PF + 1], vq[PF + 1];
 #pragma unroll
-      for (int q = 0; q < PF; ++q) { ub[q] = U[q * 64]; vq[q] = V[q * 64]; }
-      // The LDS-DMA of the coming slices: requested while the first operands are on their way - the MFMA pipe of this SIMD has
-      // nothing to do yet, so the ~47 clk a piece blocks it and the ~60 clk it costs this wave to issue are free here.
+      for (int q = 0; q < PF; ++q) { ub[q] = (W4W_EXP & 4) ? make_float4(1.f, 2.f, (float)s, 3.f) : U[q * 64]; vq[q] = (W4W_EXP & 4) ? make_float4(1.f, 2.f, 3.f, (float)q) : V[q * 64]; }
+      // The LDS-DMA of the coming slices: requested while the first operands are on their way.
       // U(t + 2) -> slot of U(t - 1); raw(t + 4) -> slot of raw(t + 1), whose window was read during slice t - 1.
       if (is_dma) {
         __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int j = 0; j < KM; ++j) nvm += duty[j].slice_requests(pp, smem, dw + j, lane, it + wk.step, hasB, s, r1, r2, nt0A, nt0B);
+        if (!(W4W_EXP & 1)) nvm = duty.slice_requests(pp, smem, lane, it + wk.step, hasB, s, r1, r2, nt0A, nt0B);
         __builtin_amdgcn_sched_barrier(0);
+      }
+      if (NH > 0 && s > 0) {
+#pragma unroll
+        for (int h = 0; h < NH; ++h)
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            acc[9 - NH + h][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4c(hu[h], i), f4c(hv[h], i), acc[9 - NH + h][i], 0, 0, 0);
       }
 #pragma unroll
       for (int q = 0; q < 9; ++q) {
-        if (q + PF < 9) { ub[(q + PF) % (PF + 1)] = U[(q + PF) * 64]; vq[(q + PF) % (PF + 1)] = V[(q + PF) * 64]; }
+        if (q + PF < 9) {
+          ub[(q + PF) % (PF + 1)] = (W4W_EXP & 4) ? make_float4(1.f, (float)s, 2.f, 3.f) : U[(q + PF) * 64];
+          vq[(q + PF) % (PF + 1)] = (W4W_EXP & 4) ? make_float4(1.f, 2.f, 3.f, (float)q) : V[(q + PF) * 64];
+        }
         const float4 u = ub[q % (PF + 1)], v = vq[q % (PF + 1)];
+        if (q < 9 - NH || s + 1 == S) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc[q][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4c(u, i), f4c(v, i), acc[q][i], 0, 0, 0);
+          for (int i = 0; i < 4; ++i) {
+            if (W4W_EXP & 8) acc[q][i][0] += f4c(u, i) * f4c(v, i);
+            else acc[q][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4c(u, i), f4c(v, i), acc[q][i], 0, 0, 0);
+          }
+        } else {
+          hu[q - (9 - NH)] = u; hv[q - (9 - NH)] = v;
+        }
       }
       W4W_T(c1);
       if (is_dma) w4w_wait_vm(nvm);                       // what this wave requested BEFORE this slice has landed: U(t + 1), raw(t + 3)
@@ -335,6 +400,7 @@ __device__ __forceinline__ void w4w_mfma_wave(const W4WParams& pp, float4* smem,
       vb ^= 1;
       W4W_T(c2);
       __syncthreads();                                    // everybody is done with slice t; V(t + 1), U(t + 1), raw(t + 2) are in place
+      __builtin_amdgcn_sched_barrier(0);
       W4W_T(c3);
       W4W_ACC(0, c0, c1); W4W_ACC(1, c1, c2); W4W_ACC(2, c2, c3);
     }
@@ -366,19 +432,15 @@ __device__ __forceinline__ void w4w_mfma_wave(const W4WParams& pp, float4* smem,
       const char* rb = reinterpret_cast<const char*>(p.res + (size_t)ntc * p.out_ss);
       char* ob = reinterpret_cast<char*>(p.out + (size_t)ntc * p.out_ss);
       const bool ntok = nt < p.nT16;
-      // Z[xi][j] = sum_nu M[xi][nu] A[nu][j]  (A[nu][j] = at_c(j, nu)): row by row, a row of M (24 registers) dies as soon as its row
-      // of Z (16) exists - the allocator sees 144 -> 96 live values instead of 144 + 96
+      // Z[xi][.] = A^T applied along nu to row xi of M, row by row: a row of M (24 registers) dies as soon as its row of Z (16)
+      // exists - the allocator sees 144 -> 96 live values instead of 144 + 96.  A^T in its even / odd form (w4w_at: 10 packed
+      // operations per 6 -> 4 transform instead of the 14 of the term-by-term sums; the epilogue is VALU-bound, two MFMA waves per SIMD)
       f32x4 z[6][4];
 #pragma unroll
       for (int xi = 0; xi < 6; ++xi) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          f32x4 t = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-          for (int nu = 0; nu < 6; ++nu)
-            if (at_c(j, nu) != 0.f) t += at_c(j, nu) * acc[w4w_slot(xi, nu) >> 2][w4w_slot(xi, nu) & 3];
-          z[xi][j] = t;
-        }
+        w4w_at(acc[w4w_slot(xi, 0) >> 2][w4w_slot(xi, 0) & 3], acc[w4w_slot(xi, 1) >> 2][w4w_slot(xi, 1) & 3],
+               acc[w4w_slot(xi, 2) >> 2][w4w_slot(xi, 2) & 3], acc[w4w_slot(xi, 3) >> 2][w4w_slot(xi, 3) & 3],
+               acc[w4w_slot(xi, 4) >> 2][w4w_slot(xi, 4) & 3], acc[w4w_slot(xi, 5) >> 2][w4w_slot(xi, 5) & 3], z[xi]);
 #pragma unroll
         for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(z[xi][j][0]), "+v"(z[xi][j][1]), "+v"(z[xi][j][2]), "+v"(z[xi][j][3]));    // (row xi is finished here)
       }
@@ -394,12 +456,11 @@ __device__ __forceinline__ void w4w_mfma_wave(const W4WParams& pp, float4* smem,
 #pragma unroll
           for (int i = 0; i < 4; ++i) rr[(j + 1) & 1][i] = *reinterpret_cast<const float4*>(rb + (roff[i] + xoffb[j + 1]));
         }
+        f32x4 yc[4];
+        w4w_at(z[0][j], z[1][j], z[2][j], z[3][j], z[4][j], z[5][j], yc);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          f32x4 v = (f32x4){sh.x, sh.y, sh.z, sh.w};
-#pragma unroll
-          for (int xi = 0; xi < 6; ++xi)
-            if (at_c(i, xi) != 0.f) v += at_c(i, xi) * z[xi][j];
+          f32x4 v = yc[i] + (f32x4){sh.x, sh.y, sh.z, sh.w};
           if (has_res) {
             const float4 r = rr[j & 1][i];
             if (p.res_after_act) {
@@ -499,26 +560,21 @@ __device__ __forceinline__ void w4w_producer(const W4WParams& pp, float4* smem, 
   };
 
   // this wave's share of the LDS-DMA duty (W4W_DMAW): issuer index behind the MFMA waves'
-  constexpr int KP = w4w_kp<NT>();
-  constexpr bool kIssue = KP > 0;
-  const int dw = w4w_nmi<NT>() * w4w_km() + pw * KP;
-  W4WDuty<NT, FLAT> duty[kIssue ? KP : 1];
+  constexpr W4WPlan plan = w4w_plan<NT>();
+  constexpr bool kIssue = plan.kpu > 0 || plan.kpr > 0;
+  W4WDuty<NT, FLAT> duty;
+  duty.dwu = plan.kpu > 0 ? plan.nmu + pw : -1;
+  duty.dwr = plan.kpr > 0 ? plan.nmr + pw : -1;
   Win A, B;
   win_of(wk.first, A);
-  if constexpr (kIssue) {
-#pragma unroll
-    for (int j = 0; j < KP; ++j) duty[j].prologue(pp, smem, dw + j, lane, wk.first);
-  }
+  if constexpr (kIssue) duty.prologue(pp, smem, lane, wk.first);
   __syncthreads();                                        // P0: raw(0..2), U(0..1) of the first item have landed
   load_window(dA, A, 0);
   transform(dA, 0);
   if (S > 1) load_window(dA, A, 1);                       // dA = window of slice t + 1 at the top of slice t
   __syncthreads();                                        // P1
   if constexpr (kIssue) {
-    if (S > 3) {
-#pragma unroll
-      for (int j = 0; j < KP; ++j) duty[j].issue_raw(p, smem, dw + j, lane, 3, 0, false);
-    }
+    if (S > 3) duty.issue_raw(p, smem, lane, 3, 0, false);
   }
   // fp32 MFMAs run on the SIMD's vector ALUs: without a higher issue priority the MFMA wave of this SIMD starves this wave's
   // VALU / LDS instructions until it reaches the slice barrier
@@ -538,16 +594,15 @@ __device__ __forceinline__ void w4w_producer(const W4WParams& pp, float4* smem, 
       W4W_T(q0);
       const int r1 = ring == 2 ? 0 : ring + 1, r2 = r1 == 2 ? 0 : r1 + 1;
       int nvm = 0;
-      if constexpr (kIssue) {
-#pragma unroll
-        for (int j = 0; j < KP; ++j) nvm += duty[j].slice_requests(pp, smem, dw + j, lane, it + wk.step, hasB, s, r1, r2, ngA * NT, ngB * NT);
-      }
+      if constexpr (kIssue) { if (!(W4W_EXP & 1)) nvm = duty.slice_requests(pp, smem, lane, it + wk.step, hasB, s, r1, r2, ngA * NT, ngB * NT); }
       // V(t + 1) from the window fetched during the previous slice, then the window of slice t + 2 (raw(t + 2) landed before the
       // barrier that ended slice t - 1) - of this item or of the next one
+      if (!(W4W_EXP & 2)) {
       if (s + 1 < S || hasB) transform(dA, vb ^ 1);
       W4W_T(q1);
       if (s + 2 < S) load_window(dA, A, r2);
       else if (hasB) load_window(dA, B, r2);
+      }
       if (kIssue) w4w_wait_vm(nvm);                       // what this wave requested BEFORE this slice has landed
       ring = r1;
       vb ^= 1;
@@ -569,8 +624,9 @@ conv_wino4w_kernel(const W4WParams p) {
   extern __shared__ float4 smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  if (wave < 2 * NT) w4w_mfma_wave<NT, FLAT>(p, smem, wave, lane);
-  else w4w_producer<NT, FLAT>(p, smem, wave - 2 * NT, lane);
+  const int pw = w4w_producer_of<NT>(wave);
+  if (pw < 0) w4w_mfma_wave<NT, FLAT>(p, smem, w4w_mfma_index<NT>(wave), lane);
+  else w4w_producer<NT, FLAT>(p, smem, pw, lane);
 }
 
 struct W4WLayout { int uoff, voff, totalF4; };

@@ -132,7 +132,9 @@ static bool parse_opts(const char* str, EngineOpts* o, std::string* err) {
     else if (k == "tail_lanes") o->tail_lanes = on;
     else if (k == "up_lanes") o->up_lanes = on;
     else if (k == "wg_fuse") o->wg_fuse = on;
+#if POCO_EXPERIMENTS
     else if (k == "split_f16") o->split_f16 = on;
+#endif
     else if (k == "seq_phases") o->seq_mask = atoi(v.c_str());
     else if (k == "branch_lanes") o->branch_lanes = v;
     else if (k == "flow_ctx_rows") o->flow_ctx_rows = atoi(v.c_str());
@@ -387,11 +389,13 @@ struct Builder {
       std::copy(shift.begin(), shift.end(), sh.begin());
       op.wdev = upload(packed);
       op.bdev = upload(sh);
+#if POCO_EXPERIMENTS
       if (e.opts.split_f16 && ks == 1 && !is_linear && Cin % 32 == 0 && ain.H * ain.W >= 16 && !kperm) {
         std::vector<float> ph(gemm1x1h_packed_floats(Cin, Cout16));
         gemm1x1h_pack_weights(wp, scale.data(), Cout, Cin, Cout16, ph.data());
         op.wdev_h = upload(ph);
       }
+#endif
       if (ks == 3 && stride == 1 && !is_linear) {
         std::vector<float> wt, pu(conv_packed_weight_floats(Cin, Cout16, 4));
         conv_wino_transform_weights(wp, Cout, Cin, &wt);

@@ -126,7 +126,7 @@ void launch_crop_normalize(const unsigned char* frame, int H, int W, const float
 void launch_crop_normalize_f64(const unsigned char* frame, int H, int W, const double* boxes, double bbox_scale, float* out,
                                int N, int res, hipStream_t s);
 // crops of several same-sized frames in one launch: frames = device array of frame pointers, frame_idx[n] = frame of crop n
-void launch_crop_normalize_multi(const unsigned char* const* frames, const int* frame_idx, int H, int W, const float* boxes,
+void launch_crop_normalize_multi(const unsigned char* const* frames, int nframes, const int* frame_idx, int H, int W, const float* boxes,
                                  double bbox_scale, float* out, int N, int res, hipStream_t s);
 // poco_outputs_t.record: [rotmat 216 | betas 10 | cam 3 | var 24 | post-processed confidence 1] per crop (254 floats)
 void launch_pack_record(const float* rot, int rot_stride, const float* betas, int betas_stride, const float* cam, int cam_stride,

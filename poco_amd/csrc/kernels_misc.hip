@@ -364,12 +364,13 @@ __device__ __forceinline__ int cv_round(double v) { return __double2int_rn(v); }
 template <typename BoxT>
 __global__ void __launch_bounds__(256)
 crop_normalize_kernel(const unsigned char* __restrict__ frame, const unsigned char* const* __restrict__ frames,
-                      const int* __restrict__ frame_idx, int H, int W, const BoxT* __restrict__ boxes,
+                      const int* __restrict__ frame_idx, int nframes, int H, int W, const BoxT* __restrict__ boxes,
                       double bbox_scale, float* __restrict__ out, int res) {
 #pragma clang fp contract(off)
   __shared__ double sM[6];
   const int n = blockIdx.y, row0 = blockIdx.x * CROP_ROWS;
-  if (frames) frame = frames[frame_idx[n]];
+  // (an index outside the table is clamped into it: a caller's bad index reads the wrong frame, never a wild device pointer - ADVICE r4)
+  if (frames) frame = frames[min(max(frame_idx[n], 0), nframes - 1)];
   if (threadIdx.x < 64) {                    // the whole first wave solves the same system (no divergence, no broadcast)
     double Mi[6];
     crop_inverse_affine((double)boxes[n * 4], (double)boxes[n * 4 + 1], (double)boxes[n * 4 + 2], (double)boxes[n * 4 + 3],
@@ -431,17 +432,17 @@ static void launch_crop_t(const unsigned char* frame, int H, int W, const BoxT* 
   for (int n0 = 0; n0 < N; n0 += 65535) {             // gridDim.y limit
     const int nn = N - n0 < 65535 ? N - n0 : 65535;
     hipLaunchKernelGGL(crop_normalize_kernel<BoxT>, dim3((res + CROP_ROWS - 1) / CROP_ROWS, nn), dim3(256), 0, s, frame,
-                       (const unsigned char* const*)nullptr, (const int*)nullptr, H, W,
+                       (const unsigned char* const*)nullptr, (const int*)nullptr, 0, H, W,
                        boxes + (size_t)n0 * 4, bbox_scale, out + (size_t)n0 * 3 * res * res, res);
   }
 }
 
-void launch_crop_normalize_multi(const unsigned char* const* frames, const int* frame_idx, int H, int W, const float* boxes,
+void launch_crop_normalize_multi(const unsigned char* const* frames, int nframes, const int* frame_idx, int H, int W, const float* boxes,
                                  double bbox_scale, float* out, int N, int res, hipStream_t s) {
   for (int n0 = 0; n0 < N; n0 += 65535) {
     const int nn = N - n0 < 65535 ? N - n0 : 65535;
     hipLaunchKernelGGL(crop_normalize_kernel<float>, dim3((res + CROP_ROWS - 1) / CROP_ROWS, nn), dim3(256), 0, s,
-                       (const unsigned char*)nullptr, frames, frame_idx + n0, H, W, boxes + (size_t)n0 * 4, bbox_scale,
+                       (const unsigned char*)nullptr, frames, frame_idx + n0, nframes, H, W, boxes + (size_t)n0 * 4, bbox_scale,
                        out + (size_t)n0 * 3 * res * res, res);
   }
 }

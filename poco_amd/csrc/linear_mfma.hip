@@ -127,6 +127,11 @@ linear_mfma_kernel(const LinParams p) {
 // v where `ok`, zeros elsewhere - as a MULTIPLICATION by 1 / 0, which the optimiser cannot turn back into a predicated load.  A lane
 // whose tap is padding loaded the CENTRE pixel of its own window: a finite value whenever the true output is finite (that pixel
 // contributes to the same output through the centre tap), so 0 * v is an exact zero in every case that matters.
+// CAVEAT: if that centre pixel is +-Inf or NaN, 0 * v is NaN where true zero padding contributes 0 - an output that
+// the reference computes as +-Inf (an overflowed activation next to the border) comes out as NaN on this path only, i.e. results
+// could then differ between batch sizes that use ALG 5 (1 ... 4 crops) and those that do not.  Not reachable with finite
+// activations (every test and every trained network in range); a bitwise mask would be exact but `v & (ok ? ~0 : 0)` is folded back
+// into select(ok, v, 0) by instcombine, i.e. into the predicated load this function exists to avoid.
 __device__ __forceinline__ float4 select_or_zero(float4 v, bool ok) {
   const float k = ok ? 1.f : 0.f;
   return make_float4(v.x * k, v.y * k, v.z * k, v.w * k);

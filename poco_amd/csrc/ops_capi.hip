@@ -49,12 +49,14 @@ static int conv_common(const float* d_in, int B, int H, int W, int Cin, const fl
   POCO_HIP_CHECK(db.upload(shift));
   ConvDesc d{};
   DevBuf dwh;
+#if POCO_EXPERIMENTS
   if (ks == 1 && cfg7 && cfg7[6] == 12 && Cin % 32 == 0) {       // split-fp16 experiment: hi / lo halves of the weights
     std::vector<float> ph(gemm1x1h_packed_floats(Cin, Cout16));
     gemm1x1h_pack_weights(h_w, h_scale, Cout, Cin, Cout16, ph.data());
     POCO_HIP_CHECK(dwh.upload(ph));
     d.wfrag_h = dwh.p;
   }
+#endif
   if (ks == 3 && stride == 1) {
     std::vector<float> wt, pu(conv_packed_weight_floats(Cin, Cout16, 4));
     conv_wino_transform_weights(h_w, Cout, Cin, &wt);
@@ -194,6 +196,7 @@ extern "C" int poco_tune_conv(int B, int H, int W, int Cin, int Cout, int ks, in
   DevBuf dwh;
   bool any12 = false;
   for (int i = 0; i < ncfg; ++i) any12 = any12 || cfgs6[CONV_CFG_INTS * i + 6] == 12;
+#if POCO_EXPERIMENTS
   if (any12 && ks == 1 && Cin % 32 == 0) {               // split-fp16 experiment: timing only, hi / lo halves of random weights
     std::vector<float> hw2((size_t)Cout * Cin), ph(gemm1x1h_packed_floats(Cin, Cout));
     for (auto& v : hw2) v = rnd() * ws;
@@ -201,6 +204,7 @@ extern "C" int poco_tune_conv(int B, int H, int W, int Cin, int Cout, int ks, in
     POCO_HIP_CHECK(dwh.upload(ph));
     d.wfrag_h = dwh.p;
   }
+#endif
   d.B = B; d.H = H; d.W = W; d.Cin = Cin; d.Cout = Cout; d.ks = ks; d.stride = stride; d.act = 1;
   hipEvent_t e0, e1;
   POCO_HIP_CHECK(hipEventCreate(&e0));
@@ -252,7 +256,7 @@ extern "C" int poco_crop_normalize_multi(const unsigned char* const* d_frames, i
     return POCO_ERR_ARG;
   }
   if (N == 0) return POCO_OK;
-  launch_crop_normalize_multi(d_frames, d_frame_idx, H, W, d_boxes, bbox_scale, d_out, N, res, (hipStream_t)stream);
+  launch_crop_normalize_multi(d_frames, nframes, d_frame_idx, H, W, d_boxes, bbox_scale, d_out, N, res, (hipStream_t)stream);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { poco_set_error(std::string("poco_crop_normalize_multi: ") + hipGetErrorString(e)); return POCO_ERR_HIP; }
   return POCO_OK;

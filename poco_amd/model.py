@@ -95,7 +95,7 @@ class POCO:
                  num_flow_layers=3, sigma_dim=1, num_nf_rv=9, mask_params_id="", nflow_mask_type="alter",
                  exclude_uncert_idx="", use_dropout=False, use_iter_feats=False, cond_nflow=True, context_dim=512,
                  gt_pose_cond=False, gt_pose_cond_ds="h36m", gt_pose_cond_ratio=0.25, pretrained=None,
-                 inf_model="best", is_test=True, *, max_batch=64, smpl=None, device="cuda:0", keep_state_dict=True,
+                 inf_model="best", is_test=True, *, max_batch=64, smpl=None, device="cuda:0", keep_state_dict=None,
                  engine_options=None, max_graphs=8):
         if img_res != 224:
             raise ValueError("the engine is built for 224x224 crops (configs/demo_poco_*.yaml DATASET.IMG_RES)")
@@ -121,9 +121,11 @@ class POCO:
         self._finalized = False
         self._loaded = set()
         # host copies for state_dict() (nn.Module.state_dict() always works in the reference: checkpoint re-save, weight diffing).
-        # keep_state_dict=False drops them (the engine keeps only BN-folded, fragment-packed copies on the device; the originals
-        # are ~300 MB of host memory for HRNet-W48): state_dict() then re-reads them from the `pretrained` file if there was one
-        self._state = {} if keep_state_dict else None
+        # The engine itself keeps only BN-folded, fragment-packed copies on the device; the originals are ~300 MB of host memory
+        # for HRNet-W48.  keep_state_dict = None (default): kept only for tensors that cannot be re-read - a model built from a
+        # `pretrained` file drops them and state_dict() re-reads that file on demand, a model fed through
+        # load_state_dict() keeps them so that state_dict() works like nn.Module's.  True / False force either way.
+        self._state = None if (keep_state_dict is False or (keep_state_dict is None and pretrained is not None)) else {}
         self._pretrained_path = None
         if smpl is not None:
             self.load_smpl(smpl)
@@ -186,8 +188,8 @@ class POCO:
 
     def state_dict(self) -> "Dict[str, torch.Tensor]":
         """The loaded parameters under the reference's state_dict keys (nn.Module.state_dict of pocolib.models.POCO,
-        poco.py:13-42), in the engine's declaration order, as CPU tensors.  Needs `keep_state_dict=True` at construction
-        (default False: the engine itself keeps only BN-folded, MFMA-fragment-packed copies on the device).
+        poco.py:13-42), in the engine's declaration order, as CPU tensors - from the host copies (models fed through
+        load_state_dict) or re-read from the `pretrained` file (see `keep_state_dict`).
         Differences from the reference's state_dict(): the `smpl.*` buffers are not included (the body model is loaded
         separately, load_smpl); entries the engine tolerates but never reads (num_batches_tracked, backbone.final_layer, ...)
         appear only if they were loaded; values come back in the dtype they were loaded with (an int64
@@ -320,11 +322,16 @@ class POCO:
         At most `max_graphs` graphs are kept (least recently used first out; `release_graphs()` drops them all): a caller that
         hands over fresh tensors every time would otherwise grow the cache without bound."""
         from collections import OrderedDict
-        key = (tuple(sorted((k, v.data_ptr()) for k, v in batch.items())), tuple(sorted((k, v.data_ptr()) for k, v in out.items())))
+        # address AND shape of every tensor: a view of a captured tensor (x[:8] of a batch captured at 16 crops) has the same
+        # data_ptr and must get its own graph - replaying the 16-crop graph would overwrite rows 8-15 of the caller's outputs
+        ident = lambda d: tuple(sorted((k, v.data_ptr(), tuple(v.shape)) for k, v in d.items()))
+        key = (ident(batch), ident(out))
         cache = self.__dict__.setdefault("_graphs", OrderedDict())
         if key in cache:
             cache.move_to_end(key)
         else:
+            if len(cache) >= max(1, self.max_graphs):
+                torch.cuda.synchronize()              # a graph about to be dropped may still be replaying on the stream
             while len(cache) >= max(1, self.max_graphs):
                 cache.popitem(last=False)
             self(batch, out=out)                      # warm-up on the capture stream's pool (tuning table, attributes)

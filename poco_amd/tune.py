@@ -154,6 +154,9 @@ def candidates(B, H, W, Cin, Cout, ks, stride, lds_cap=150 * 1024) -> List[Tuple
                     tot = max(3 * raw + 3 * u + 2 * v, 3 * raw + u + 4096)
                     if raw <= 1024 and tot * 16 <= 160 * 1024:
                         out.add((1, NT, 2, 4, R, ni, 8))
+                    # ALG 13 (whole-position MFMA waves, round 5): the same rings without the exchange area
+                    if raw <= 1024 and (3 * raw + 3 * u + 2 * v) * 16 <= 160 * 1024:
+                        out.add((1, NT, 2, 1, R, ni, 13))
             # ALG 8 with FLAT items (R = 4, NI = 0; round 4): 32 consecutive tiles of the flattened (image, tile row, tile column)
             # order per item, 6-row strip patch with slots skewed by pos / 16
             fmax = (TX4 - 1 + 32 + TX4 - 1) // TX4
@@ -162,6 +165,8 @@ def candidates(B, H, W, Cin, Cout, ks, stride, lds_cap=150 * 1024) -> List[Tuple
             u, v = NT * 576, 2 * 576
             if raw <= 1024 and max(3 * raw + 3 * u + 2 * v, 3 * raw + u + 4096) * 16 <= 160 * 1024:
                 out.add((1, NT, 2, 4, 4, 0, 8))
+            if raw <= 1024 and (3 * raw + 3 * u + 2 * v) * 16 <= 160 * 1024:
+                out.add((1, NT, 2, 1, 4, 0, 13))
             # ... over a MOSAIC of MS x MS images that share their zero borders (R = 4 MS): only where it saves tiles (14 x 14 planes:
             # 15 x 15 tiles per 4 x 4 images instead of 16 x 16)
             for MS in (2, 4, 8):
@@ -255,8 +260,13 @@ def apply_table(model, B: int, table=None) -> int:
         if d is None:
             continue
         rest = shape_key(B, *d[:6]).split("x", 1)[1]
-        for b, cfg in sorted(by_shape.get(rest, []), key=lambda bc: (abs(math.log(bc[0] / B)), bc[0])):
+        # nearest tuned batch in log space, ties to the LARGER neighbour (its tiles were chosen with more blocks in flight, the safer
+        # direction).  The split-K direct conv (ALG 5 with ks = 3) re-streams all 9 Cin Cout weights per 64-pixel block: its
+        # entries were tuned at 1 / 4 crops and only transfer to batch sizes up to the tuned one
+        for b, cfg in sorted(by_shape.get(rest, []), key=lambda bc: (abs(math.log(bc[0] / B)), -bc[0])):
             if not cfg or cfg[0] <= 0:
+                continue
+            if cfg[6] == 5 and d[4] == 3 and B > b:
                 continue
             try:
                 model.set_conv_cfg(i, B, cfg)

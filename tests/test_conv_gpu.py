@@ -139,6 +139,9 @@ def test_conv_winograd_half_deep_rings(case, nt, cuda):
     slice c and awaited with a counted s_waitcnt vmcnt that leaves one batch in flight (small-batch latency).  Same MFMAs in the same
     order as the 2-deep kernel: BITWISE its result, for 1 ... 24 slices (K = 16 ... 384), one tile per block and persistent blocks that
     walk several; configurations whose rings do not fit the LDS are refused."""
+    from tests import util as _u
+    if not _u.has_experiments():
+        pytest.skip("experiment build only (python -m poco_amd.build --experiments; POCO_HIP_LIB=poco_amd/lib/exp/libpoco_hip_experiments.so)")
     from poco_amd import ops
     B, H, W, Cin, Cout, use_res = case
     rng = np.random.default_rng(B * 7 + Cin + Cout)
@@ -300,6 +303,9 @@ def test_conv1x1_split_f16_experiment(case, cfg, cuda):
     """ALG 12 (EXPERIMENT, csrc/gemm1x1h.hip): 1x1 convs with every operand split into fp16 hi + lo, three
     v_mfma_f32_16x16x32_f16 per product, fp32 accumulation.  22 mantissa bits per operand: within 2e-5 of the fp64 conv like
     the fp32 kernels (values O(1), K up to 1024, odd K = 3 slices of 32)."""
+    from tests import util as _u
+    if not _u.has_experiments():
+        pytest.skip("experiment build only (python -m poco_amd.build --experiments; POCO_HIP_LIB=poco_amd/lib/exp/libpoco_hip_experiments.so)")
     from poco_amd import ops
     B, H, W, Cin, Cout, stride, has_res = case
     rng = np.random.default_rng(B * 977 + Cin + Cout)

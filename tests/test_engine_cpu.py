@@ -31,7 +31,9 @@ def test_library_reads_no_environment_variable():
     blob = _lib.LIB_PATH.read_bytes()
     found = sorted(set(m.decode() for m in re.findall(rb"POCO_[A-Z0-9_]{3,}", blob)))
     assert found == [], found
-    for f in sorted((Path(__file__).resolve().parent.parent / "poco_amd" / "csrc").glob("*")):
+    for f in sorted((Path(__file__).resolve().parent.parent / "poco_amd" / "csrc").rglob("*")):
+        if not f.is_file():
+            continue
         depth_stack = []
         for ln in f.read_text().splitlines():
             s = ln.strip()
@@ -203,7 +205,7 @@ def test_tuned_table_entries_are_valid_configurations(variant):
         for i in convs:
             cfg = m._L.poco_get_conv_cfg       # the active configuration is always retrievable
             c = (C.c_int * 7)()
-            assert cfg(m._h, i, B, c) == 0 and c[6] in (0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11)
+            assert cfg(m._h, i, B, c) == 0 and c[6] in (0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 13)
 
 
 def test_c_abi_from_plain_c(tmp_path):
@@ -285,3 +287,19 @@ def test_schedule_has_no_unsynchronised_cross_lane_read(variant, xdep, monkeypat
 
 def phase_monotone(sched, k):
     return k == 0 or sched[k][0] >= sched[k - 1][0]
+
+
+def test_shipped_library_contains_no_experiments():
+    """the split-fp16 GEMM (csrc/exp/gemm1x1h.hip) and the 3-deep rings of ALG 4 are built only by
+    `python -m poco_amd.build --experiments`: in the shipped library `split_f16` is an unknown build option and no symbol of
+    either is linked in."""
+    import subprocess
+    from tests import util
+    if util.has_experiments():
+        pytest.skip("POCO_HIP_LIB points at an experiment build")
+    names = subprocess.run(["nm", "-C", "--defined-only", str(_lib.LIB_PATH)], capture_output=True, text=True).stdout
+    assert "gemm1x1h" not in names
+    blob = _lib.LIB_PATH.read_bytes()
+    assert b"gemm1x1h" not in blob and b"split_f16" not in blob
+    with pytest.raises(_lib.PocoHipError, match="split_f16"):
+        POCO(backbone="resnet50-cliff", num_flow_layers=1, max_batch=1, engine_options={"split_f16": 1})

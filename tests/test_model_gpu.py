@@ -318,6 +318,9 @@ def test_split_f16_experiment_passes_the_gate(cuda, monkeypatch):
     """VERDICT r2 next #9 (EXPERIMENT, bench.py --split-f16, never the default): ResNet-50-CLIFF with every plain 1x1 conv on the
     split-fp16 GEMM (fp16 hi + lo, 3 MFMAs per product) must pass the STRESS fixtures at the same 1e-3 gate - golden B = 2 made by
     the reference's modules, and the oracle at the bench batch with the tuned table."""
+    from tests import util as _u
+    if not _u.has_experiments():
+        pytest.skip("experiment build only (python -m poco_amd.build --experiments; POCO_HIP_LIB=poco_amd/lib/exp/libpoco_hip_experiments.so)")
     variant = "resnet50-cliff"
     m = util.make_engine(variant, max_batch=2, profile="stress", options={"split_f16": 1})
     n12 = sum(1 for i, _ in enumerate(m.ops()) if m.conv_desc(i) is not None and m.conv_desc(i)[4] == 1 and m.conv_desc(i)[2] % 32 == 0
@@ -391,6 +394,37 @@ def test_graph_cache_is_bounded(cuda):
     assert torch.equal(outs[0]["pred_pose"], first["pred_pose"]) and len(m._graphs) == 2
     m.release_graphs()
     assert not hasattr(m, "_graphs") or not m._graphs
+
+
+def test_graph_cache_tells_views_of_one_tensor_apart(cuda):
+    """the cache key was (name, data_ptr) only, so x[:3] of tensors already captured at 6 crops replayed the
+    6-crop graph and overwrote rows 3-5 of the caller's outputs.  The key now carries the shapes: the view gets its own capture."""
+    m = util.make_engine("resnet50-cliff", max_batch=6)
+    batch = util.cuda_batch(synth.synth_batch(6, 11), cuda)
+    out = m._alloc_outputs(6, False)
+    m.graph_forward(batch, out)
+    torch.cuda.synchronize()
+    full = {k: v.clone() for k, v in out.items()}
+    # refill rows 3-5 with other crops, then ask for the first three only through views of the SAME storage
+    other = util.cuda_batch(synth.synth_batch(6, 12), cuda)
+    for k in batch:
+        batch[k][3:] = other[k][3:]
+    sentinel = {k: v[3:].clone().fill_(-7.0) for k, v in out.items()}
+    for k, v in out.items():
+        v[3:] = sentinel[k]
+    vb = {k: v[:3] for k, v in batch.items()}
+    vo = {k: v[:3] for k, v in out.items()}
+    assert all(vb[k].data_ptr() == batch[k].data_ptr() for k in batch)
+    m.graph_forward(vb, vo)
+    torch.cuda.synchronize()
+    assert len(m._graphs) == 2
+    for k in ("pred_pose", "pred_shape", "pred_cam", "var_pose", "smpl_vertices", "record"):
+        assert torch.equal(out[k][:3], full[k][:3]), k                     # crops are independent: rows 0-2 as before
+        assert torch.equal(out[k][3:], sentinel[k]), k                     # rows 3-5 of the caller's storage untouched
+    m.graph_forward(batch, out)                                            # the 6-crop graph is still there and sees the new rows
+    torch.cuda.synchronize()
+    assert len(m._graphs) == 2 and not torch.equal(out["pred_pose"][3:], full["pred_pose"][3:])
+    assert torch.equal(out["pred_pose"][:3], full["pred_pose"][:3])
 
 
 def test_graph_replay_matches_eager(cuda):

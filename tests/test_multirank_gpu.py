@@ -54,6 +54,22 @@ def test_bench_gpus4_ragged_batch_gathers(cuda):
     assert sum(ln.startswith("{") for ln in r.stdout.splitlines()) == 1
 
 
+def test_bench_config4_shape_eight_ranks_of_64_crops(cuda):
+    """VERDICT r4 next #5 / BASELINE config #4 (POCO-CLIFF, 512 crops over 8 ranks): the exact job shape of the driver's scaling run
+    - 8 ranks x 64 crops of the headline variant, engine-written records, ONE all_gather_into_tensor per step, every gathered row
+    checked against rank 0's own recomputation of the other ranks' batches - rehearsed on the one GPU with the gloo transport
+    (eight engines, 8 x 0.9 GB of workspace, share the 288 GB).  Only the RCCL transport itself is left to the 8-GPU node."""
+    r = _run(["bench.py", "--gpus", "8", "--backend", "gloo", "--steps", "2", "--warmup", "1", "--batch", "64", "--check-gather",
+              "--no-stream", "--no-cpu-baseline", "--no-side", "--no-variants", "--no-dominant"], timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = _json_line(r.stdout)
+    assert line["n_gpus"] == 8 and line["dist"]["world_size"] == 8 and line["config"]["global_batch"] == 512
+    assert line["config"]["variant"] == "hrnet_w48_cls-cliff" and line["config"]["crops_per_gpu"] == 64
+    assert line["dist"]["gather_check"].startswith("ok"), line["dist"]
+    assert line["scaling"] == "weak" and line["summary"]["n_gpus"] == 8
+    assert sum(ln.startswith("{") for ln in r.stdout.splitlines()) == 1
+
+
 def test_rccl_buffers_dry_check(cuda):
     """The nccl branch of bench.py hands RCCL exactly these buffers: validated here for an 8-rank job without a second GPU
     (device tensors of this rank's own device, float32, contiguous, recv = world x send), and the check refuses host or

@@ -39,3 +39,20 @@ def oracle_forward(variant, batch_np, seed=0, smpl_seed=7, profile="default"):
     from oracle import poco_ref
     sd = poco_ref.to_torch(synth_weights(variant, seed, profile))
     return poco_ref.poco_forward(variant, sd, poco_ref.to_torch(synth.synth_smpl(smpl_seed)), poco_ref.to_torch(batch_np))
+
+
+def has_experiments() -> bool:
+    """Is the loaded library an experiment build (python -m poco_amd.build --experiments; POCO_HIP_LIB=poco_amd/lib/exp/libpoco_hip_experiments.so)?
+    The shipped library contains neither the split-fp16 GEMM (ALG 12) nor the 3-deep rings of ALG 4: `split_f16` is then an unknown
+    build option (host-only check, no GPU needed)."""
+    import ctypes as C
+    from poco_amd import _lib
+    L = _lib.lib()
+    L.poco_create_ex.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_char_p, C.POINTER(C.c_void_p)]
+    L.poco_destroy.argtypes = [C.c_void_p]
+    L.poco_destroy.restype = None
+    h = C.c_void_p()
+    if L.poco_create_ex(b"resnet50-cliff", 1, 1, b"split_f16=1", C.byref(h)) != 0:
+        return False
+    L.poco_destroy(h)
+    return True

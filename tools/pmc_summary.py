@@ -28,6 +28,12 @@ def csrc_digest() -> str:
             # code only: // comments and blank lines do not invalidate a profile
             code = [ln.split("//")[0].rstrip() for ln in f.read_text().splitlines()]
             h.update("\n".join(ln for ln in code if ln.strip()).encode())
+    # ... and the tile configurations the launches run with: executed MFMA flops / busy cycles / traffic are properties of
+    # (kernel, configuration), and a table-only change must make a committed profile stale too; only the `cfg` lists
+    # count, re-measured ms / tflops fields of an unchanged configuration do not
+    import json
+    table = json.loads((ROOT / "poco_amd" / "tuned" / "gfx950.json").read_text())
+    h.update(json.dumps({k: v.get("cfg") for k, v in sorted(table.items())}, sort_keys=True).encode())
     return h.hexdigest()[:16]
 
 

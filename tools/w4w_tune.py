@@ -1,0 +1,93 @@
+"""Round 5: in-context pass over the F(4x4) shapes with ALG 13 (whole-position MFMA waves, conv_wino4w.hip) as candidates.
+  python tools/w4w_tune.py variant B [--write] [--two-pass]
+Greedy over the shapes (most expensive first): the table's configuration vs ALG 13 with the same items (rectangular R / NI or
+flat), with flat items, on all CUs or half of them (cfg MT = 1 / 2) and the other NTs that fit; timed as hipGraph replays of the
+whole forward; a candidate replaces the current one if the forward gets > 0.25 % faster."""
+import json, sys, time
+from pathlib import Path
+import numpy as np
+import torch
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+from poco_amd import ops, synth, tune  # noqa: E402
+from poco_amd._lib import PocoHipError  # noqa: E402
+from tests import util  # noqa: E402
+
+variant, B = sys.argv[1], int(sys.argv[2])
+dev = torch.device("cuda:0")
+batch = util.cuda_batch(synth.synth_batch(B, 1), dev)
+m = util.make_engine(variant, max_batch=B)
+m(batch)
+
+
+def fwd_ms(reps=40):
+    m.release_graphs()
+    out = m._alloc_outputs(B, False)
+    for _ in range(6):
+        m.graph_forward(batch, out)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        m.graph_forward(batch, out)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps * 1e3
+
+
+prof = m.profile_ops(batch, iters=3)
+shapes, cost = {}, {}
+for i, (nm, f, ty, ms) in enumerate(prof):
+    d = m.conv_desc(i)
+    if d is None or not (d[4] == 3 and d[5] == 1 and d[0] >= 14 and d[1] >= 14):
+        continue
+    k = tune.shape_key(B, *d[:6])
+    shapes.setdefault(k, []).append(i)
+    cost[k] = cost.get(k, 0.0) + ms
+base = fwd_ms()
+print(f"{variant} B={B}: table {base:.3f} ms", flush=True)
+cur_t = base
+picked = {}
+npass = 2 if "--two-pass" in sys.argv else 1
+for k in [kk for _ in range(npass) for kk in sorted(cost, key=lambda kk: -cost[kk])]:
+    idxs = shapes[k]
+    H, W, Cin, Cout = m.conv_desc(idxs[0])[:4]
+    cur = tuple(m.conv_cfg(idxs[0], B))
+    all13 = [c for c in tune.candidates(B, H, W, Cin, Cout, 3, 1) if c[6] == 13]
+    same_items = [c for c in all13 if c[1] == cur[1] and (c[4], c[5]) == (cur[4], cur[5])]
+    flat = [c for c in all13 if c[5] == 0]
+    rect = [c for c in all13 if c[5] != 0 and c not in same_items]
+    rect.sort(key=lambda c: (c[1] != cur[1], -c[1], -c[4] * max(1, c[5])))
+    cands = []
+    for c in same_items + sorted(flat, key=lambda c: (c[1] != cur[1], -c[1])) + rect[:3]:
+        for mt in (1, 2):
+            cc = (mt,) + c[1:]
+            if cc != cur and cc not in cands:
+                cands.append(cc)
+    best, best_t = cur, cur_t
+    for c in cands:
+        try:
+            for i in idxs:
+                m.set_conv_cfg(i, B, c)
+        except PocoHipError:
+            continue
+        t = fwd_ms()
+        print(f"    {k} x{len(idxs)} {c}: {t:.3f} ms", flush=True)
+        if t < best_t * 0.9975:
+            best, best_t = c, t
+    for i in idxs:
+        m.set_conv_cfg(i, B, best)
+    if best != cur:
+        picked[k] = best
+        cur_t = best_t
+    print(f"  {k:28s} x{len(idxs):3d} {cur} -> {best}  forward {cur_t:.3f} ms", flush=True)
+final = fwd_ms()
+print(f"{variant} B={B}: {base:.3f} -> {final:.3f} ms ({(final / base - 1) * 100:+.2f} %), {len(picked)} entries moved: {picked}")
+if "--write" in sys.argv and picked and final < base * 0.998:
+    full = json.loads(tune.TABLE.read_text())
+    for k, c in picked.items():
+        Bk, H, W, Cin, Cout, ks, st = map(int, __import__("re").fullmatch(r"(\d+)x(\d+)x(\d+)x(\d+)x(\d+)k(\d+)s(\d+)", k).groups())
+        x = torch.randn(B, H, W, Cin, device=dev)
+        w = (np.random.default_rng(0).standard_normal((Cout, Cin, 3, 3)) / np.sqrt(9 * Cin)).astype(np.float32)
+        ms, tf, _ = ops.bench_conv2d(x, w, 1, cfg=c, iters=30)
+        ent = full.setdefault(k, {"heuristic_ms": 0.0, "uses": len(shapes[k])})
+        ent.update({"cfg": list(c), "ms": round(float(ms), 5), "tflops": round(float(tf), 1), "in_context": True, "uses": len(shapes[k])})
+    tune.TABLE.write_text(json.dumps(full, indent=0, sort_keys=True))
+    print("wrote", tune.TABLE)
