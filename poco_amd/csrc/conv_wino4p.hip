@@ -56,6 +56,9 @@ using w4::bt_row;
                       //  4: no barrier in front of exchange round 0 (the last slice barrier already separates the last operand reads from the
                       //     exchange writes), and the producers deal the next item's first fetches over the 2 NT barrier gaps of the exchange
                       //     instead of issuing all of them in front of its first barrier (where the eight MFMA waves waited for them)
+#ifndef W4P_NINNER
+#define W4P_NINNER 1  // items walked n-group-innermost (conv_wino4p_geo.h: w4p_item_id); 0 = the round-4 order, for A/B builds
+#endif
 #ifndef W4P_TRACE
 #define W4P_TRACE 0   // 1: block 0 accumulates s_memtime phase sums of its 8 MFMA waves and 4 producer waves (tools/w4p_trace.py; reading the
                       // counter drains lgkmcnt, so a phase that ends with LDS reads in flight includes their latency)
@@ -107,11 +110,12 @@ __device__ __forceinline__ void w4p_consumer(const W4PParams& p, float4* smem, i
   const int npieces_raw = rawF4 >> 6;
   const Walk wk = item_walk(p);
   for (int item = wk.first; item < wk.end; item += wk.step) {
-    const int nt0 = (item / p.nblocks_m) * NT;
-    const Tile tl = tile_of<FLAT>(p, item, grp, idx);
+    const int id = W4P_NINNER ? w4p_item_id(p, item) : item;
+    const int nt0 = (id / p.nblocks_m) * NT;
+    const Tile tl = tile_of<FLAT>(p, id, grp, idx);
     // ---- staging duties of this wave: raw pieces wave, wave + 8 and U pieces wave, wave + 8, ... ------------------------------
     int goff[W4P_MAXP];
-    raw_piece_offsets<W4P_MAXP, FLAT>(p, item, wave, W4P_NCONS, lane, goff);
+    raw_piece_offsets<W4P_MAXP, FLAT>(p, id, wave, W4P_NCONS, lane, goff);
     bool live[W4P_MAXP];                                    // pieces with at least one in-image position (wave-uniform)
 #pragma unroll
     for (int k = 0; k < W4P_MAXP; ++k) live[k] = __ballot(goff[k] >= 0) != 0ull;
@@ -494,8 +498,9 @@ __device__ __forceinline__ void w4p_producer(const W4PParams& p, float4* smem, i
   auto prefetch_item = [&](int item) __attribute__((always_inline)) {
     constexpr int MAXP = 4;                                 // raw pieces pw, pw + 4, ... (rawF4 <= 1024 slots)
     int goff[MAXP];
-    raw_piece_offsets<MAXP, FLAT>(p, item, pw, W4P_NPROD, lane, goff);
-    const int nt0 = (item / p.nblocks_m) * NT;
+    const int id = W4P_NINNER ? w4p_item_id(p, item) : item;
+    raw_piece_offsets<MAXP, FLAT>(p, id, pw, W4P_NPROD, lane, goff);
+    const int nt0 = (id / p.nblocks_m) * NT;
 #pragma unroll
     for (int k = 0; k < MAXP; ++k) {
       const int piece = pw + W4P_NPROD * k;
@@ -531,7 +536,7 @@ __device__ __forceinline__ void w4p_producer(const W4PParams& p, float4* smem, i
     constexpr int NU = (9 * NT + W4P_NPROD - 1) / W4P_NPROD;
     constexpr int NJ = 12 + 2 * NU;
     const int lo = part * NJ / nparts, hi = (part + 1) * NJ / nparts;
-    const int nt0 = (item / p.nblocks_m) * NT;
+    const int nt0 = ((W4P_NINNER ? w4p_item_id(p, item) : item) / p.nblocks_m) * NT;
     if (part == 0) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
@@ -562,7 +567,7 @@ __device__ __forceinline__ void w4p_producer(const W4PParams& p, float4* smem, i
     }
   };
   auto issue_u1 = [&](int item) __attribute__((always_inline)) {       // U(1) -> ring slot 1
-    const int nt0 = (item / p.nblocks_m) * NT;
+    const int nt0 = ((W4P_NINNER ? w4p_item_id(p, item) : item) / p.nblocks_m) * NT;
 #pragma unroll
     for (int i0 = 0; i0 < 9 * NT; i0 += W4P_NPROD) {
       const int i = i0 + pw;
@@ -580,9 +585,10 @@ __device__ __forceinline__ void w4p_producer(const W4PParams& p, float4* smem, i
   if (!(W4P_EXP & 32)) __builtin_amdgcn_s_setprio(3);
 
   for (int item = wk.first; item < wk.end; item += wk.step) {
-    const int nt0 = (item / p.nblocks_m) * NT;
+    const int id = W4P_NINNER ? w4p_item_id(p, item) : item;
+    const int nt0 = (id / p.nblocks_m) * NT;
     // ---- this lane's (tile, channel) pair: float offsets of its 36 window elements in a raw slot -----------------------
-    const Tile tl = tile_of<FLAT>(p, item, grp, idx);
+    const Tile tl = tile_of<FLAT>(p, id, grp, idx);
     // pos(k, 0) is even (patch width and tile origins are even), so the columns (2c, 2c + 1) of a window row never straddle a
     // multiple of 8 in the skewed slot order: their slots are neighbours (16 B apart) and ONE ds_read2_b32 fetches the pair
     // into a 64-bit register pair = one operand of the packed-fp32 transform below.  18 addresses / reads instead of 36.
@@ -685,7 +691,7 @@ __device__ __forceinline__ void w4p_producer(const W4PParams& p, float4* smem, i
       // the next item's first fetches, dealt over the 2 NT gaps between the barriers of the exchange rounds (no barrier in front of
       // round 0): ~5 LDS-DMA instructions (~60 clk each) per gap, so that this wave is never the last one at a barrier
       int goffn[4];
-      if (more) raw_piece_offsets<4, FLAT>(p, item + wk.step, pw, W4P_NPROD, lane, goffn);
+      if (more) raw_piece_offsets<4, FLAT>(p, W4P_NINNER ? w4p_item_id(p, item + wk.step) : item + wk.step, pw, W4P_NPROD, lane, goffn);
 #pragma unroll
       for (int gap = 0; gap < 2 * NT; ++gap) {
         if (gap > 0) __syncthreads();
@@ -801,6 +807,10 @@ int conv_wino4p_launch(const ConvDesc& d, const ConvCfg& cfg, hipStream_t stream
   p.dPW = make_fastdiv(g.PW); p.dSlab = make_fastdiv(g.PR * g.PW); p.dBands = make_fastdiv(g.nbands);
   p.dTX = make_fastdiv(g.TX); p.dTslab = make_fastdiv(g.tps);
   p.nblocks_m = flat ? g.S : (g.S + g.NI - 1) / g.NI; p.nb_n = (p.nT16 + cfg.NT - 1) / cfg.NT;
+  p.dNbn = make_fastdiv(p.nb_n);
+  // measured (tools/ninner_solo.py, tools/conv_traffic.py): 480 -> 128 @ 56x56 -4 % and 715 -> 479 MB per launch; the short-K shapes
+  // (14x14 192 -> 192, 28x28 96 -> 96) +1 ... +2 % - their patch is small next to the L2 and the extra division sits on the item start
+  p.ninner = p.nb_n > 1 && d.Cin * p.nb_n >= 1024;
   if (flat) {
     p.TY = fg.TY; p.ntiles = fg.ntiles; p.fragW = fg.fragW;
     p.dTY = make_fastdiv(fg.TY); p.dFragW = make_fastdiv(fg.fragW);

@@ -26,7 +26,19 @@ struct W4PParams {
   // 16 x 16.  TX / TY / ntiles then count the tiles of the virtual planes; Tile::b is the mosaic index, oy0 / tx are virtual.
   int MS, Hp1, Wp1;
   FastDiv dHp1, dWp1;
+  // round 5: items are WALKED n-group-innermost (walk index w = m * nb_n + n-group, so that the n-groups of one tile strip run on
+  // neighbouring blocks of one XCD at the same time and read their patch from one L2 - the PARE head's 480 -> 128 conv moved
+  // 715 MB per launch, 2.9 x its algorithmic bytes, with the n-group-outermost walk); the helpers below keep taking the id
+  // m + n-group * nblocks_m (w4p_item_id)
+  FastDiv dNbn;
+  int ninner;           // 1: walk n-group-innermost (set per launch: where the patch re-reads are heavy, Cin * nb_n >= 1024)
 };
+// walk index -> item id of the geometry helpers
+__device__ __forceinline__ int w4p_item_id(const W4PParams& p, int w) {
+  if (!p.ninner) return w;
+  const uint32_t m = fdiv((uint32_t)w, p.dNbn);
+  return (int)m + (w - (int)m * p.nb_n) * p.nblocks_m;
+}
 
 // virtual coordinate v of a mosaic axis -> (image index along the axis, coordinate inside the image); the border lines between
 // images map to coordinate H (W), i.e. "outside"
