@@ -43,6 +43,43 @@ __device__ __forceinline__ void dma16_sv(const void* sbase, unsigned voff, unsig
       : "memory");
 }
 
+// N consecutive one-KiB pieces of one contiguous stream -> LDS, in ONE asm block: source = wave-uniform base + per-lane offsets
+// voff[k] (lane * 16 + k * step bytes, loop-invariant VGPRs), LDS destination m0 = dst0 + k * step.  Per piece that is
+// s_add_u32 m0 / s_nop / global_load_lds_dwordx4 instead of the eight instructions of a dma16_sv call with its own scalar address
+// arithmetic and m0 save / restore (an LDS-DMA request cost its issuing wave ~100 clk in the first traces of this kernel).
+#define W4_DMA1 "s_add_u32 m0, m0, %[st]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 "
+template <int N>
+__device__ __forceinline__ void dma_stream(const void* sbase, const unsigned (&voff)[7], unsigned dst0, unsigned step) {
+  static_assert(N >= 1 && N <= 7, "1..7 pieces per call");
+  unsigned keep;
+  if constexpr (N == 1)
+    asm volatile("s_mov_b32 %[k], m0\n\ts_mov_b32 m0, %[d]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[v0], %[b]\n\ts_mov_b32 m0, %[k]"
+                 : [k] "=&s"(keep) : [d] "s"(dst0), [st] "s"(step), [b] "s"(sbase), [v0] "v"(voff[0]) : "memory", "scc");
+  else if constexpr (N == 2)
+    asm volatile("s_mov_b32 %[k], m0\n\ts_mov_b32 m0, %[d]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[v0], %[b]\n\t" W4_DMA1 "%[v1], %[b]\n\ts_mov_b32 m0, %[k]"
+                 : [k] "=&s"(keep) : [d] "s"(dst0), [st] "s"(step), [b] "s"(sbase), [v0] "v"(voff[0]), [v1] "v"(voff[1]) : "memory", "scc");
+  else if constexpr (N == 3)
+    asm volatile("s_mov_b32 %[k], m0\n\ts_mov_b32 m0, %[d]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[v0], %[b]\n\t" W4_DMA1 "%[v1], %[b]\n\t" W4_DMA1 "%[v2], %[b]\n\ts_mov_b32 m0, %[k]"
+                 : [k] "=&s"(keep) : [d] "s"(dst0), [st] "s"(step), [b] "s"(sbase), [v0] "v"(voff[0]), [v1] "v"(voff[1]), [v2] "v"(voff[2]) : "memory", "scc");
+  else if constexpr (N == 4)
+    asm volatile("s_mov_b32 %[k], m0\n\ts_mov_b32 m0, %[d]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[v0], %[b]\n\t" W4_DMA1 "%[v1], %[b]\n\t" W4_DMA1 "%[v2], %[b]\n\t" W4_DMA1
+                 "%[v3], %[b]\n\ts_mov_b32 m0, %[k]"
+                 : [k] "=&s"(keep) : [d] "s"(dst0), [st] "s"(step), [b] "s"(sbase), [v0] "v"(voff[0]), [v1] "v"(voff[1]), [v2] "v"(voff[2]), [v3] "v"(voff[3]) : "memory", "scc");
+  else if constexpr (N == 5)
+    asm volatile("s_mov_b32 %[k], m0\n\ts_mov_b32 m0, %[d]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[v0], %[b]\n\t" W4_DMA1 "%[v1], %[b]\n\t" W4_DMA1 "%[v2], %[b]\n\t" W4_DMA1
+                 "%[v3], %[b]\n\t" W4_DMA1 "%[v4], %[b]\n\ts_mov_b32 m0, %[k]"
+                 : [k] "=&s"(keep) : [d] "s"(dst0), [st] "s"(step), [b] "s"(sbase), [v0] "v"(voff[0]), [v1] "v"(voff[1]), [v2] "v"(voff[2]), [v3] "v"(voff[3]), [v4] "v"(voff[4]) : "memory", "scc");
+  else if constexpr (N == 6)
+    asm volatile("s_mov_b32 %[k], m0\n\ts_mov_b32 m0, %[d]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[v0], %[b]\n\t" W4_DMA1 "%[v1], %[b]\n\t" W4_DMA1 "%[v2], %[b]\n\t" W4_DMA1
+                 "%[v3], %[b]\n\t" W4_DMA1 "%[v4], %[b]\n\t" W4_DMA1 "%[v5], %[b]\n\ts_mov_b32 m0, %[k]"
+                 : [k] "=&s"(keep) : [d] "s"(dst0), [st] "s"(step), [b] "s"(sbase), [v0] "v"(voff[0]), [v1] "v"(voff[1]), [v2] "v"(voff[2]), [v3] "v"(voff[3]), [v4] "v"(voff[4]), [v5] "v"(voff[5]) : "memory", "scc");
+  else
+    asm volatile("s_mov_b32 %[k], m0\n\ts_mov_b32 m0, %[d]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[v0], %[b]\n\t" W4_DMA1 "%[v1], %[b]\n\t" W4_DMA1 "%[v2], %[b]\n\t" W4_DMA1
+                 "%[v3], %[b]\n\t" W4_DMA1 "%[v4], %[b]\n\t" W4_DMA1 "%[v5], %[b]\n\t" W4_DMA1 "%[v6], %[b]\n\ts_mov_b32 m0, %[k]"
+                 : [k] "=&s"(keep) : [d] "s"(dst0), [st] "s"(step), [b] "s"(sbase), [v0] "v"(voff[0]), [v1] "v"(voff[1]), [v2] "v"(voff[2]), [v3] "v"(voff[3]), [v4] "v"(voff[4]), [v5] "v"(voff[5]), [v6] "v"(voff[6]) : "memory", "scc");
+}
+#undef W4_DMA1
+
 // slab / patch geometry of a (R, NI) configuration: slabs of R output rows (a multiple of 4) x the full width, NI whole
 // images per block when R covers the plane; patch positions live in skewed float4 slots pos + pos/8
 struct Geo { int R, NI, nbands, S, TX, PR, PW, npos, rawF4, tps; };

@@ -48,11 +48,12 @@ using w4::bt_row;
                       // 16 no per-slice barrier work at all in the producers (neither DMA nor transform), 128 producers skip the window
                       // reads only, 512 / 1024 no U / no patch LDS-DMA inside the K loop
 #ifndef W4P_EPI
-#define W4P_EPI 7     // round 5 epilogue / item-start restructure (bit mask; 0 = the round-4 kernel, for same-box A/B builds):
+#define W4P_EPI 15     // round 5 epilogue / item-start restructure (bit mask; 0 = the round-4 kernel, for same-box A/B builds):
 #endif                //  1: the exchange area sits at the END of the LDS (over U slot 2 + V) instead of over U slots 1, 2: U(1) of the next item
                       //     is fetched together with U(0) during the exchange rounds, no exposed fetch at the item start
                       //  2: bias / residual loads of round n+1 are issued BEFORE the stores of round n and awaited before them (round 0's after
                       //     its Z is written): no vmcnt wait of a round covers the stores of the previous round any more
+                      //  8: the U pieces of a slice requested as one streamed asm block per wave (w4::dma_stream)
                       //  4: no barrier in front of exchange round 0 (the last slice barrier already separates the last operand reads from the
                       //     exchange writes), and the producers deal the next item's first fetches over the 2 NT barrier gaps of the exchange
                       //     instead of issuing all of them in front of its first barrier (where the eight MFMA waves waited for them)
@@ -137,6 +138,22 @@ __device__ __forceinline__ void w4p_consumer(const W4PParams& p, float4* smem, i
       return cnt;
     };
     auto issue_u = [&](int c4, int slot) __attribute__((always_inline)) -> int {     // U of slice c4, n-tiles nt0.. -> U ring slot
+      if constexpr ((W4P_EPI & 8) != 0) {
+        // round 5: the 9 NT pieces of a (slice, n-group) are contiguous in the packed fragments, so this wave's pieces wave, wave + 8, ...
+        // go out as ONE asm block (w4::dma_stream: per piece s_add_u32 m0 / s_nop / global_load_lds_dwordx4 instead of a dma16_sv call
+        // with its own 64-bit scalar address arithmetic and m0 save / restore).  An n-group that reaches beyond the tensor reads on into
+        // the next slice's fragments / the slack behind the last one (conv_wino4p_packed_floats); those n-tiles are never stored.
+        constexpr int NUP = (9 * NT + W4P_NCONS - 1) / W4P_NCONS;
+        const unsigned dst0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds_base + (unsigned)(p.uoff + slot * uF4) * 16u + (unsigned)wave * 1024u));
+        const float4* src = p.ufrag + (((size_t)c4 * p.nT16 + nt0) * 9 + wave) * 64;
+        unsigned voff[7];
+#pragma unroll
+        for (int k = 0; k < 7; ++k) voff[k] = (unsigned)lane * 16u + (unsigned)(k * W4P_NCONS) * 1024u;
+        const bool full = wave + W4P_NCONS * (NUP - 1) < 9 * NT;            // (wave-uniform)
+        if (full) w4::dma_stream<NUP>(src, voff, dst0, W4P_NCONS * 1024u);
+        else if constexpr (NUP > 1) w4::dma_stream<(NUP > 1 ? NUP - 1 : 1)>(src, voff, dst0, W4P_NCONS * 1024u);
+        return full ? NUP : NUP - 1;
+      }
       int cnt = 0;
       const unsigned sb = lds_base + (unsigned)(p.uoff + slot * uF4) * 16u;
 #pragma unroll
@@ -750,7 +767,7 @@ bool w4p_geo(const ConvDesc& d, const ConvCfg& cfg, w4::Geo* g, W4PLayout* L, Fl
 // packed fragments for ALG 8: [Cin/4][Cout16/16][9 pieces][64 lanes] float4; piece 2q+a (q = 0..3, a = 0..1): lane = g*16 + co_l holds
 // U[pos(q, 4a + j)][co][4 c4 + g] * scale[co], j = 0..3; piece 8: float index q*64 + lane = U[pos(q, 8)][co][4 c4 + g] * scale[co];
 // pos(q, i) = 6 (RA(q) + w4p_row(q, i)) + w4p_nu(q, i) (the slot order of the packed input transform, see w4p_nu)
-size_t conv_wino4p_packed_floats(int Cin, int Cout16) { return (size_t)36 * Cin * Cout16; }
+size_t conv_wino4p_packed_floats(int Cin, int Cout16) { return (size_t)36 * Cin * Cout16 + (size_t)2 * 9 * 256; }     // + 2 n-tile blocks of slack (streamed U requests)
 void conv_wino4p_pack_weights(const float* w_oihw, const float* scale, int Cout, int Cin, int Cout16, float* dst) {
   std::vector<double> u;
   w4::u_transform(w_oihw, Cout, Cin, &u);
@@ -758,6 +775,7 @@ void conv_wino4p_pack_weights(const float* w_oihw, const float* scale, int Cout,
   auto val = [&](int pos, int co, int ci) -> float {
     return co < Cout ? (float)(u[((size_t)pos * Cout + co) * Cin + ci] * (scale ? (double)scale[co] : 1.0)) : 0.f;
   };
+  std::fill(dst + (size_t)36 * Cin * Cout16, dst + conv_wino4p_packed_floats(Cin, Cout16), 0.f);
   for (int c4 = 0; c4 < nC4; ++c4)
     for (int nt = 0; nt < nT16; ++nt) {
       float* blk = dst + ((size_t)c4 * nT16 + nt) * 9 * 256;

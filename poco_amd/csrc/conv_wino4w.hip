@@ -123,42 +123,6 @@ __device__ __forceinline__ int w4w_item_id(const W4WParams& p, int it, int* ngro
 // SIMDs are unevenly loaded - NT = 3: SIMDs 0 / 1 carry two MFMA waves (72 MFMAs = 2304 clk per slice, the floor of the kernel),
 // SIMDs 2 / 3 one MFMA wave + one producer.
 // ---------------------------------------------------------------------------------------------------------------------
-// N consecutive one-KiB pieces of one contiguous stream -> LDS, in ONE asm block: source = wave-uniform base + per-lane offsets
-// voff[k] (lane * 16 + k * step bytes, loop-invariant VGPRs), LDS destination m0 = dst0 + k * step.  Per piece that is
-// s_add_u32 m0 / s_nop / global_load_lds_dwordx4 instead of the eight instructions of a dma16_sv call with its own scalar address
-// arithmetic and m0 save / restore (an LDS-DMA request cost its issuing wave ~100 clk in the first traces of this kernel).
-#define W4W_DMA1 "s_add_u32 m0, m0, %[st]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 "
-template <int N>
-__device__ __forceinline__ void w4w_dma_stream(const void* sbase, const unsigned (&voff)[7], unsigned dst0, unsigned step) {
-  static_assert(N >= 1 && N <= 7, "1..7 pieces per call");
-  unsigned keep;
-  if constexpr (N == 1)
-    asm volatile("s_mov_b32 %[k], m0\n\ts_mov_b32 m0, %[d]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[v0], %[b]\n\ts_mov_b32 m0, %[k]"
-                 : [k] "=&s"(keep) : [d] "s"(dst0), [st] "s"(step), [b] "s"(sbase), [v0] "v"(voff[0]) : "memory", "scc");
-  else if constexpr (N == 2)
-    asm volatile("s_mov_b32 %[k], m0\n\ts_mov_b32 m0, %[d]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[v0], %[b]\n\t" W4W_DMA1 "%[v1], %[b]\n\ts_mov_b32 m0, %[k]"
-                 : [k] "=&s"(keep) : [d] "s"(dst0), [st] "s"(step), [b] "s"(sbase), [v0] "v"(voff[0]), [v1] "v"(voff[1]) : "memory", "scc");
-  else if constexpr (N == 3)
-    asm volatile("s_mov_b32 %[k], m0\n\ts_mov_b32 m0, %[d]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[v0], %[b]\n\t" W4W_DMA1 "%[v1], %[b]\n\t" W4W_DMA1 "%[v2], %[b]\n\ts_mov_b32 m0, %[k]"
-                 : [k] "=&s"(keep) : [d] "s"(dst0), [st] "s"(step), [b] "s"(sbase), [v0] "v"(voff[0]), [v1] "v"(voff[1]), [v2] "v"(voff[2]) : "memory", "scc");
-  else if constexpr (N == 4)
-    asm volatile("s_mov_b32 %[k], m0\n\ts_mov_b32 m0, %[d]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[v0], %[b]\n\t" W4W_DMA1 "%[v1], %[b]\n\t" W4W_DMA1 "%[v2], %[b]\n\t" W4W_DMA1
-                 "%[v3], %[b]\n\ts_mov_b32 m0, %[k]"
-                 : [k] "=&s"(keep) : [d] "s"(dst0), [st] "s"(step), [b] "s"(sbase), [v0] "v"(voff[0]), [v1] "v"(voff[1]), [v2] "v"(voff[2]), [v3] "v"(voff[3]) : "memory", "scc");
-  else if constexpr (N == 5)
-    asm volatile("s_mov_b32 %[k], m0\n\ts_mov_b32 m0, %[d]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[v0], %[b]\n\t" W4W_DMA1 "%[v1], %[b]\n\t" W4W_DMA1 "%[v2], %[b]\n\t" W4W_DMA1
-                 "%[v3], %[b]\n\t" W4W_DMA1 "%[v4], %[b]\n\ts_mov_b32 m0, %[k]"
-                 : [k] "=&s"(keep) : [d] "s"(dst0), [st] "s"(step), [b] "s"(sbase), [v0] "v"(voff[0]), [v1] "v"(voff[1]), [v2] "v"(voff[2]), [v3] "v"(voff[3]), [v4] "v"(voff[4]) : "memory", "scc");
-  else if constexpr (N == 6)
-    asm volatile("s_mov_b32 %[k], m0\n\ts_mov_b32 m0, %[d]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[v0], %[b]\n\t" W4W_DMA1 "%[v1], %[b]\n\t" W4W_DMA1 "%[v2], %[b]\n\t" W4W_DMA1
-                 "%[v3], %[b]\n\t" W4W_DMA1 "%[v4], %[b]\n\t" W4W_DMA1 "%[v5], %[b]\n\ts_mov_b32 m0, %[k]"
-                 : [k] "=&s"(keep) : [d] "s"(dst0), [st] "s"(step), [b] "s"(sbase), [v0] "v"(voff[0]), [v1] "v"(voff[1]), [v2] "v"(voff[2]), [v3] "v"(voff[3]), [v4] "v"(voff[4]), [v5] "v"(voff[5]) : "memory", "scc");
-  else
-    asm volatile("s_mov_b32 %[k], m0\n\ts_mov_b32 m0, %[d]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[v0], %[b]\n\t" W4W_DMA1 "%[v1], %[b]\n\t" W4W_DMA1 "%[v2], %[b]\n\t" W4W_DMA1
-                 "%[v3], %[b]\n\t" W4W_DMA1 "%[v4], %[b]\n\t" W4W_DMA1 "%[v5], %[b]\n\t" W4W_DMA1 "%[v6], %[b]\n\ts_mov_b32 m0, %[k]"
-                 : [k] "=&s"(keep) : [d] "s"(dst0), [st] "s"(step), [b] "s"(sbase), [v0] "v"(voff[0]), [v1] "v"(voff[1]), [v2] "v"(voff[2]), [v3] "v"(voff[3]), [v4] "v"(voff[4]), [v5] "v"(voff[5]), [v6] "v"(voff[6]) : "memory", "scc");
-}
-#undef W4W_DMA1
 
 // WHO requests what (W4W_DMAW) and WHERE the producers sit (W4W_LAYOUT).  The 9 NT U pieces of a slice are dealt round-robin to
 // NWU issuers, the rawF4 / 64 patch pieces to NWR issuers; an issuer is an MFMA wave (by its MFMA index m = 0 .. 2 NT - 1) or a
@@ -260,17 +224,17 @@ struct W4WDuty {
     constexpr int NA = NUP <= 7 ? NUP : 7;                      // first call: up to 7 pieces
     const bool full = dw + NW * (NUP - 1) < 9 * NT;             // (wave-uniform)
     if constexpr (NUP <= 7) {
-      if (full) w4w_dma_stream<NA>(src, voff, dst0, NW * 1024u);
-      else if constexpr (NA > 1) w4w_dma_stream<(NA > 1 ? NA - 1 : 1)>(src, voff, dst0, NW * 1024u);
+      if (full) w4::dma_stream<NA>(src, voff, dst0, NW * 1024u);
+      else if constexpr (NA > 1) w4::dma_stream<(NA > 1 ? NA - 1 : 1)>(src, voff, dst0, NW * 1024u);
       return full ? NUP : NUP - 1;
     } else {
       static_assert(NUP <= 14, "two calls of up to 7 pieces");
-      w4w_dma_stream<7>(src, voff, dst0, NW * 1024u);
+      w4::dma_stream<7>(src, voff, dst0, NW * 1024u);
       constexpr int NB = NUP - 7;
       const float4* src2 = src + (size_t)(7 * NW) * 64;
       const unsigned dst2 = dst0 + 7u * NW * 1024u;
-      if (full) w4w_dma_stream<NB>(src2, voff, dst2, NW * 1024u);
-      else if constexpr (NB > 1) w4w_dma_stream<(NB > 1 ? NB - 1 : 1)>(src2, voff, dst2, NW * 1024u);
+      if (full) w4::dma_stream<NB>(src2, voff, dst2, NW * 1024u);
+      else if constexpr (NB > 1) w4::dma_stream<(NB > 1 ? NB - 1 : 1)>(src2, voff, dst2, NW * 1024u);
       return full ? NUP : NUP - 1;
     }
   }

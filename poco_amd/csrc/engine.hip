@@ -407,7 +407,8 @@ struct Builder {
             conv_wino4_pack_weights(wp, scale.data(), Cout, Cin, Cout16, pu4.data());
             op.wdev_wino4 = upload(pu4);
           }
-          conv_wino4p_pack_weights(wp, scale.data(), Cout, Cin, Cout16, pu4.data());     // same size, other order
+          pu4.resize(conv_wino4p_packed_floats(Cin, Cout16));                             // other order (+ slack for the streamed requests)
+          conv_wino4p_pack_weights(wp, scale.data(), Cout, Cin, Cout16, pu4.data());
           op.wdev_wino4p = upload(pu4);
           pu4.resize(conv_wino4w_packed_floats(Cin, Cout16));                             // ALG 13: whole-position waves (+ slack)
           conv_wino4w_pack_weights(wp, scale.data(), Cout, Cin, Cout16, pu4.data());
