@@ -44,8 +44,12 @@ using w4::at_c;
 #ifndef W4W_EXP
 #define W4W_EXP 0     // timing probes (results are garbage): 1 no LDS-DMA in the K loop, 2 producers skip transform + window reads, 4 MFMA waves
 #endif                // skip their operand reads, 8 MFMA waves skip the MFMAs
+#ifndef W4W_PF
+#define W4W_PF 4      // operand quads requested ahead of the MFMAs that use them (PF + 1 register sets of 8).  Same box, us per launch on the
+                      // five solo shapes: PF 2 47.5 / 46.8 / 77.5 / 86.7 / 881, PF 4 46.9 / 46.3 / 77.0 / 84.1 / 868, PF 6 48.3 / 47.5 / 78.6 / 87.3 / 890, PF 8 (spills) 52.8 / ...
+#endif
 #ifndef W4W_HOLD
-#define W4W_HOLD 2    // quads of a slice whose MFMAs run behind the slice barrier (see the K loop)
+#define W4W_HOLD 0    // quads of a slice whose MFMAs run behind the slice barrier (see the K loop): 2 is 1-2 % slower than 0 (registers)
 #endif
 #ifndef W4W_LAYOUT
 #define W4W_LAYOUT 1
@@ -323,7 +327,7 @@ __device__ __forceinline__ void w4w_mfma_wave(const W4WParams& pp, float4* smem,
       // right after a barrier every wave of the block asks the LDS for operands at once, and the MFMA pipes used to idle through that
       // round trip (~300 clk of a ~2900-clk slice on every SIMD).  The last slice of an item keeps nothing back (its accumulators go to
       // the epilogue).
-      constexpr int PF = 2, NH = W4W_HOLD;
+      constexpr int PF = W4W_PF, NH = W4W_HOLD;
       float4 ub[PF + 1], vq[PF + 1];
 #pragma unroll
       for (int q = 0; q < PF; ++q) { ub[q] = (W4W_EXP & 4) ? make_float4(1.f, 2.f, (float)s, 3.f) : U[q * 64]; vq[q] = (W4W_EXP & 4) ? make_float4(1.f, 2.f, 3.f, (float)q) : V[q * 64]; }
