@@ -80,6 +80,114 @@ __device__ __forceinline__ void dma_stream(const void* sbase, const unsigned (&v
 }
 #undef W4_DMA1
 
+// N one-KiB GATHER pieces (per-lane byte offsets voff[k] from one wave-uniform base; lanes outside mask[k] - padding positions of a
+// patch - request nothing and leave their LDS slot alone) -> LDS destinations dst0 + k * step, in ONE asm block: per piece
+// s_add_u32 m0 / s_mov_b64 exec / s_nop / global_load_lds_dwordx4 instead of a dma16_sv call inside a compiler-made exec branch.
+// A piece whose mask is empty still issues (a no-op that counts in vmcnt): the caller counts N requests.
+template <int N>
+__device__ __forceinline__ void dma_gather(const void* sbase, const unsigned (&voff)[8], const unsigned long long (&mask)[8], unsigned dst0,
+                                           unsigned step) {
+  static_assert(N >= 1 && N <= 8, "1..8 pieces per call");
+  unsigned keep;
+  unsigned long long sexec;
+  if constexpr (N == 1)
+    asm volatile("s_mov_b32 %[k], m0\n\ts_mov_b64 %[se], exec\n\ts_mov_b32 m0, %[d]\n\t"
+                 "s_mov_b64 exec, %[m0]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[v0], %[b]\n\t"
+                 "s_mov_b64 exec, %[se]\n\ts_mov_b32 m0, %[k]"
+                 : [k] "=&s"(keep), [se] "=&s"(sexec) : [d] "s"(dst0), [st] "s"(step), [b] "s"(sbase), [m0] "s"(mask[0]), [v0] "v"(voff[0]) : "memory", "scc");
+  else if constexpr (N == 2)
+    asm volatile("s_mov_b32 %[k], m0\n\ts_mov_b64 %[se], exec\n\ts_mov_b32 m0, %[d]\n\t"
+                 "s_mov_b64 exec, %[m0]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[v0], %[b]\n\t"
+                 "s_add_u32 m0, m0, %[st]\n\t"
+                 "s_mov_b64 exec, %[m1]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[v1], %[b]\n\t"
+                 "s_mov_b64 exec, %[se]\n\ts_mov_b32 m0, %[k]"
+                 : [k] "=&s"(keep), [se] "=&s"(sexec) : [d] "s"(dst0), [st] "s"(step), [b] "s"(sbase), [m0] "s"(mask[0]), [v0] "v"(voff[0]), [m1] "s"(mask[1]), [v1] "v"(voff[1]) : "memory", "scc");
+  else if constexpr (N == 3)
+    asm volatile("s_mov_b32 %[k], m0\n\ts_mov_b64 %[se], exec\n\ts_mov_b32 m0, %[d]\n\t"
+                 "s_mov_b64 exec, %[m0]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[v0], %[b]\n\t"
+                 "s_add_u32 m0, m0, %[st]\n\t"
+                 "s_mov_b64 exec, %[m1]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[v1], %[b]\n\t"
+                 "s_add_u32 m0, m0, %[st]\n\t"
+                 "s_mov_b64 exec, %[m2]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[v2], %[b]\n\t"
+                 "s_mov_b64 exec, %[se]\n\ts_mov_b32 m0, %[k]"
+                 : [k] "=&s"(keep), [se] "=&s"(sexec) : [d] "s"(dst0), [st] "s"(step), [b] "s"(sbase), [m0] "s"(mask[0]), [v0] "v"(voff[0]), [m1] "s"(mask[1]), [v1] "v"(voff[1]), [m2] "s"(mask[2]), [v2] "v"(voff[2]) : "memory", "scc");
+  else if constexpr (N == 4)
+    asm volatile("s_mov_b32 %[k], m0\n\ts_mov_b64 %[se], exec\n\ts_mov_b32 m0, %[d]\n\t"
+                 "s_mov_b64 exec, %[m0]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[v0], %[b]\n\t"
+                 "s_add_u32 m0, m0, %[st]\n\t"
+                 "s_mov_b64 exec, %[m1]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[v1], %[b]\n\t"
+                 "s_add_u32 m0, m0, %[st]\n\t"
+                 "s_mov_b64 exec, %[m2]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[v2], %[b]\n\t"
+                 "s_add_u32 m0, m0, %[st]\n\t"
+                 "s_mov_b64 exec, %[m3]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[v3], %[b]\n\t"
+                 "s_mov_b64 exec, %[se]\n\ts_mov_b32 m0, %[k]"
+                 : [k] "=&s"(keep), [se] "=&s"(sexec) : [d] "s"(dst0), [st] "s"(step), [b] "s"(sbase), [m0] "s"(mask[0]), [v0] "v"(voff[0]), [m1] "s"(mask[1]), [v1] "v"(voff[1]), [m2] "s"(mask[2]), [v2] "v"(voff[2]), [m3] "s"(mask[3]), [v3] "v"(voff[3]) : "memory", "scc");
+  else if constexpr (N == 5)
+    asm volatile("s_mov_b32 %[k], m0\n\ts_mov_b64 %[se], exec\n\ts_mov_b32 m0, %[d]\n\t"
+                 "s_mov_b64 exec, %[m0]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[v0], %[b]\n\t"
+                 "s_add_u32 m0, m0, %[st]\n\t"
+                 "s_mov_b64 exec, %[m1]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[v1], %[b]\n\t"
+                 "s_add_u32 m0, m0, %[st]\n\t"
+                 "s_mov_b64 exec, %[m2]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[v2], %[b]\n\t"
+                 "s_add_u32 m0, m0, %[st]\n\t"
+                 "s_mov_b64 exec, %[m3]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[v3], %[b]\n\t"
+                 "s_add_u32 m0, m0, %[st]\n\t"
+                 "s_mov_b64 exec, %[m4]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[v4], %[b]\n\t"
+                 "s_mov_b64 exec, %[se]\n\ts_mov_b32 m0, %[k]"
+                 : [k] "=&s"(keep), [se] "=&s"(sexec) : [d] "s"(dst0), [st] "s"(step), [b] "s"(sbase), [m0] "s"(mask[0]), [v0] "v"(voff[0]), [m1] "s"(mask[1]), [v1] "v"(voff[1]), [m2] "s"(mask[2]), [v2] "v"(voff[2]), [m3] "s"(mask[3]), [v3] "v"(voff[3]), [m4] "s"(mask[4]), [v4] "v"(voff[4]) : "memory", "scc");
+  else if constexpr (N == 6)
+    asm volatile("s_mov_b32 %[k], m0\n\ts_mov_b64 %[se], exec\n\ts_mov_b32 m0, %[d]\n\t"
+                 "s_mov_b64 exec, %[m0]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[v0], %[b]\n\t"
+                 "s_add_u32 m0, m0, %[st]\n\t"
+                 "s_mov_b64 exec, %[m1]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[v1], %[b]\n\t"
+                 "s_add_u32 m0, m0, %[st]\n\t"
+                 "s_mov_b64 exec, %[m2]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[v2], %[b]\n\t"
+                 "s_add_u32 m0, m0, %[st]\n\t"
+                 "s_mov_b64 exec, %[m3]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[v3], %[b]\n\t"
+                 "s_add_u32 m0, m0, %[st]\n\t"
+                 "s_mov_b64 exec, %[m4]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[v4], %[b]\n\t"
+                 "s_add_u32 m0, m0, %[st]\n\t"
+                 "s_mov_b64 exec, %[m5]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[v5], %[b]\n\t"
+                 "s_mov_b64 exec, %[se]\n\ts_mov_b32 m0, %[k]"
+                 : [k] "=&s"(keep), [se] "=&s"(sexec) : [d] "s"(dst0), [st] "s"(step), [b] "s"(sbase), [m0] "s"(mask[0]), [v0] "v"(voff[0]), [m1] "s"(mask[1]), [v1] "v"(voff[1]), [m2] "s"(mask[2]), [v2] "v"(voff[2]), [m3] "s"(mask[3]), [v3] "v"(voff[3]), [m4] "s"(mask[4]), [v4] "v"(voff[4]), [m5] "s"(mask[5]), [v5] "v"(voff[5]) : "memory", "scc");
+  else if constexpr (N == 7)
+    asm volatile("s_mov_b32 %[k], m0\n\ts_mov_b64 %[se], exec\n\ts_mov_b32 m0, %[d]\n\t"
+                 "s_mov_b64 exec, %[m0]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[v0], %[b]\n\t"
+                 "s_add_u32 m0, m0, %[st]\n\t"
+                 "s_mov_b64 exec, %[m1]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[v1], %[b]\n\t"
+                 "s_add_u32 m0, m0, %[st]\n\t"
+                 "s_mov_b64 exec, %[m2]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[v2], %[b]\n\t"
+                 "s_add_u32 m0, m0, %[st]\n\t"
+                 "s_mov_b64 exec, %[m3]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[v3], %[b]\n\t"
+                 "s_add_u32 m0, m0, %[st]\n\t"
+                 "s_mov_b64 exec, %[m4]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[v4], %[b]\n\t"
+                 "s_add_u32 m0, m0, %[st]\n\t"
+                 "s_mov_b64 exec, %[m5]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[v5], %[b]\n\t"
+                 "s_add_u32 m0, m0, %[st]\n\t"
+                 "s_mov_b64 exec, %[m6]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[v6], %[b]\n\t"
+                 "s_mov_b64 exec, %[se]\n\ts_mov_b32 m0, %[k]"
+                 : [k] "=&s"(keep), [se] "=&s"(sexec) : [d] "s"(dst0), [st] "s"(step), [b] "s"(sbase), [m0] "s"(mask[0]), [v0] "v"(voff[0]), [m1] "s"(mask[1]), [v1] "v"(voff[1]), [m2] "s"(mask[2]), [v2] "v"(voff[2]), [m3] "s"(mask[3]), [v3] "v"(voff[3]), [m4] "s"(mask[4]), [v4] "v"(voff[4]), [m5] "s"(mask[5]), [v5] "v"(voff[5]), [m6] "s"(mask[6]), [v6] "v"(voff[6]) : "memory", "scc");
+  else if constexpr (N == 8)
+    asm volatile("s_mov_b32 %[k], m0\n\ts_mov_b64 %[se], exec\n\ts_mov_b32 m0, %[d]\n\t"
+                 "s_mov_b64 exec, %[m0]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[v0], %[b]\n\t"
+                 "s_add_u32 m0, m0, %[st]\n\t"
+                 "s_mov_b64 exec, %[m1]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[v1], %[b]\n\t"
+                 "s_add_u32 m0, m0, %[st]\n\t"
+                 "s_mov_b64 exec, %[m2]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[v2], %[b]\n\t"
+                 "s_add_u32 m0, m0, %[st]\n\t"
+                 "s_mov_b64 exec, %[m3]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[v3], %[b]\n\t"
+                 "s_add_u32 m0, m0, %[st]\n\t"
+                 "s_mov_b64 exec, %[m4]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[v4], %[b]\n\t"
+                 "s_add_u32 m0, m0, %[st]\n\t"
+                 "s_mov_b64 exec, %[m5]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[v5], %[b]\n\t"
+                 "s_add_u32 m0, m0, %[st]\n\t"
+                 "s_mov_b64 exec, %[m6]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[v6], %[b]\n\t"
+                 "s_add_u32 m0, m0, %[st]\n\t"
+                 "s_mov_b64 exec, %[m7]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[v7], %[b]\n\t"
+                 "s_mov_b64 exec, %[se]\n\ts_mov_b32 m0, %[k]"
+                 : [k] "=&s"(keep), [se] "=&s"(sexec) : [d] "s"(dst0), [st] "s"(step), [b] "s"(sbase), [m0] "s"(mask[0]), [v0] "v"(voff[0]), [m1] "s"(mask[1]), [v1] "v"(voff[1]), [m2] "s"(mask[2]), [v2] "v"(voff[2]), [m3] "s"(mask[3]), [v3] "v"(voff[3]), [m4] "s"(mask[4]), [v4] "v"(voff[4]), [m5] "s"(mask[5]), [v5] "v"(voff[5]), [m6] "s"(mask[6]), [v6] "v"(voff[6]), [m7] "s"(mask[7]), [v7] "v"(voff[7]) : "memory", "scc");
+}
+
 // slab / patch geometry of a (R, NI) configuration: slabs of R output rows (a multiple of 4) x the full width, NI whole
 // images per block when R covers the plane; patch positions live in skewed float4 slots pos + pos/8
 struct Geo { int R, NI, nbands, S, TX, PR, PW, npos, rawF4, tps; };

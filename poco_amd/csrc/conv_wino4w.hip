@@ -38,12 +38,21 @@ using w4::at_c;
 #include "conv_wino4p_geo.h"
 
 #ifndef W4W_DMAW
-#define W4W_DMAW 6    // who requests the LDS-DMA of the coming slices (see W4WDuty)
+#define W4W_DMAW 9    // who requests the LDS-DMA of the coming slices (see W4WDuty)
 #endif
 
 #ifndef W4W_EXP
 #define W4W_EXP 0     // timing probes (results are garbage): 1 no LDS-DMA in the K loop, 2 producers skip transform + window reads, 4 MFMA waves
 #endif                // skip their operand reads, 8 MFMA waves skip the MFMAs
+#ifndef W4W_DMALAST
+#define W4W_DMALAST 0     // (1: 72.5 vs 71.6 us on 14x14 192->192, 855 vs 803 on 480->128 - the requests need their two slices to land)
+#endif
+#ifndef W4W_WIN2
+#define W4W_WIN2 0
+#endif
+#ifndef W4W_GATHER
+#define W4W_GATHER 1  // raw pieces requested as one exec-masked asm block per issuer (w4::dma_gather); 0 = one dma16_sv per piece
+#endif
 #ifndef W4W_PF
 #define W4W_PF 4      // operand quads requested ahead of the MFMAs that use them (PF + 1 register sets of 8).  Same box, us per launch on the
                       // five solo shapes: PF 2 47.5 / 46.8 / 77.5 / 86.7 / 881, PF 4 46.9 / 46.3 / 77.0 / 84.1 / 868, PF 6 48.3 / 47.5 / 78.6 / 87.3 / 890, PF 8 (spills) 52.8 / ...
@@ -143,6 +152,9 @@ __device__ __forceinline__ int w4w_item_id(const W4WParams& p, int it, int* ngro
 //   6      producers                 all MFMA
 //   7      producers                 producers
 //   8      all MFMA                  producers
+//   9      NT = 3: mode 7 (the producers request everything: they own SIMD 3 in layout 1 and the three MFMA SIMDs do nothing but MFMAs and
+//          operand reads - 14x14 192->192 76.8 -> 71.3 us, 28x28 96->96 46.4 -> 44.5, 480->128 882 -> 807); NT < 3: mode 6 (the producers
+//          share their SIMDs with MFMA waves there: 56x56 64->64 83.7 us against 99.7 with mode 7)
 struct W4WPlan { int mu0, nmu, kpu, mr0, nmr, kpr; };
 template <int NT> constexpr W4WPlan w4w_plan() {
   constexpr int M = 2 * NT;
@@ -150,6 +162,7 @@ template <int NT> constexpr W4WPlan w4w_plan() {
   if (W4W_DMAW == 6) return {0, 0, 1, 0, M, 0};
   if (W4W_DMAW == 7) return {0, 0, 1, 0, 0, 1};
   if (W4W_DMAW == 8) return {0, M, 0, 0, 0, 1};
+  if (W4W_DMAW == 9) return NT == 3 ? W4WPlan{0, 0, 1, 0, 0, 1} : W4WPlan{0, 0, 1, 0, M, 0};      // shipped: see the table above
   if (NT == 1) return {0, 2, 1, 0, 2, 1};
   return {2, 2, 1, 2, 2, 1};
 }
@@ -165,6 +178,16 @@ template <int NT> __device__ __forceinline__ int w4w_mfma_index(int wave) {
   return wave;
 }
 
+// np (wave-uniform, 0 .. MAXN) gather pieces
+template <int MAXN>
+__device__ __forceinline__ void w4w_gather_n(int np, const void* sbase, const unsigned (&voff)[8], const unsigned long long (&mask)[8], unsigned dst0,
+                                             unsigned step) {
+  if constexpr (MAXN >= 1) {
+    if (np == MAXN) w4::dma_gather<MAXN>(sbase, voff, mask, dst0, step);
+    else w4w_gather_n<MAXN - 1>(np, sbase, voff, mask, dst0, step);
+  }
+}
+
 template <int NT, int FLAT>
 struct W4WDuty {
   static constexpr int NWU = w4w_nwu<NT>(), NWR = w4w_nwr<NT>();
@@ -172,6 +195,7 @@ struct W4WDuty {
   static constexpr int NUP = (9 * NT + NWU - 1) / NWU;                 // U pieces per U issuer and slice
   int goff[MAXP];
   bool live[MAXP];
+  unsigned long long lmask[MAXP];                                       // lanes of a piece that carry an in-image position
   int dwu, dwr;                                                         // this wave's index among the U / raw issuers, -1 = none (wave-uniform)
   // the patch of item `it`: global float offsets of this issuer's raw pieces (lane = slot inside the piece), -1 = padding
   __device__ __forceinline__ void setup(const W4WParams& pp, int it, int lane) {
@@ -180,7 +204,7 @@ struct W4WDuty {
     const int id = w4w_item_id(pp, it, &ng);
     raw_piece_offsets<MAXP, FLAT>(pp.g, id, dwr, NWR, lane, goff);
 #pragma unroll
-    for (int k = 0; k < MAXP; ++k) live[k] = __ballot(goff[k] >= 0) != 0ull;
+    for (int k = 0; k < MAXP; ++k) { lmask[k] = __ballot(goff[k] >= 0); live[k] = lmask[k] != 0ull; }
   }
   // 4-channel slice c4 of the patch -> raw ring slot; zero = also clear the padding lanes of the slot (first use by this item)
   __device__ __forceinline__ int issue_raw(const W4PParams& p, float4* smem, int lane, int c4, int slot, bool zero) const {
@@ -192,20 +216,41 @@ struct W4WDuty {
     const float* sbase = p.in + (size_t)(c4 >> 2) * p.in_ss + (c4 & 3) * 4;
     const unsigned sb = lds_base + (unsigned)(slot * p.rawF4) * 16u;
     const int npieces_raw = p.rawF4 >> 6;
+    if (zero) {
 #pragma unroll
-    for (int k = 0; k < MAXP; ++k) {
-      const int piece = dw + NW * k;
-      if (piece < npieces_raw) {
-        if (zero && goff[k] < 0) {
+      for (int k = 0; k < MAXP; ++k) {
+        const int piece = dw + NW * k;
+        if (piece < npieces_raw && goff[k] < 0) {
           float4 zz = make_float4(0.f, 0.f, 0.f, 0.f);
           asm volatile("" : "+v"(zz.x), "+v"(zz.y), "+v"(zz.z), "+v"(zz.w));      // (materialised here: hipcc kept one zero vector live across the K loop and spilled it)
           smem[slot * p.rawF4 + piece * 64 + lane] = zz;
         }
-        if (live[k]) {
-          if (goff[k] >= 0)
-            w4::dma16_sv(sbase, (unsigned)goff[k] * 4u, (unsigned)__builtin_amdgcn_readfirstlane((int)(sb + (unsigned)piece * 1024u)));
-          ++cnt;
-        }
+      }
+    }
+    if constexpr (W4W_GATHER != 0 && w4w_plan<NT>().nmr == 0) {
+      // (only where the producers alone request the patch: on the MFMA waves the always-issued empty pieces and exec switches cost
+      // more than the per-piece branches - 48.8 vs 47.4 us)
+      // all of this issuer's pieces in one (two) asm block(s); the number of pieces dw, dw + NW, ... < npieces_raw is wave-uniform
+      static_assert(MAXP <= 8, "at most 8 raw pieces per issuer");
+      unsigned voff[8];
+      unsigned long long mask[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        voff[k] = k < MAXP ? (unsigned)goff[k] * 4u : 0u;
+        mask[k] = k < MAXP ? lmask[k] : 0ull;
+      }
+      const int np = dw < npieces_raw ? (npieces_raw - 1 - dw) / NW + 1 : 0;            // pieces of this issuer
+      const unsigned dst0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(sb + (unsigned)dw * 1024u));
+      w4w_gather_n<MAXP>(np, sbase, voff, mask, dst0, NW * 1024u);
+      return np;
+    }
+#pragma unroll
+    for (int k = 0; k < MAXP; ++k) {
+      const int piece = dw + NW * k;
+      if (piece < npieces_raw && live[k]) {
+        if (goff[k] >= 0)
+          w4::dma16_sv(sbase, (unsigned)goff[k] * 4u, (unsigned)__builtin_amdgcn_readfirstlane((int)(sb + (unsigned)piece * 1024u)));
+        ++cnt;
       }
     }
     return cnt;
@@ -479,9 +524,14 @@ __device__ __forceinline__ void w4w_producer(const W4WParams& pp, float4* smem, 
         w.woff[k][c] = (pos + (pos >> (FLAT ? 4 : 3))) * 4 + g;
       }
   };
-  // (Tried: TWO window register sets, the window of slice t + 2 requested at the top of slice t ahead of the transform of window
+  // W4W_WIN2 = 1: TWO window register sets used alternately (by the parity of the global slice: no copies) - the window of slice t + 2 is
+  // requested at the top of slice t and its latency hides behind the transform of window t + 1.
+  // (Tried in the first layout: TWO window register sets, the window of slice t + 2 requested at the top of slice t ahead of the transform of window
   // t + 1 - 3-7 % slower per launch: the 15 reads then queue in front of the MFMA waves' first operand reads of the slice.)
   f32x2 dA[6][3];
+#if W4W_WIN2
+  f32x2 dB[6][3];
+#endif
   auto load_window = [&](f32x2 (&d)[6][3], const Win& w, int rslot) __attribute__((always_inline)) {
     const float* rawf = reinterpret_cast<const float*>(smem + rslot * rawF4);
 #pragma unroll
@@ -562,14 +612,31 @@ __device__ __forceinline__ void w4w_producer(const W4WParams& pp, float4* smem, 
       W4W_T(q0);
       const int r1 = ring == 2 ? 0 : ring + 1, r2 = r1 == 2 ? 0 : r1 + 1;
       int nvm = 0;
-      if constexpr (kIssue) { if (!(W4W_EXP & 1)) nvm = duty.slice_requests(pp, smem, lane, it + wk.step, hasB, s, r1, r2, ngA * NT, ngB * NT); }
+      if constexpr (kIssue && !W4W_DMALAST) { if (!(W4W_EXP & 1)) nvm = duty.slice_requests(pp, smem, lane, it + wk.step, hasB, s, r1, r2, ngA * NT, ngB * NT); }
       // V(t + 1) from the window fetched during the previous slice, then the window of slice t + 2 (raw(t + 2) landed before the
       // barrier that ended slice t - 1) - of this item or of the next one
       if (!(W4W_EXP & 2)) {
+#if W4W_WIN2
+      auto step = [&](f32x2 (&cur)[6][3], f32x2 (&nxt)[6][3]) __attribute__((always_inline)) {
+        if (s + 2 < S) load_window(nxt, A, r2);
+        else if (hasB) load_window(nxt, B, r2);
+        __builtin_amdgcn_sched_barrier(0);
+        if (s + 1 < S || hasB) transform(cur, vb ^ 1);
+      };
+      if (vb) step(dB, dA); else step(dA, dB);
+      W4W_T(q1);
+#else
       if (s + 1 < S || hasB) transform(dA, vb ^ 1);
       W4W_T(q1);
       if (s + 2 < S) load_window(dA, A, r2);
       else if (hasB) load_window(dA, B, r2);
+#endif
+      }
+      // W4W_DMALAST: the requests of the coming slices go out behind the window reads, whose latency (~650 clk under the MFMA waves'
+      // operand traffic) they cover - U(t + 2) / raw(t + 4) have two slices to land either way
+      if constexpr (kIssue && W4W_DMALAST) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(W4W_EXP & 1)) nvm = duty.slice_requests(pp, smem, lane, it + wk.step, hasB, s, r1, r2, ngA * NT, ngB * NT);
       }
       if (kIssue) w4w_wait_vm(nvm);                       // what this wave requested BEFORE this slice has landed
       ring = r1;

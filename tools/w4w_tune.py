@@ -87,6 +87,11 @@ if "--write" in sys.argv and picked and final < base * 0.998:
         x = torch.randn(B, H, W, Cin, device=dev)
         w = (np.random.default_rng(0).standard_normal((Cout, Cin, 3, 3)) / np.sqrt(9 * Cin)).astype(np.float32)
         ms, tf, _ = ops.bench_conv2d(x, w, 1, cfg=c, iters=30)
+        if k in full and full[k].get("uses", 0) > len(shapes[k]) and "--force" not in sys.argv:
+            # the table is keyed by shape only: a variant that launches this shape once must not re-pick the entry of a variant that
+            # launches it 64 times (round 5: the W48 pass at 32 crops moved 32x56x56x32x32 and cost PARE 9 % at its bench batch)
+            print(f"  kept {k} (used {full[k]['uses']} x by another variant, {len(shapes[k])} x here)")
+            continue
         ent = full.setdefault(k, {"heuristic_ms": 0.0, "uses": len(shapes[k])})
         ent.update({"cfg": list(c), "ms": round(float(ms), 5), "tflops": round(float(tf), 1), "in_context": True, "uses": len(shapes[k])})
     tune.TABLE.write_text(json.dumps(full, indent=0, sort_keys=True))
