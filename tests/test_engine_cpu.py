@@ -303,3 +303,30 @@ def test_shipped_library_contains_no_experiments():
     assert b"gemm1x1h" not in blob and b"split_f16" not in blob
     with pytest.raises(_lib.PocoHipError, match="split_f16"):
         POCO(backbone="resnet50-cliff", num_flow_layers=1, max_batch=1, engine_options={"split_f16": 1})
+
+
+def test_apply_table_prefers_the_larger_neighbour_and_keeps_split_k_convs_small(monkeypatch):
+    """without an entry for B the nearest tuned batch (log space) is used, ties to the LARGER one; an ALG 5 split-K 3x3
+    entry (tuned at 1 / 4 crops, re-streams all weights per 64-pixel block) is only transferred to batch sizes up to its own."""
+    from poco_amd import tune
+    m = POCO(backbone="hrnet_w48_cls-cliff", num_flow_layers=1, max_batch=1)      # declarations only
+    convs = [i for i, _ in enumerate(m.ops()) if m.conv_desc(i) is not None]
+    i3 = next(i for i in convs if m.conv_desc(i)[4] == 3 and m.conv_desc(i)[5] == 1 and m.conv_desc(i)[0] == 14)     # a 14x14 3x3 stride-1 conv
+    H, W, Cin, Cout, ks, st = m.conv_desc(i3)[:6]
+    small = [1, 2, 4, 2, 14, 1, 4]
+    big = [2, 3, 2, 1, 16, 2, 13]
+    table = {tune.shape_key(4, H, W, Cin, Cout, ks, st): small, tune.shape_key(16, H, W, Cin, Cout, ks, st): big}
+    def active(B):                                                    # (m.conv_cfg would re-apply the shipped table first)
+        c = (C.c_int * 7)()
+        assert m._L.poco_get_conv_cfg(m._h, i3, B, c) == 0
+        return list(c)
+    tune.apply_table(m, 8, table)                                     # 8 is as far from 4 as from 16 in log space
+    assert active(8) == big
+    splitk = [1, 1, 4, 1, 1, 1, 5]
+    table = {tune.shape_key(4, H, W, Cin, Cout, ks, st): splitk}
+    before = active(6)
+    tune.apply_table(m, 6, table)                                     # 6 > 4: the split-K entry does not travel upwards ...
+    assert active(6) == before
+    before3 = active(3)
+    tune.apply_table(m, 3, table)                                     # ... but downwards it does (if the library accepts it for the op)
+    assert active(3) in (splitk, before3)
