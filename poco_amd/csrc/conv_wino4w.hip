@@ -44,9 +44,6 @@ using w4::at_c;
 #ifndef W4W_EXP
 #define W4W_EXP 0     // timing probes (results are garbage): 1 no LDS-DMA in the K loop, 2 producers skip transform + window reads, 4 MFMA waves
 #endif                // skip their operand reads, 8 MFMA waves skip the MFMAs
-#ifndef W4W_LATEU1
-#define W4W_LATEU1 0      // (1: 14x14 192->192 solo 71.0 -> 70.0 us, but the 4-lane forward +0.3 % in two same-box rounds: not kept)
-#endif
 #ifndef W4W_DMALAST
 #define W4W_DMALAST 0     // (1: 72.5 vs 71.6 us on 14x14 192->192, 855 vs 803 on 480->128 - the requests need their two slices to land)
 #endif
@@ -300,12 +297,8 @@ struct W4WDuty {
     int ng0;
     (void)w4w_item_id(pp, it0, &ng0);
     issue_u(p, smem, lane, ng0 * NT, 0, 0);
-    // U(1) is not needed before slice 1: it stays in flight across P0 / P1 (the cold start of a launch is a burst of ~96 KB per CU from
-    // L2 / HBM, and only the first 69 KB gate the first MFMA); this issuer's wait at the end of slice 0 covers it
-    int late = 0;
-    if (p.nC4 > 1) late = issue_u(p, smem, lane, ng0 * NT, 1, 1);
-    if (W4W_LATEU1) w4w_wait_vm(late);
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (p.nC4 > 1) issue_u(p, smem, lane, ng0 * NT, 1, 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
   // global slice t = (item it, slice s): U(t + 2) -> slot r2 (of U(t - 1)); raw(t + 4) -> slot r1 (of raw(t + 1), whose window was read
   // during slice t - 1) - of this item or of the next one, whose patch takes over at s = S - 4.  Returns the number of requests.
