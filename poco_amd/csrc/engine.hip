@@ -38,7 +38,7 @@ struct ParamDecl {
 
 enum OpType {
   OP_STEM, OP_CONV, OP_MAXPOOL, OP_BILINEAR, OP_FUSE, OP_AVGPOOL, OP_ATTN, OP_LC2D, OP_ROT6D, OP_COPY,
-  OP_BCAST, OP_SMPL, OP_CAMERA, OP_NCHW_OUT, OP_CHAIN, OP_DUAL1X1, OP_RECORD
+  OP_BCAST, OP_SMPL, OP_CAMERA, OP_NCHW_OUT, OP_CHAIN, OP_DUAL1X1, OP_RECORD, OP_MLP
 };
 
 // external buffer slots (inputs / outputs of poco_forward)
@@ -89,6 +89,10 @@ struct Op {
   // misc ints
   int n = 0, C = 0;
   std::map<int, ConvCfg> cfg;   // per batch size
+  // OP_MLP (mlp_chain.hip): the Linear layers (OP_CONV), row copies / broadcasts (OP_COPY / OP_BCAST) and rot6d (OP_ROT6D) of the
+  // regressor chain as sub-ops in stage order; `stage` = the sub-op's stage
+  std::vector<Op> sub;
+  int stage = 0;
 };
 
 // Build options (poco_create_ex): the A/B forms of the schedule and of the fused ops.  Every form computes the same model (tests
@@ -102,6 +106,8 @@ struct EngineOpts {
   bool tail_lanes = true;  // SMPL-LBS + camera | output copies + confidence MLP on two lanes (PARE: the two head branches too)
   bool up_lanes = true;    // PARE: the three upsample chains continue on their branches' lanes
   bool wg_fuse = true;     // ALG 11: consecutive convs of a lane chained through wg_mid_kernel
+  bool mlp_fuse = true;    // CLIFF regressor (fc1 / fc2 / decoders x 3 iterations, state scatter, rot6d) as one persistent launch (mlp_chain.hip)
+  int mlp_blocks = 256;    // ... on at most this many blocks (one grid barrier per stage: fewer blocks = cheaper barriers, more = more jobs at once)
   bool split_f16 = false;  // EXPERIMENT (never the default): plain 1x1 convs on the split-fp16 GEMM (gemm1x1h.hip)
   int seq_mask = 0;        // bit mask: run the tagged kind of parallel region on one lane
   std::string branch_lanes = "0123";   // HR branch i runs on lane branch_lanes[i]
@@ -132,6 +138,8 @@ static bool parse_opts(const char* str, EngineOpts* o, std::string* err) {
     else if (k == "tail_lanes") o->tail_lanes = on;
     else if (k == "up_lanes") o->up_lanes = on;
     else if (k == "wg_fuse") o->wg_fuse = on;
+    else if (k == "mlp_fuse") o->mlp_fuse = on;
+    else if (k == "mlp_blocks") o->mlp_blocks = std::min(256, std::max(1, atoi(v.c_str())));
 #if POCO_EXPERIMENTS
     else if (k == "split_f16") o->split_f16 = on;
 #endif
@@ -181,6 +189,8 @@ struct Engine {
   float* flow_scratch = nullptr;          // step A of the flow (context GEMM): planned at finalize for opts.flow_ctx_rows context rows
   size_t flow_scratch_floats = 0;
   int uncert_feat_dim = 0;
+  unsigned* mlp_sync = nullptr;       // OP_MLP: grid-barrier counters (device) ...
+  unsigned* mlp_err_host = nullptr;   // ... and the sticky time-out word (pinned host memory the kernel can write)
   std::string err;
 
   ~Engine() {
@@ -193,6 +203,8 @@ struct Engine {
     for (void* p : dev_allocs) (void)hipFree(p);
     if (ws) (void)hipFree(ws);
     if (flow_scratch) (void)hipFree(flow_scratch);
+    if (mlp_sync) (void)hipFree(mlp_sync);
+    if (mlp_err_host) (void)hipHostFree(mlp_err_host);
     for (float* q : wino4g_scratch) if (q) (void)hipFree(q);
   }
 };
@@ -217,6 +229,7 @@ static void op_accesses(const Engine& e, const Op& op, std::vector<OpAccess>* rd
   if (op.type == OP_SMPL || op.type == OP_CAMERA || op.type == OP_RECORD) { add(rd, e.smpl_betas, ALL); add(rd, e.smpl_rot, ALL); add(rd, e.cam_ref, ALL); }   // implicit operands
   add(wr, op.out, conv ? op.Cout : (op.type == OP_FUSE ? op.C : ALL));
   add(wr, op.out2, ALL);
+  for (const Op& su : op.sub) op_accesses(e, su, rd, wr);
 }
 
 struct Builder {
@@ -295,7 +308,10 @@ struct Builder {
   }
   void end_parallel() { in_parallel = false; }
   void lane(int k) { cur_lane = region_seq ? 0 : k % 4; }
+  std::vector<Op>* capture = nullptr;   // OP_MLP under construction: ops are collected as its sub-ops instead of entering the program
+  int cur_stage = 0;
   void push(Op&& op) {
+    if (capture) { op.stage = cur_stage; capture->push_back(std::move(op)); return; }
     if (!in_parallel) { ++cur_phase; cur_lane = 0; }
     op.phase = cur_phase;
     op.lane = cur_lane;
@@ -1085,6 +1101,14 @@ bool build_graph(Engine& e, bool declare) {
     const HostParam* ip = b.P(hp + "init_pose", {1, 144});
     const HostParam* is = b.P(hp + "init_shape", {1, 10});
     const HostParam* ic = b.P(hp + "init_cam", {1, 3});
+    // mlp_fuse: everything from here to rot6d is collected as the sub-ops of ONE persistent launch (OP_MLP, mlp_chain.hip);
+    // `cur_stage` numbers the stages (a grid barrier in between): 0 = state / bbox rows, fc1's feature part, the confidence
+    // 1 + 3 it ... 3 + 3 it = fc1.state / fc2 / decoders of iteration it, 10 = rot6d and the copies that scatter the final state
+    // into the outputs.  The confidence branch's featNet and the uncert_feat copy read only the pooled feature: they ride with the
+    // decoder stages 3 and 6, which have 10 x B/16 tile jobs for the grid
+    const bool fuse = e.opts.mlp_fuse;
+    std::vector<Op> mlp_sub;
+    if (fuse) { b.capture = &mlp_sub; b.cur_stage = 0; }
     Op bc; bc.type = OP_BCAST; bc.name = hp + "init_state"; bc.out = Builder::R(xc, XC_STATE); bc.n = 157;
     if (!declare && ip && is && ic) {
       std::vector<float> st(ip->data);
@@ -1122,38 +1146,59 @@ bool build_graph(Engine& e, bool declare) {
     for (int k = 2048; k < 2208; ++k) perm_state[k] = perm[k] - 2048;
     int h0 = b.conv(hp + "fc1.feat", hp + "fc1", "", Builder::R(xc, 0), 2208, 1024, 1, 1, 0, true, Ref(), 0, Ref(),
                     &perm_feat, 2048, true);
-    e.ops.back().flops = 2.0 * 1024 * 2048;
+    (fuse ? mlp_sub : e.ops).back().flops = 2.0 * 1024 * 2048;
+    const int u = b.new_act(448, 1, 1, true);       // [sigmoid(featNet(feat)) 216 | pad | sigmoid(poseNet(R)) 216 | pad] (poco_head.py:122-141)
+    if (fuse) {
+      b.cur_stage = 3;
+      b.conv(up + "uncert_fc_featNet", up + "uncert_fc_featNet", "", Builder::R(xc, 0), 2048, 216, 1, 1, 2, true, Ref(), 0,
+             Builder::R(u, 0), nullptr, 0, true);
+      b.cur_stage = 6;
+      add_copy(b, "out.uncert_feat", Builder::R(xc, 0), Builder::X(Y_UFEAT), 2048);
+    }
     int h2 = -1;
     for (int it = 0; it < 3; ++it) {
       const std::string sfx = "#" + std::to_string(it);
+      b.cur_stage = 1 + 3 * it;
       int h1 = b.conv(hp + "fc1.state" + sfx, hp + "fc1", "", Builder::R(xc, 2048), 2208, 1024, 1, 1, 0, false, Builder::R(h0), 0,
                       Ref(), &perm_state, XC_DIM - 2048, true);
-      e.ops.back().flops = 2.0 * 1024 * 160;
+      (fuse ? mlp_sub : e.ops).back().flops = 2.0 * 1024 * 160;
+      b.cur_stage = 2 + 3 * it;
       h2 = b.conv(hp + "fc2" + sfx, hp + "fc2", "", Builder::R(h1), 1024, 1024, 1, 1, 0, true, Ref(), 0, Ref(),
                   nullptr, 0, true);
       // fused decoder: state += dec(h2)  (in place on the state slice of xc)
+      b.cur_stage = 3 + 3 * it;
       b.conv(hp + "dec" + sfx, "", "", Builder::R(h2), 1024, 157, 1, 1, 0, true, Builder::R(xc, XC_STATE), 0,
              Builder::R(xc, XC_STATE), nullptr, 0, true, true, have_dec ? &decW : nullptr, have_dec ? &decB : nullptr);
     }
     int rot = b.new_act(224, 1, 1, true);
+    b.cur_stage = 10;
     { Op op; op.type = OP_ROT6D; op.name = hp + "rot6d"; op.in = Builder::R(xc, XC_STATE); op.out = Builder::R(rot);
       op.out2 = Builder::X(Y_POSE); b.push(std::move(op)); }
     // the tail is two independent chains of small kernels: SMPL-LBS + camera on one lane, the output copies and the confidence
     // MLP on another (POCO_NO_TAIL_LANES=1: one stream)
-    if (b.tail_lanes) { b.begin_parallel(9); b.lane(1); }
+    if (!fuse && b.tail_lanes) { b.begin_parallel(9); b.lane(1); }
     add_copy(b, "out.pred_pose6d", Builder::R(xc, XC_STATE), Builder::X(Y_POSE6D), 144);
     add_copy(b, "out.pred_shape", Builder::R(xc, XC_STATE + 144), Builder::X(Y_SHAPE), 10);
     add_copy(b, "out.pred_cam", Builder::R(xc, XC_STATE + 154), Builder::X(Y_CAM), 3);
-    add_copy(b, "out.uncert_feat", Builder::R(xc, 0), Builder::X(Y_UFEAT), 2048);
+    if (!fuse) add_copy(b, "out.uncert_feat", Builder::R(xc, 0), Builder::X(Y_UFEAT), 2048);
     add_copy(b, "out.body_feat2", Builder::R(h2), Builder::X(Y_BODY2), 1024);
     e.uncert_feat_dim = 2048;
+    if (fuse) {
+      b.capture = nullptr;
+      Op op; op.type = OP_MLP; op.name = hp + "regressor";
+      for (const Op& su : mlp_sub) op.flops += su.flops;
+      std::stable_sort(mlp_sub.begin(), mlp_sub.end(), [](const Op& x, const Op& y) { return x.stage < y.stage; });
+      op.sub = std::move(mlp_sub);
+      b.push(std::move(op));
+      if (b.tail_lanes) b.begin_parallel(9);
+    }
     if (b.tail_lanes) b.lane(0);
     build_tail(b, Builder::R(xc, XC_STATE + 144), Builder::R(rot), Builder::R(xc, XC_STATE + 154), true);
     if (b.tail_lanes) b.lane(1);
     // poco_head 'feat-pose-net' (poco_head.py:122-141): sigmoid(featNet(feat)) || sigmoid(poseNet(R)) -> fc1 -> sigmoid
-    int u = b.new_act(448, 1, 1, true);
-    b.conv(up + "uncert_fc_featNet", up + "uncert_fc_featNet", "", Builder::R(xc, 0), 2048, 216, 1, 1, 2, true, Ref(), 0,
-           Builder::R(u, 0), nullptr, 0, true);
+    if (!fuse)
+      b.conv(up + "uncert_fc_featNet", up + "uncert_fc_featNet", "", Builder::R(xc, 0), 2048, 216, 1, 1, 2, true, Ref(), 0,
+             Builder::R(u, 0), nullptr, 0, true);
     b.conv(up + "uncert_fc_poseNet", up + "uncert_fc_poseNet", "", Builder::R(rot), 216, 216, 1, 1, 2, true, Ref(), 0,
            Builder::R(u, 216), nullptr, 224, true);
     int var = b.conv(up + "uncert_fc1", up + "uncert_fc1", "", Builder::R(u), 432, 24, 1, 1, 2, true, Ref(), 0, Ref(),
@@ -1258,6 +1303,7 @@ void plan_workspace(Engine& e) {
     nphase = std::max(nphase, i + 1);
     touch(e, op.in, i); touch(e, op.in2, i); touch(e, op.res, i); touch(e, op.out, i); touch(e, op.out2, i);
     for (int k = 0; k < op.fn; ++k) touch(e, op.fsrc[k], i);
+    for (const Op& su : op.sub) { touch(e, su.in, i); touch(e, su.res, i); touch(e, su.out, i); touch(e, su.out2, i); }
     if (op.type == OP_SMPL || op.type == OP_CAMERA || op.type == OP_RECORD) {
       touch(e, e.smpl_betas, i); touch(e, e.smpl_rot, i); touch(e, e.cam_ref, i);
     }
@@ -1461,6 +1507,52 @@ int run_op(Engine& e, Op& op, int B, const IO& io, hipStream_t s) {
       return launch_gemm1x1_dual(aptr(e, op.in), a.C, op.Cin, aptr(e, op.in2), x.C, op.C, x.H, x.W, op.stride, op.wdev, op.bdev,
                                  aptr(e, op.out), e.acts[op.out.act].C, op.Cout, B, a.H, a.W, op.actfn, s);
     }
+    case OP_MLP: {
+      MlpProgram p{};
+      p.B = B; p.sync = e.mlp_sync; p.err_host = e.mlp_err_host;
+      int nl = 0, nr = 0, last = -1;
+      for (const Op& su : op.sub) {
+        if (su.stage < last || su.stage >= MLP_MAX_STAGES) { poco_set_error("forward: " + op.name + ": sub-ops out of stage order"); return POCO_ERR_STATE; }
+        for (int sg = last + 1; sg <= su.stage; ++sg) p.stage[sg] = MlpStage{nl, 0, nr, 0};
+        last = su.stage;
+        MlpStage& st = p.stage[su.stage];
+        if (su.type == OP_CONV) {
+          const Act& ai = e.acts[su.in.act];
+          const Act& ao = e.acts[su.out.act];
+          if (nl >= MLP_MAX_LAYERS || su.ks != 1 || ai.H * ai.W != 1 || su.res_after || su.actfn > 2 || (su.Cin & 15) || (su.Cout & 15)) {
+            poco_set_error("forward: " + su.name + " is not a Linear layer the fused regressor can run"); return POCO_ERR_STATE;
+          }
+          MlpLayer& L = p.layer[nl++];
+          L.in = aptr(e, su.in); L.in_rs = ai.C;
+          if (su.res.act >= 0) { L.res = aptr(e, su.res); L.res_rs = e.acts[su.res.act].C; }
+          L.out = aptr(e, su.out); L.out_rs = ao.C;
+          L.wfrag = reinterpret_cast<const float4*>(su.wdev); L.bias = su.bdev;
+          L.nC16 = su.Cin / 16; L.nT16 = su.Cout / 16; L.act = su.actfn;
+          ++st.nlayers;
+        } else {
+          if (nr >= MLP_MAX_ROWS) { poco_set_error("forward: " + op.name + ": too many row jobs"); return POCO_ERR_STATE; }
+          MlpRowJob J{};
+          if (su.type == OP_ROT6D) {
+            J.kind = MLP_ROW_ROT6D;
+            J.src = aptr(e, su.in); J.src_rs = astride(e, su.in);
+            J.dst = aptr(e, su.out); J.dst_rs = astride(e, su.out);
+            J.dst2 = ext_out(io, su.out2.ext); J.dst2_rs = 216;
+          } else if (su.type == OP_BCAST) {
+            J.kind = MLP_ROW_BCAST; J.src = su.wdev; J.dst = aptr(e, su.out); J.dst_rs = astride(e, su.out); J.n = su.n;
+          } else if (su.type == OP_COPY) {
+            J.kind = MLP_ROW_COPY; J.n = su.n;
+            if (su.in.ext) { J.src = ext_in(io, su.in.ext); J.src_rs = su.n; if (!J.src) { poco_set_error("forward: missing input for " + su.name); return POCO_ERR_ARG; } }
+            else { J.src = aptr(e, su.in); J.src_rs = astride(e, su.in); }
+            if (su.out.ext) { J.dst = ext_out(io, su.out.ext); J.dst_rs = su.n; if (!J.dst) continue; }   // output not requested
+            else { J.dst = aptr(e, su.out); J.dst_rs = astride(e, su.out); }
+          } else { poco_set_error("forward: " + su.name + " cannot be a sub-op of the fused regressor"); return POCO_ERR_STATE; }
+          p.row[nr++] = J;
+          ++st.nrows;
+        }
+      }
+      p.nstages = last + 1;
+      return launch_mlp_chain(p, e.opts.mlp_blocks, s);
+    }
     case OP_COPY: {
       const float* src; int sstride;
       if (op.in.ext) { src = ext_in(io, op.in.ext); sstride = op.n; if (!src) { poco_set_error("forward: missing input for " + op.name); return POCO_ERR_ARG; } }
@@ -1615,6 +1707,7 @@ extern "C" int poco_finalize(poco_handle_t h) {
   for (const Op& op : e->ops) {
     auto use = [&](const Ref& r) { if (r.act >= 0 && r.act < (int)e->act_uses.size()) ++e->act_uses[r.act]; };
     use(op.in); use(op.in2); use(op.res);
+    for (const Op& su : op.sub) { use(su.in); use(su.res); }
     for (int k = 0; k < op.fn && k < 4; ++k) use(op.fsrc[k]);
   }
   if (e->wino4g_scratch_need)          // ALG 11 staging: one buffer per lane (ops of different lanes run concurrently)
@@ -1624,6 +1717,13 @@ extern "C" int poco_finalize(poco_handle_t h) {
     e->flow_scratch_floats = realnvp_scratch_floats(e->flow, rows);
     POCO_HIP_CHECK(hipMalloc(&e->flow_scratch, e->flow_scratch_floats * sizeof(float)));
   }
+  for (const Op& op : e->ops)
+    if (op.type == OP_MLP && !e->mlp_sync) {
+      POCO_HIP_CHECK(hipMalloc(&e->mlp_sync, 1024));
+      POCO_HIP_CHECK(hipMemset(e->mlp_sync, 0, 1024));
+      POCO_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&e->mlp_err_host), 64, hipHostMallocMapped));
+      *e->mlp_err_host = 0;
+    }
   POCO_HIP_CHECK(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
   for (Op& op : e->ops)
     if (op.wait_mask) {
@@ -1727,6 +1827,11 @@ extern "C" int poco_forward(poco_handle_t h, int B, const poco_inputs_t* in, con
   if (int rc = sized_struct_copy(out, &out_l, "poco_outputs_t")) return rc;
   if (!e->finalized) { poco_set_error("poco_forward: call poco_finalize first"); return POCO_ERR_STATE; }
   if (B < 1 || B > e->max_batch) { poco_set_error("poco_forward: batch " + std::to_string(B) + " outside 1.." + std::to_string(e->max_batch)); return POCO_ERR_ARG; }
+  if (e->mlp_err_host && *reinterpret_cast<volatile unsigned*>(e->mlp_err_host)) {
+    poco_set_error("poco_forward: a grid barrier of the fused regressor (mlp_chain.hip) timed out in an earlier forward - its outputs are invalid; "
+                   "rebuild the engine with the option mlp_fuse=0");
+    return POCO_ERR_HIP;
+  }
   hipStream_t caller = (hipStream_t)stream;
   IO io{&in_l, &out_l};
   int rc = enqueue_program(e, B, io, caller);

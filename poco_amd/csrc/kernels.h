@@ -59,6 +59,37 @@ void launch_broadcast_rows(const float* src, float* dst, int dst_stride, int n, 
 // NHWC [B,HW,cs] (first C channels) -> NCHW [B,C,HW]
 void launch_nhwc_to_nchw(const float* in, int cs, float* out, int B, int H, int W, int C, hipStream_t s);
 
+// ---- the CLIFF regressor as one persistent launch (mlp_chain.hip) -----------------------------------------
+// A program of stages; the jobs of a stage are independent, consecutive stages are separated by a grid barrier.
+struct MlpLayer {            // out[r][n] = act(bias[n] + sum_k W[n][k] in[r][k] (+ res[r][n])) for rows r < B (row-major vectors)
+  const float* in;           // [B][in_rs], K = 16 nC16 consecutive floats from `in`
+  const float* res;          // nullable, [B][res_rs]
+  float* out;                // [B][out_rs]
+  const float4* wfrag;       // conv_pack_weights(ks = 1): [nC16][nT16][64] float4
+  const float* bias;         // [16 nT16]
+  int nC16, nT16, in_rs, res_rs, out_rs, act;   // act: 0 none, 1 ReLU, 2 sigmoid
+};
+enum { MLP_ROW_COPY = 0, MLP_ROW_BCAST = 1, MLP_ROW_ROT6D = 2 };
+struct MlpRowJob {           // COPY: dst[r][i] = src[r][i], i < n; BCAST: dst[r][i] = src[i]; ROT6D: 24 x 6 -> 24 x 9 into dst and dst2 (nullable)
+  const float* src;
+  float* dst;
+  float* dst2;
+  int kind, src_rs, dst_rs, dst2_rs, n;
+};
+struct MlpStage { int layer0, nlayers, row0, nrows; };
+constexpr int MLP_MAX_LAYERS = 16, MLP_MAX_ROWS = 12, MLP_MAX_STAGES = 14;
+struct MlpProgram {
+  MlpLayer layer[MLP_MAX_LAYERS];
+  MlpRowJob row[MLP_MAX_ROWS];
+  MlpStage stage[MLP_MAX_STAGES];
+  int nstages, B;
+  unsigned* sync;            // device, 1 KiB: arrival counters (mlp_chain.hip); zero before the first launch, re-armed by the kernel
+  unsigned* err_host;        // pinned host word (device-visible): set when a grid barrier timed out
+  long long* trace;          // nullable (tools/probe/mlp_probe.hip): block 0 writes wall_clock64() at the start, after each stage's jobs and after each barrier
+};
+int mlp_chain_grid(const MlpProgram& p, int max_blocks);
+int launch_mlp_chain(const MlpProgram& p, int max_blocks, hipStream_t s);
+
 // ---- SMPL (kernels_smpl.hip) -------------------------------------------------------------------------
 struct SmplDev {
   int V;                       // 6890

@@ -158,6 +158,35 @@ def test_chained_bottleneck_matches_separate_convs(variant, cuda, monkeypatch):
         assert (a[k] - b[k]).abs().max().item() < 2e-5, k
 
 
+@pytest.mark.parametrize("variant,B", [("resnet50-cliff", 1), ("resnet50-cliff", 23), ("hrnet_w48_cls-cliff", 64), ("resnet50-cliff", 130)])
+def test_fused_regressor_matches_separate_launches(variant, B, cuda):
+    """cliff head: init state + fc1 / fc2 / decoders x 3 iterations + state scatter + rot6d (cliff_head.py:96-118) as ONE persistent
+    launch with grid barriers between the stages (csrc/mlp_chain.hip) against the chain of ~20 separate launches (option
+    mlp_fuse=0).  The K-split and the order of the partial sums are those of linear_mfma_kernel wherever that one splits K over
+    8 waves, so most outputs agree bitwise; the gate is 2e-5.  Ragged batches (23, 130 crops = 2 / 9 row tiles), one crop, and the
+    result must not depend on the grid (mlp_blocks 1 / 64 / 256) nor change over replays (the kernel re-arms its own counters)."""
+    batch = util.cuda_batch(synth.synth_batch(B, 31), cuda)
+    fused = util.make_engine(variant, max_batch=B, profile="stress")
+    separate = util.make_engine(variant, max_batch=B, profile="stress", options={"mlp_fuse": 0})
+    names = lambda m: [n for n, _, _ in m.ops()]
+    assert "head.regressor" in names(fused) and "head.regressor" not in names(separate)
+    assert len(names(separate)) - len(names(fused)) == 18
+    keys = ("pred_pose", "pred_shape", "pred_cam", "var_pose", "smpl_vertices", "uncert_feat", "body_feat2")
+    a = {k: v.clone() for k, v in fused(batch).items() if isinstance(v, torch.Tensor)}
+    b = separate(batch)
+    for k in keys:
+        assert (a[k] - b[k]).abs().max().item() < 2e-5 * max(1.0, b[k].abs().max().item()), k
+    for _ in range(3):                       # replays: same counters, same results
+        c = fused(batch)
+        for k in keys:
+            assert torch.equal(a[k], c[k]), k
+    for nb in (1, 64, 256):
+        other = util.make_engine(variant, max_batch=B, profile="stress", options={"mlp_blocks": nb})
+        c = other(batch)
+        for k in keys:
+            assert torch.equal(a[k], c[k]), (k, nb)
+
+
 GATED = ("pred_pose", "pred_shape", "pred_cam", "var_pose", "smpl_vertices", "smpl_joints3d")   # north_star: abs 1e-3
 FEATS = ("uncert_feat", "body_feat2", "pred_segm_mask")                                            # relative 1e-3
 
