@@ -369,8 +369,8 @@ class POCO:
     def op_sched(self, op_index: int):
         """(phase, lane, wait_mask, reads, writes) of an op - the schedule the engine enqueues (include/poco_hip.h poco_op_sched; no
         GPU needed); reads / writes are (activation id, first channel, end channel) triples."""
-        v = (C.c_int * 64)()
-        check(self._L.poco_op_sched(self._h, op_index, v, 64), "poco_op_sched")
+        v = (C.c_int * 512)()          # the fused regressor (OP_MLP) lists the accesses of its ~20 sub-ops
+        check(self._L.poco_op_sched(self._h, op_index, v, 512), "poco_op_sched")
         nr = v[3]
         rd = tuple((v[4 + 3 * k], v[5 + 3 * k], v[6 + 3 * k]) for k in range(nr))
         p = 4 + 3 * nr
