@@ -48,31 +48,42 @@ bneck_chain_kernel(const ChainParams p) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int nwaves = blockDim.x >> 6;
   const int idx = lane & 15, g = lane >> 4;
-  for (int mt = blockIdx.x * nwaves + wave; mt < p.ntiles; mt += gridDim.x * nwaves) {
+  // Software pipeline over the wave's sub-tiles: the operands of tile k+1 (t: 4 float4, residual: 16 float4 per lane) are requested
+  // right after the epilogue of tile k - `tb` / `rr` are dead by then - and travel under the 256 MFMAs of its second GEMM and the
+  // first GEMM of tile k+1; before, every tile began with an exposed load of `t` and fetched its residual with only half a GEMM of
+  // cover (148 us for a launch whose MFMA and HBM floors are both ~92 us).  Same arithmetic, same results.
+  const int tstep = gridDim.x * nwaves;
+  float4 tb[4], rr[16];
+  auto tile_addr = [&](int mt, const float** tp, const float** rp, float** yp, float** up, bool* valid) {
     const int pix = mt * 16 + idx;
-    const bool valid = pix < p.P;
+    *valid = pix < p.P;
     const uint32_t pc = (uint32_t)min(pix, p.P - 1);         // dead lanes recompute the last pixel
     const uint32_t row = fdiv(pc, p.dW);
     const int xo = (int)(pc - row * (uint32_t)p.W) * 16 + 4 * g;
-    const float* tp = p.t + (size_t)row * p.t_rs + xo;
-    const float* rp = p.res + (size_t)row * p.res_rs + xo;
-    float4 tb[4], rr[16];
+    *tp = p.t + (size_t)row * p.t_rs + xo;
+    *rp = p.res + (size_t)row * p.res_rs + xo;
+    *yp = p.y + (size_t)row * p.y_rs + xo;
+    *up = p.u + (size_t)row * p.u_rs + xo;
+  };
+  auto fetch = [&](int mt) {
+    const float *tp, *rp; float *yq, *uq; bool v;
+    tile_addr(min(mt, p.ntiles - 1), &tp, &rp, &yq, &uq, &v);   // past the end: a harmless re-read of the last tile (no predicated loads)
 #pragma unroll
     for (int c = 0; c < 4; ++c) tb[c] = *reinterpret_cast<const float4*>(tp + c * p.t_ss);
+#pragma unroll
+    for (int n = 0; n < 16; ++n) rr[n] = *reinterpret_cast<const float4*>(rp + n * p.res_ss);
+  };
+  const int mt0 = blockIdx.x * nwaves + wave;
+  if (mt0 < p.ntiles) fetch(mt0);
+  for (int mt = mt0; mt < p.ntiles; mt += tstep) {
+    const float *tp_, *rp_; float *yp, *up; bool valid;
+    tile_addr(mt, &tp_, &rp_, &yp, &up, &valid);
 
     f32x4 acc[16];
 #pragma unroll
     for (int n = 0; n < 16; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-      if (c == 2) {
-        // the residual is fetched under the second half of the first GEMM (fenced: hoisted to the top it costs 64
-        // more live VGPRs and the kernel spills)
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int n = 0; n < 16; ++n) rr[n] = *reinterpret_cast<const float4*>(rp + n * p.res_ss);
-        __builtin_amdgcn_sched_barrier(0);
-      }
       const float bv[4] = {tb[c].x, tb[c].y, tb[c].z, tb[c].w};
       // groups of 4 n-tiles, k-step outermost inside a group: consecutive MFMAs never share an accumulator
 #pragma unroll
@@ -90,7 +101,6 @@ bneck_chain_kernel(const ChainParams p) {
       }
     }
     // y = ReLU(acc + shift + residual): stored, and kept in place as the B operand of the second GEMM
-    float* yp = p.y + (size_t)row * p.y_rs + xo;
 #pragma unroll
     for (int n = 0; n < 16; ++n) {
       const float4 b = b3s[n * 4 + g];
@@ -100,6 +110,8 @@ bneck_chain_kernel(const ChainParams p) {
       acc[n] = v;
       if (valid) *reinterpret_cast<float4*>(yp + n * p.y_ss) = make_float4(v[0], v[1], v[2], v[3]);
     }
+    __builtin_amdgcn_sched_barrier(0);
+    fetch(mt + tstep);                                   // operands of the wave's next tile: under GEMM 2 and the next GEMM 1
     __builtin_amdgcn_sched_barrier(0);
     f32x4 acc2[4];
 #pragma unroll
@@ -117,7 +129,6 @@ bneck_chain_kernel(const ChainParams p) {
           acc2[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(aj, acc[c][j], acc2[n], 0, 0, 0);
         }
     }
-    float* up = p.u + (size_t)row * p.u_rs + xo;
 #pragma unroll
     for (int n = 0; n < 4; ++n) {
       const float4 b = b1s[n * 4 + g];

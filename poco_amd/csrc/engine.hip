@@ -106,6 +106,7 @@ struct EngineOpts {
   bool tail_lanes = true;  // SMPL-LBS + camera | output copies + confidence MLP on two lanes (PARE: the two head branches too)
   bool up_lanes = true;    // PARE: the three upsample chains continue on their branches' lanes
   bool wg_fuse = true;     // ALG 11: consecutive convs of a lane chained through wg_mid_kernel
+  bool stem_mfma = true;   // stem conv as an implicit GEMM on the MFMA (stem_mfma.hip) instead of the packed-FMA kernels of kernels_misc.hip
   bool mlp_fuse = true;    // CLIFF regressor (fc1 / fc2 / decoders x 3 iterations, state scatter, rot6d) as one persistent launch (mlp_chain.hip)
   int mlp_blocks = 256;    // ... on at most this many blocks (one grid barrier per stage: fewer blocks = cheaper barriers, more = more jobs at once)
   bool split_f16 = false;  // EXPERIMENT (never the default): plain 1x1 convs on the split-fp16 GEMM (gemm1x1h.hip)
@@ -139,6 +140,7 @@ static bool parse_opts(const char* str, EngineOpts* o, std::string* err) {
     else if (k == "up_lanes") o->up_lanes = on;
     else if (k == "wg_fuse") o->wg_fuse = on;
     else if (k == "mlp_fuse") o->mlp_fuse = on;
+    else if (k == "stem_mfma") o->stem_mfma = on;
     else if (k == "mlp_blocks") o->mlp_blocks = std::min(256, std::max(1, atoi(v.c_str())));
 #if POCO_EXPERIMENTS
     else if (k == "split_f16") o->split_f16 = on;
@@ -1405,7 +1407,7 @@ int run_op(Engine& e, Op& op, int B, const IO& io, hipStream_t s) {
     case OP_STEM: {
       const float* img = ext_in(io, X_IMG);
       if (!img) { poco_set_error("forward: img is NULL"); return POCO_ERR_ARG; }
-      launch_stem_conv(img, op.wdev, op.bdev, aptr(e, op.out), B, op.n, op.n, op.ks, s);
+      launch_stem_conv(img, op.wdev, op.bdev, aptr(e, op.out), B, op.n, op.n, op.ks, s, e.opts.stem_mfma);
       return POCO_OK;
     }
     case OP_CONV: {

@@ -10,7 +10,10 @@
 //   ks=3,stride 2,pad 1 : hrnet.py:467-469 ;  ks=7,stride 2,pad 3 : resnet.py:203-205
 // w: [ks*ks*3][Cout] (tap-major, scale folded), shift [Cout]; Cout must be 64.
 void launch_stem_conv(const float* img_nchw, const float* w, const float* shift, float* out_nhwc, int B,
-                      int H, int W, int ks, hipStream_t s);
+                      int H, int W, int ks, hipStream_t s, int use_mfma = 1);
+// the same as an implicit GEMM on the fp32 MFMA (stem_mfma.hip); false = shape not covered (Wo != 112), nothing launched
+bool launch_stem_conv_mfma(const float* img_nchw, const float* w, const float* shift, float* out_nhwc, int B, int H, int W, int ks,
+                           hipStream_t s);
 // 3x3 stride-2 pad-1 max pool, NHWC (resnet.py:206).
 // conv3 + residual + ReLU of one Bottleneck chained with conv1 + ReLU of the next (bneck_chain.hip)
 int launch_bneck_chain(const float* t, int t_cs, const float* res, int res_cs, float* y, int y_cs, float* u, int u_cs,

@@ -227,7 +227,8 @@ inline int nblk(long n, int t) { return (int)((n + t - 1) / t); }
 }  // namespace
 
 void launch_stem_conv(const float* img, const float* w, const float* shift, float* out, int B, int H, int W,
-                      int ks, hipStream_t s) {
+                      int ks, hipStream_t s, int use_mfma) {
+  if (use_mfma && launch_stem_conv_mfma(img, w, shift, out, B, H, W, ks, s)) return;   // 224 x 224 crops: implicit GEMM on the MFMA (stem_mfma.hip)
   const int pad = (ks - 1) / 2;
   const int Ho = (H + 2 * pad - ks) / 2 + 1, Wo = (W + 2 * pad - ks) / 2 + 1;
   const long npix = (long)B * Ho * Wo;

@@ -187,6 +187,20 @@ def test_fused_regressor_matches_separate_launches(variant, B, cuda):
             assert torch.equal(a[k], c[k]), (k, nb)
 
 
+@pytest.mark.parametrize("variant,B", [("resnet50-cliff", 3), ("hrnet_w32-pare", 5), ("resnet50-cliff", 64), ("hrnet_w48_cls-cliff", 17)])
+def test_mfma_stem_matches_valu_stem(variant, B, cuda):
+    """Stem conv (7x7 / 3x3, stride 2, Cin = 3; resnet.py:203-205, hrnet.py:467-469) as an implicit GEMM on the fp32 MFMA
+    (csrc/stem_mfma.hip: one output row per wave, zero-padded input rows double-buffered in LDS) against the packed-FMA kernels
+    (option stem_mfma=0).  Different summation order over the 147 / 27 taps: the gate is 2e-5 on the regressed outputs.  Batches
+    that give every block 1, 2 and 7 chunks of rows, with blocks that end past the last image row (17 crops: 5 chunks x 6 blocks)."""
+    batch = util.cuda_batch(synth.synth_batch(B, 13), cuda)
+    mfma = util.make_engine(variant, max_batch=B, profile="stress")
+    valu = util.make_engine(variant, max_batch=B, profile="stress", options={"stem_mfma": 0})
+    a, b = mfma(batch), valu(batch)
+    for k in ("pred_pose", "pred_shape", "pred_cam", "var_pose", "smpl_vertices"):
+        assert (a[k] - b[k]).abs().max().item() < 2e-5 * max(1.0, b[k].abs().max().item()), k
+
+
 GATED = ("pred_pose", "pred_shape", "pred_cam", "var_pose", "smpl_vertices", "smpl_joints3d")   # north_star: abs 1e-3
 FEATS = ("uncert_feat", "body_feat2", "pred_segm_mask")                                            # relative 1e-3
 
