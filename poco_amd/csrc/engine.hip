@@ -179,7 +179,7 @@ struct Engine {
   std::vector<hipEvent_t> ev_dep;   // one per op with a cross-lane dependency (Op::wait_lane)
   // SMPL / flow device models
   SmplDev smpl{};
-  int a_A = -1, a_j24 = -1, a_verts = -1, a_j49 = -1, a_attn_scratch = -1, a_camt = -1, a_fullt = -1, a_j2d = -1;
+  int a_coef = -1, a_A = -1, a_j24 = -1, a_verts = -1, a_j49 = -1, a_attn_scratch = -1, a_camt = -1, a_fullt = -1, a_j2d = -1;
   Ref smpl_betas, smpl_rot, cam_ref;
   FlowDev flow{};
   bool has_flow = false;
@@ -879,6 +879,7 @@ void build_smpl(Builder& b) {
   const HostParam* ev = b.P("smpl.extra_vertex_ids", {21});
   const HostParam* jm = b.P("smpl.joint_map", {49});
   e.a_A = b.new_act(288, 1, 1, true);
+  e.a_coef = b.new_act(SMPL_KB + 4, 1, 1, true);
   e.a_j24 = b.new_act(72, 1, 1, true);
   e.a_verts = b.new_act(V * 3, 1, 1, true);
   e.a_j49 = b.new_act(147, 1, 1, true);
@@ -907,6 +908,18 @@ void build_smpl(Builder& b) {
   e.smpl.v_template = b.upload(vt->data);
   e.smpl.shapedirs = b.upload(sdt);
   e.smpl.posedirs = b.upload(pd->data);
+  {   // the blend GEMM's B matrix (kernels_smpl.hip): posedirs | shapedirs | v_template stacked, coordinate-major, V padded to 32
+    const int VP = (V + 31) / 32 * 32;
+    std::vector<float> bl((size_t)SMPL_KB * 3 * VP, 0.f);
+    for (int v = 0; v < V; ++v)
+      for (int c = 0; c < 3; ++c) {
+        for (int k = 0; k < 207; ++k) bl[((size_t)k * 3 + c) * VP + v] = pd->data[(size_t)k * V * 3 + v * 3 + c];
+        for (int l = 0; l < 10; ++l) bl[((size_t)(207 + l) * 3 + c) * VP + v] = sd->data[((size_t)v * 3 + c) * 10 + l];
+        bl[((size_t)217 * 3 + c) * VP + v] = vt->data[(size_t)v * 3 + c];
+      }
+    e.smpl.blend_cm = b.upload(bl);
+    e.smpl.VP = VP;
+  }
   e.smpl.lbs_weights = b.upload(lw->data);
   e.smpl.J_template = b.upload(Jt);
   e.smpl.J_shapedirs = b.upload(Js);
@@ -1573,13 +1586,13 @@ int run_op(Engine& e, Op& op, int B, const IO& io, hipStream_t s) {
       sio.betas = aptr(e, e.smpl_betas); sio.betas_stride = astride(e, e.smpl_betas);
       sio.rotmat = aptr(e, e.smpl_rot); sio.rot_stride = astride(e, e.smpl_rot);
       sio.A = sptr(e, e.a_A);
+      sio.coef = sptr(e, e.a_coef);
       sio.joints24 = sptr(e, e.a_j24);
       float* yv = io.out->smpl_vertices;
       sio.verts = yv ? yv : sptr(e, e.a_verts);
-      float* yj = io.out->smpl_joints3d;
       sio.joints49 = sptr(e, e.a_j49);
+      sio.joints49_out = io.out->smpl_joints3d;
       launch_smpl_lbs(e.smpl, sio, B, s);
-      if (yj) launch_copy_rows(sio.joints49, 147, yj, 147, 147, B, s);
       return POCO_OK;
     }
     case OP_CAMERA: {
@@ -1985,6 +1998,7 @@ extern "C" int poco_smpl_lbs(poco_handle_t h, int B, const float* d_betas, const
   sio.betas = d_betas; sio.betas_stride = 10;
   sio.rotmat = d_rotmat; sio.rot_stride = 216;
   sio.A = e->ws + e->acts[e->a_A].off;
+  sio.coef = e->ws + e->acts[e->a_coef].off;
   sio.joints24 = e->ws + e->acts[e->a_j24].off;
   sio.verts = d_verts;
   sio.joints49 = d_joints49;

@@ -94,11 +94,14 @@ int mlp_chain_grid(const MlpProgram& p, int max_blocks);
 int launch_mlp_chain(const MlpProgram& p, int max_blocks, hipStream_t s);
 
 // ---- SMPL (kernels_smpl.hip) -------------------------------------------------------------------------
+constexpr int SMPL_KB = 220;   // K of the blend GEMM: 207 pose + 10 shape + 1 template, padded to a multiple of 4
 struct SmplDev {
   int V;                       // 6890
   const float* v_template;     // [V,3]
   const float* shapedirs;      // [10][V*3]   (transposed for coalescing)
   const float* posedirs;       // [207][V*3]
+  const float* blend_cm;       // [SMPL_KB][3][VP]: rows 0..206 posedirs, 207..216 shapedirs, 217 v_template, coordinate-major (kernels_smpl.hip)
+  int VP;                      // V padded to a multiple of 32
   const float* lbs_weights;    // [V,24]
   const float* J_template;     // [24,3]      J_regressor . v_template
   const float* J_shapedirs;    // [24,3,10]   J_regressor . shapedirs
@@ -111,9 +114,11 @@ struct SmplIO {
   const float* betas;  int betas_stride;    // [B,10]
   const float* rotmat; int rot_stride;      // [B,216]
   float* A;                                 // scratch [B,24,12]
+  float* coef;                              // scratch [B,SMPL_KB]: coefficient rows of the blend GEMM (chain kernel -> skin kernel)
   float* joints24;                          // scratch [B,24,3]
   float* verts;                             // [B,V,3] output
   float* joints49;                          // [B,49,3] output
+  float* joints49_out;                      // nullable: the same, written a second time (the caller's smpl_joints3d)
 };
 // smplx.lbs.lbs restated + the 49-joint wrapper of smpl_head.py:22-34.
 void launch_smpl_lbs(const SmplDev& m, const SmplIO& io, int B, hipStream_t s);

@@ -3,19 +3,19 @@
 // Restates smplx.lbs.lbs as invoked by the reference (pocolib/models/head/smpl_head.py:22-34,53-58,
 // smplcam_head.py:48-53; algorithm: SURVEY.md 3.5) as three batched small-matrix kernels:
 //   1. smpl_chain_kernel   : J(betas), 24-joint kinematic chain of 3x4 affines, A_i = G_i * [I|-J_i]
-//   2. smpl_skin_kernel    : per vertex: shape blend (10), pose blend (207), skinning (24x12), apply.
-//                            A block owns SKIN_T vertices x CB crops so posedirs (17 MB, the only large
-//                            operand) is streamed once per CB crops with 12-byte coalesced reads.
+//   2. smpl_skin_kernel    : the blend shapes as ONE GEMM on the fp32 MFMA (round 5),
+//                                v_posed[crop][v, c] = sum_k coef[crop][k] * blend[k][c][v],   k = 207 pose | 10 shape | template,
+//                            coef = [R - I (23 joints x 9) | betas | 1] written by the chain kernel, blend = posedirs / shapedirs /
+//                            v_template stacked coordinate-major on the host; then skinning (24 x 12 per vertex and crop) + apply on
+//                            the VALU.  A block owns 32 vertices x up to 64 crops: the 18 MB of blend rows are streamed once per 64
+//                            crops in 64-byte runs.  (Rounds 1-4: a VALU kernel, one thread per vertex x 8 crops, 207 x 3
+//                            12-byte loads per thread: 42 us for 64 crops; this one: see DESIGN.md.)
 //   3. smpl_joints_kernel  : 9 regressed extra joints (block reduction over 6890 vertices), 21 vertex
 //                            picks, 49-joint gather (smpl_head.py:25-27).
 // HBM bound: 82.7 KB of vertices written per crop; algorithmic reads ~17.8 MB of model per CB crops.
 #include "kernels.h"
 
 namespace {
-
-constexpr int CB = 8;    // crops per skinning block (posedirs is re-read once per CB crops).  Round 3 re-measured the neighbours at 64
-                         // crops (all three kernels): CB = 4 / 256 threads 80 us, CB = 8 / 256 threads 67 us, CB = 16 / 128 threads 117 us
-constexpr int SKIN_T = 256;  // vertices (threads) per skinning block
 
 // One wave per crop.  The chain is serial over the 24 joints (each needs its parent), but the 12 entries of a
 // joint's 3x4 affine are independent: lanes 0..11 compute one entry each from LDS, one barrier per joint.
@@ -49,6 +49,15 @@ smpl_chain_kernel(SmplDev m, SmplIO io, int B) {
     }
     __syncthreads();
   }
+  // coefficient row of the blend GEMM: pose feature (rotmat - I of joints 1..23, smplx lbs.py `pose_feature`), betas, 1 (template)
+  float* cf = io.coef + (size_t)b * SMPL_KB;
+  for (int k = t; k < SMPL_KB; k += 64) {
+    float v = 0.f;
+    if (k < 207) { const int e = 9 + k; v = R[e / 9][e % 9] - (((e % 9) % 4 == 0) ? 1.f : 0.f); }
+    else if (k < 217) v = betas[k - 207];
+    else if (k == 217) v = 1.f;
+    cf[k] = v;
+  }
   float* A = io.A + (size_t)b * 288;
   float* j24 = io.joints24 + (size_t)b * 72;
   for (int k = t; k < 288; k += 64) {
@@ -62,104 +71,87 @@ smpl_chain_kernel(SmplDev m, SmplIO io, int B) {
   }
 }
 
-__global__ void __launch_bounds__(SKIN_T)
+// grid (VP / 32, ceil(B / 64)), 8 waves: wave w owns crops 64 by + 16 (w & 3) ... + 15 (MFMA rows) x 16 of the block's 32 vertices
+// (tile w >> 2) x 3 coordinates: three accumulators.  D[i = crop][j = vertex]: lane (j = lane % 16, q = lane / 16) ends up with
+// x, y, z of vertex j for crops 4 q ... 4 q + 3 of the wave's 16 - one vertex's 24 skinning weights per lane, the crops' 3 x 4
+// affines A (chain kernel) broadcast from LDS.  The kernel is a chain of memory round trips, not of MFMAs (55 K steps x 3 per wave):
+// the operands of 28 K steps are requested together, i.e. two round trips per wave.
+constexpr int SKIN_CH = 28;
+__global__ void __launch_bounds__(512)
 smpl_skin_kernel(SmplDev m, SmplIO io, int B) {
-  __shared__ float pf[CB][208];
-  __shared__ float bt[CB][12];
-  __shared__ __attribute__((aligned(16))) float As[CB][288];
-  const int tid = threadIdx.x;
-  const int v = blockIdx.x * SKIN_T + tid;
-  const int b0 = blockIdx.y * CB;
-  const int nb = min(CB, B - b0);
-  for (int i = tid; i < CB * 207; i += SKIN_T) {
-    const int cb = i / 207, k = i % 207;
-    float val = 0.f;
-    if (cb < nb) {
-      const int e = 9 + k;   // skip the root joint's 9 entries
-      val = io.rotmat[(size_t)(b0 + cb) * io.rot_stride + e] - (((e % 9) % 4 == 0) ? 1.f : 0.f);
+  __shared__ __attribute__((aligned(16))) float As[64][288];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 15, q = lane >> 4;
+  const int b0 = blockIdx.y * 64;
+  const int nb = min(64, B - b0);
+  const int c0 = 16 * (wave & 3);                     // first crop of this wave inside the block
+  const int v = blockIdx.x * 32 + 16 * (wave >> 2) + j;
+  const bool active = c0 < nb;                        // wave-uniform
+  const float* cf = io.coef + (size_t)(b0 + min(c0 + j, nb - 1)) * SMPL_KB + q;      // A operand: row = crop, k = 4 step + q
+  const float* bl = m.blend_cm + (size_t)q * 3 * m.VP + v;                             // B operand: k = 4 step + q, column = vertex
+  const size_t kstride = (size_t)4 * 3 * m.VP;                                        // floats per K step
+  f32x4 acc[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  constexpr int NS = SMPL_KB / 4;
+  float a[SKIN_CH], bv[SKIN_CH][3];
+  auto request = [&](int s0) {
+#pragma unroll
+    for (int u = 0; u < SKIN_CH; ++u) {
+      const int st = min(s0 + u, NS - 1);             // past the end: a re-read, not used
+      a[u] = cf[st * 4];
+      const float* bp = bl + (size_t)st * kstride;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) bv[u][c] = bp[(size_t)c * m.VP];
     }
-    pf[cb][k] = val;
-  }
-  for (int i = tid; i < CB * 10; i += SKIN_T) {
-    const int cb = i / 10, l = i % 10;
-    bt[cb][l] = (cb < nb) ? io.betas[(size_t)(b0 + cb) * io.betas_stride + l] : 0.f;
-  }
-  for (int i = tid; i < CB * 288; i += SKIN_T) {
-    const int cb = i / 288, k = i % 288;
-    As[cb][k] = (cb < nb) ? io.A[(size_t)(b0 + cb) * 288 + k] : 0.f;
-  }
+  };
+  if (active) request(0);                             // first round trip under the staging of the affines
+  for (int i = tid; i < nb * 72; i += 512)            // float4 copies of the block's affines
+    reinterpret_cast<float4*>(&As[0][0])[i] = reinterpret_cast<const float4*>(io.A + (size_t)b0 * 288)[i];
   __syncthreads();
-  if (v >= m.V) return;
-  const int V3 = m.V * 3;
-  float vp[CB][3];
-  {
-    const float t0 = m.v_template[v * 3], t1 = m.v_template[v * 3 + 1], t2 = m.v_template[v * 3 + 2];
-#pragma unroll
-    for (int cb = 0; cb < CB; ++cb) { vp[cb][0] = t0; vp[cb][1] = t1; vp[cb][2] = t2; }
-  }
-  for (int l = 0; l < 10; ++l) {
-    const float* sd = m.shapedirs + (size_t)l * V3 + v * 3;
-    const float s0 = sd[0], s1 = sd[1], s2 = sd[2];
-#pragma unroll
-    for (int cb = 0; cb < CB; ++cb) {
-      const float be = bt[cb][l];
-      vp[cb][0] = fmaf(s0, be, vp[cb][0]); vp[cb][1] = fmaf(s1, be, vp[cb][1]); vp[cb][2] = fmaf(s2, be, vp[cb][2]);
-    }
-  }
-  // pose blend shapes: accumulate the offset separately, then add (matches v_shaped + offsets)
-  float po[CB][3];
-#pragma unroll
-  for (int cb = 0; cb < CB; ++cb) po[cb][0] = po[cb][1] = po[cb][2] = 0.f;
-  // 207 = 9 x 23: the 23 row loads of a chunk are issued together (the loop is latency-bound: < 1 wave per SIMD)
+  if (!active) return;
 #pragma unroll 1
-  for (int k0 = 0; k0 < 207; k0 += 23) {
-    float d[23][3];
+  for (int s0 = 0; s0 < NS; s0 += SKIN_CH) {
 #pragma unroll
-    for (int u = 0; u < 23; ++u) {
-      const float* pd = m.posedirs + (size_t)(k0 + u) * V3 + v * 3;
-      d[u][0] = pd[0]; d[u][1] = pd[1]; d[u][2] = pd[2];
-    }
+    for (int u = 0; u < SKIN_CH; ++u)
+      if (s0 + u < NS) {
 #pragma unroll
-    for (int u = 0; u < 23; ++u) {
-#pragma unroll
-      for (int cb = 0; cb < CB; ++cb) {
-        const float f = pf[cb][k0 + u];
-        po[cb][0] = fmaf(f, d[u][0], po[cb][0]); po[cb][1] = fmaf(f, d[u][1], po[cb][1]); po[cb][2] = fmaf(f, d[u][2], po[cb][2]);
+        for (int c = 0; c < 3; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], bv[u][c], acc[c], 0, 0, 0);
       }
-    }
+    if (s0 + SKIN_CH < NS) request(s0 + SKIN_CH);
   }
+  if (v >= m.V) return;
   float w[24];
-  {
-    const float4* wr = reinterpret_cast<const float4*>(m.lbs_weights + (size_t)v * 24);
+  const float4* wr = reinterpret_cast<const float4*>(m.lbs_weights + (size_t)v * 24);
 #pragma unroll
-    for (int q = 0; q < 6; ++q) {
-      const float4 t = wr[q];
-      w[q * 4] = t.x; w[q * 4 + 1] = t.y; w[q * 4 + 2] = t.z; w[q * 4 + 3] = t.w;
-    }
+  for (int k = 0; k < 6; ++k) {
+    const float4 t = wr[k];
+    w[k * 4] = t.x; w[k * 4 + 1] = t.y; w[k * 4 + 2] = t.z; w[k * 4 + 3] = t.w;
   }
-#pragma unroll     // fully unrolled (vp/po stay in registers); the tail of a ragged last block is predicated
-  for (int cb = 0; cb < CB; ++cb) {
-    if (cb < nb) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int cb = c0 + 4 * q + e;
+    if (cb >= nb) continue;
     float T[12];
 #pragma unroll
     for (int k = 0; k < 12; ++k) T[k] = 0.f;
 #pragma unroll
-    for (int j = 0; j < 24; ++j) {
-      const float wj = w[j];
-      const float4* a4 = reinterpret_cast<const float4*>(&As[cb][j * 12]);
+    for (int jj = 0; jj < 24; ++jj) {
+      const float wj = w[jj];
+      const float4* a4 = reinterpret_cast<const float4*>(&As[cb][jj * 12]);
 #pragma unroll
-      for (int q = 0; q < 3; ++q) {
-        const float4 a = a4[q];
-        T[q * 4] = fmaf(wj, a.x, T[q * 4]); T[q * 4 + 1] = fmaf(wj, a.y, T[q * 4 + 1]);
-        T[q * 4 + 2] = fmaf(wj, a.z, T[q * 4 + 2]); T[q * 4 + 3] = fmaf(wj, a.w, T[q * 4 + 3]);
+      for (int k = 0; k < 3; ++k) {
+        const float4 aa = a4[k];
+        T[k * 4] = fmaf(wj, aa.x, T[k * 4]); T[k * 4 + 1] = fmaf(wj, aa.y, T[k * 4 + 1]);
+        T[k * 4 + 2] = fmaf(wj, aa.z, T[k * 4 + 2]); T[k * 4 + 3] = fmaf(wj, aa.w, T[k * 4 + 3]);
       }
     }
-    const float x = vp[cb][0] + po[cb][0], y = vp[cb][1] + po[cb][1], z = vp[cb][2] + po[cb][2];
+    const float x = acc[0][e], y = acc[1][e], z = acc[2][e];
     float* o = io.verts + ((size_t)(b0 + cb) * m.V + v) * 3;
     o[0] = T[0] * x + T[1] * y + T[2] * z + T[3];
     o[1] = T[4] * x + T[5] * y + T[6] * z + T[7];
     o[2] = T[8] * x + T[9] * y + T[10] * z + T[11];
-    }
   }
 }
 
@@ -172,11 +164,17 @@ smpl_joints_kernel(SmplDev m, SmplIO io, int B) {
   float acc[27];
 #pragma unroll
   for (int k = 0; k < 27; ++k) acc[k] = 0.f;
-  for (int v = tid; v < m.V; v += 1024) {
+  // vertices tid, tid + 1024, ...: all 12 loads of an iteration are independent of the previous one's - unrolled so that they are
+  // requested together (a rolled loop is 7 dependent memory round trips per crop); past-the-end lanes re-read vertex V - 1 with weight 0
+#pragma unroll
+  for (int it = 0; it < 7; ++it) {
+    const int vv = tid + it * 1024;
+    const int v = min(vv, m.V - 1);
+    const float keep = vv < m.V ? 1.f : 0.f;
     const float x = vb[v * 3], y = vb[v * 3 + 1], z = vb[v * 3 + 2];
 #pragma unroll
     for (int j = 0; j < 9; ++j) {
-      const float wj = m.J_regressor_extra[(size_t)j * m.V + v];
+      const float wj = m.J_regressor_extra[(size_t)j * m.V + v] * keep;
       acc[j * 3] = fmaf(wj, x, acc[j * 3]); acc[j * 3 + 1] = fmaf(wj, y, acc[j * 3 + 1]);
       acc[j * 3 + 2] = fmaf(wj, z, acc[j * 3 + 2]);
     }
@@ -202,6 +200,7 @@ smpl_joints_kernel(SmplDev m, SmplIO io, int B) {
     else if (idx < 45) val = vb[(size_t)m.extra_vertex_ids[idx - 24] * 3 + k];
     else val = extra[(idx - 45) * 3 + k];
     io.joints49[(size_t)b * 147 + tid] = val;
+    if (io.joints49_out) io.joints49_out[(size_t)b * 147 + tid] = val;
   }
 }
 
@@ -244,7 +243,7 @@ __global__ void camera_kernel(CamArgs a, int B) {
 
 void launch_smpl_lbs(const SmplDev& m, const SmplIO& io, int B, hipStream_t s) {
   hipLaunchKernelGGL(smpl_chain_kernel, dim3(B), dim3(64), 0, s, m, io, B);
-  hipLaunchKernelGGL(smpl_skin_kernel, dim3((m.V + SKIN_T - 1) / SKIN_T, (B + CB - 1) / CB), dim3(SKIN_T), 0, s, m, io, B);
+  hipLaunchKernelGGL(smpl_skin_kernel, dim3(m.VP / 32, (B + 63) / 64), dim3(512), 0, s, m, io, B);
   hipLaunchKernelGGL(smpl_joints_kernel, dim3(B), dim3(1024), 0, s, m, io, B);
 }
 

@@ -17,7 +17,7 @@ ks = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].repl
        r.get("Stream_Id", r.get("Queue_Id", "0"))) for r in rows]
 ks.sort()
 # last forward = between the last two stem kernels
-stems = [i for i, k in enumerate(ks) if "stem_conv" in k[2]]
+stems = [i for i, k in enumerate(ks) if "stem_conv" in k[2] or "stem_mfma" in k[2]]
 lo, hi = stems[-2], stems[-1]
 fw = ks[lo:hi]
 t0, t1 = fw[0][0], max(k[1] for k in fw)
