@@ -87,6 +87,9 @@ struct ConvDesc {
   const float* wfrag_h = nullptr;         // EXPERIMENT (ALG 12, gemm1x1h.hip): hi / lo fp16 halves of the 1x1 weights, nullable
   float* scratch = nullptr;               // ALG 11: V + M staging (conv_wino4g_scratch_floats), owned by the caller
   size_t scratch_floats = 0;
+  float* sk_scratch = nullptr;            // ALG 14 (gemm1x1sk.hip): flags + partial accumulators (gemm1x1sk_scratch_floats), zeroed once by the owner
+  size_t sk_scratch_floats = 0;
+  unsigned* sk_err_host = nullptr;        // ... and the pinned host word its bounded waits raise
   // ALG 11 chaining (engine only): the previous conv already left this conv's V in scratch half `wg_vsel`; this conv leaves the
   // next conv's V in the other half (wg_mid_kernel) and writes its own output tensor only if somebody else still reads it
   int wg_skip_in = 0, wg_vsel = 0, wg_emit_next = 0, wg_store_y = 1;
@@ -120,6 +123,12 @@ bool gemm1x1_cfg_valid(const ConvDesc& d, const ConvCfg& cfg);
 int gemm1x1_launch(const ConvDesc& d, const ConvCfg& cfg, hipStream_t stream);
 // ---- the same with coalesced global traffic and an LDS transposition (gemm1x1t.hip), ALG 9 -----------------
 bool gemm1x1t_cfg_valid(const ConvDesc& d, const ConvCfg& cfg);
+// ---- stream-K 1x1 GEMM (gemm1x1sk.hip), ALG 14 ---------------------------------------------------------
+constexpr int SK_MAX_WAVES = 2048;                 // flags at the head of the scratch buffer
+constexpr size_t SK_PART_FLOATS = (size_t)32768 * 256;   // partial accumulators: waves x tiles per wave tile x 256 floats
+size_t gemm1x1sk_scratch_floats();
+bool gemm1x1sk_cfg_valid(const ConvDesc& d, const ConvCfg& cfg);
+int gemm1x1sk_launch(const ConvDesc& d, const ConvCfg& cfg, hipStream_t stream);
 size_t gemm1x1t_lds_bytes(const ConvDesc& d, const ConvCfg& cfg);
 int gemm1x1t_launch(const ConvDesc& d, const ConvCfg& cfg, hipStream_t stream);
 

@@ -97,6 +97,7 @@ size_t conv_lds_bytes(const ConvDesc& d, const ConvCfg& cfg) {
   if (cfg.ALG == 5) return linear_cfg_valid(d, cfg) ? (size_t)cfg.WM * 4 * 64 * sizeof(float4) : 0;
   if (cfg.ALG == 6) return gemm1x1_cfg_valid(d, cfg) ? 16 : 0;      // no LDS; non-zero = "valid" for the callers
   if (cfg.ALG == 9) return gemm1x1t_lds_bytes(d, cfg);
+  if (cfg.ALG == 14) return gemm1x1sk_cfg_valid(d, cfg) ? 16 : 0;   // no LDS; non-zero = "valid" for the callers
   if (cfg.ALG == 10) return gemm3x3_cfg_valid(d, cfg) ? 16 : 0;     // no LDS; non-zero = "valid" for the callers
   if (cfg.ALG == 11) return conv_wino4g_cfg_valid(d, cfg) ? 16 : 0;
 #if POCO_EXPERIMENTS
@@ -185,6 +186,7 @@ int conv_launch(const ConvDesc& d, const ConvCfg& cfg, hipStream_t stream) {
   if (cfg.ALG == 5) return linear_launch(d, cfg, stream);
   if (cfg.ALG == 6) return gemm1x1_launch(d, cfg, stream);
   if (cfg.ALG == 9) return gemm1x1t_launch(d, cfg, stream);
+  if (cfg.ALG == 14) return gemm1x1sk_launch(d, cfg, stream);
   if (cfg.ALG == 10) return gemm3x3_launch(d, cfg, stream);
   if (cfg.ALG == 11) return conv_wino4g_launch(d, cfg, stream);
 #if POCO_EXPERIMENTS

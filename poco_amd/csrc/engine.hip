@@ -191,8 +191,9 @@ struct Engine {
   float* flow_scratch = nullptr;          // step A of the flow (context GEMM): planned at finalize for opts.flow_ctx_rows context rows
   size_t flow_scratch_floats = 0;
   int uncert_feat_dim = 0;
+  float* sk_scratch[4] = {};          // ALG 14 (stream-K 1x1 GEMM): flags + partials, one buffer per lane
   unsigned* mlp_sync = nullptr;       // OP_MLP: grid-barrier counters (device) ...
-  unsigned* mlp_err_host = nullptr;   // ... and the sticky time-out word (pinned host memory the kernel can write)
+  unsigned* mlp_err_host = nullptr;   // ... and the sticky time-out word (pinned host memory the kernels can write; shared with ALG 14)
   std::string err;
 
   ~Engine() {
@@ -206,6 +207,7 @@ struct Engine {
     if (ws) (void)hipFree(ws);
     if (flow_scratch) (void)hipFree(flow_scratch);
     if (mlp_sync) (void)hipFree(mlp_sync);
+    for (float* q : sk_scratch) if (q) (void)hipFree(q);
     if (mlp_err_host) (void)hipHostFree(mlp_err_host);
     for (float* q : wino4g_scratch) if (q) (void)hipFree(q);
   }
@@ -1432,6 +1434,7 @@ int run_op(Engine& e, Op& op, int B, const IO& io, hipStream_t s) {
       d.out = aptr(e, op.out); d.out_cs = ao.C; d.out_co = 0;
       d.wfrag = op.wdev; d.bias = op.bdev; d.wfrag_wino = op.wdev_wino; d.wfrag_wino4 = op.wdev_wino4; d.wfrag_wino4p = op.wdev_wino4p; d.wfrag_wino4w = op.wdev_wino4w;
       d.wfrag_wino4g = op.wdev_wino4g; d.scratch = e.wino4g_scratch[op.lane & 3]; d.scratch_floats = e.wino4g_scratch_need;
+      d.sk_scratch = e.sk_scratch[op.lane & 3]; d.sk_scratch_floats = gemm1x1sk_scratch_floats(); d.sk_err_host = e.mlp_err_host;
       d.B = B; d.H = ai.H; d.W = ai.W; d.Cin = op.Cin; d.Cout = op.Cout; d.ks = op.ks; d.stride = op.stride;
       d.act = op.actfn; d.res_after_act = op.res_after; d.relu_from = op.relu_from;
       auto it = op.cfg.find(B);
@@ -1732,13 +1735,17 @@ extern "C" int poco_finalize(poco_handle_t h) {
     e->flow_scratch_floats = realnvp_scratch_floats(e->flow, rows);
     POCO_HIP_CHECK(hipMalloc(&e->flow_scratch, e->flow_scratch_floats * sizeof(float)));
   }
+  POCO_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&e->mlp_err_host), 64, hipHostMallocMapped));
+  *e->mlp_err_host = 0;
   for (const Op& op : e->ops)
     if (op.type == OP_MLP && !e->mlp_sync) {
       POCO_HIP_CHECK(hipMalloc(&e->mlp_sync, 1024));
       POCO_HIP_CHECK(hipMemset(e->mlp_sync, 0, 1024));
-      POCO_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&e->mlp_err_host), 64, hipHostMallocMapped));
-      *e->mlp_err_host = 0;
     }
+  for (int k = 0; k < 4; ++k) {          // ALG 14: flags (zero between launches) + partial accumulators, per lane
+    POCO_HIP_CHECK(hipMalloc(&e->sk_scratch[k], gemm1x1sk_scratch_floats() * sizeof(float)));
+    POCO_HIP_CHECK(hipMemset(e->sk_scratch[k], 0, (size_t)SK_MAX_WAVES * sizeof(float)));
+  }
   POCO_HIP_CHECK(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
   for (Op& op : e->ops)
     if (op.wait_mask) {
@@ -1843,8 +1850,8 @@ extern "C" int poco_forward(poco_handle_t h, int B, const poco_inputs_t* in, con
   if (!e->finalized) { poco_set_error("poco_forward: call poco_finalize first"); return POCO_ERR_STATE; }
   if (B < 1 || B > e->max_batch) { poco_set_error("poco_forward: batch " + std::to_string(B) + " outside 1.." + std::to_string(e->max_batch)); return POCO_ERR_ARG; }
   if (e->mlp_err_host && *reinterpret_cast<volatile unsigned*>(e->mlp_err_host)) {
-    poco_set_error("poco_forward: a grid barrier of the fused regressor (mlp_chain.hip) timed out in an earlier forward - its outputs are invalid; "
-                   "rebuild the engine with the option mlp_fuse=0");
+    poco_set_error("poco_forward: a bounded wait of the fused regressor (mlp_chain.hip) or of a stream-K GEMM (ALG 14) timed out in an earlier "
+                   "forward - its outputs are invalid; rebuild the engine with the option mlp_fuse=0 / without ALG 14 table entries");
     return POCO_ERR_HIP;
   }
   hipStream_t caller = (hipStream_t)stream;

@@ -44,7 +44,7 @@ static int conv_common(const float* d_in, int B, int H, int W, int Cin, const fl
   std::vector<float> shift(Cout16, 0.f);
   if (h_shift)
     for (int i = 0; i < Cout; ++i) shift[i] = h_shift[i];
-  DevBuf dw, db, dwu, dwu4, dwu4p, dwu4w, dwu4g, dscr;
+  DevBuf dw, db, dwu, dwu4, dwu4p, dwu4w, dwu4g, dscr, dsk;
   POCO_HIP_CHECK(dw.upload(packed));
   POCO_HIP_CHECK(db.upload(shift));
   ConvDesc d{};
@@ -91,6 +91,15 @@ static int conv_common(const float* d_in, int B, int H, int W, int Cin, const fl
       d.scratch = dscr.p;
     }
   }
+  if (cfg7 && cfg7[6] == 14) {                    // stream-K 1x1 GEMM: flags (zero) + partial accumulators, the pinned error word
+    static unsigned* sk_err = nullptr;
+    if (!sk_err) { POCO_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&sk_err), 64, hipHostMallocMapped)); *sk_err = 0; }
+    d.sk_scratch_floats = gemm1x1sk_scratch_floats();
+    POCO_HIP_CHECK(hipMalloc(&dsk.p, d.sk_scratch_floats * sizeof(float)));
+    POCO_HIP_CHECK(hipMemset(dsk.p, 0, (size_t)SK_MAX_WAVES * sizeof(float)));
+    d.sk_scratch = dsk.p;
+    d.sk_err_host = sk_err;
+  }
   d.in = d_in; d.in_cs = Cin; d.in_co = 0;
   d.res = d_res; d.res_cs = Cout; d.res_co = 0;
   d.out = d_out; d.out_cs = Cout; d.out_co = 0;
@@ -117,6 +126,7 @@ static int conv_common(const float* d_in, int B, int H, int W, int Cin, const fl
     (void)hipEventDestroy(e1);
   }
   POCO_HIP_CHECK(hipStreamSynchronize(stream));
+  if (d.sk_err_host && *reinterpret_cast<volatile unsigned*>(d.sk_err_host)) { poco_set_error("conv: a wait of the stream-K GEMM (ALG 14) timed out"); return POCO_ERR_HIP; }
   return POCO_OK;
 }
 
@@ -192,6 +202,18 @@ extern "C" int poco_tune_conv(int B, int H, int W, int Cin, int Cout, int ks, in
     d.scratch_floats = conv_wino4g_scratch_floats(B, H, W, Cin, Cout);
     POCO_HIP_CHECK(hipMalloc(&dscr.p, d.scratch_floats * sizeof(float)));
     d.scratch = dscr.p;
+  }
+  DevBuf dsk;
+  bool any14 = false;
+  for (int i = 0; i < ncfg; ++i) any14 = any14 || cfgs6[CONV_CFG_INTS * i + 6] == 14;
+  if (any14) {                                            // stream-K 1x1 GEMM: flags (zero) + partials, the pinned error word
+    static unsigned* sk_err = nullptr;
+    if (!sk_err) { POCO_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&sk_err), 64, hipHostMallocMapped)); *sk_err = 0; }
+    d.sk_scratch_floats = gemm1x1sk_scratch_floats();
+    POCO_HIP_CHECK(hipMalloc(&dsk.p, d.sk_scratch_floats * sizeof(float)));
+    POCO_HIP_CHECK(hipMemset(dsk.p, 0, (size_t)SK_MAX_WAVES * sizeof(float)));
+    d.sk_scratch = dsk.p;
+    d.sk_err_host = sk_err;
   }
   DevBuf dwh;
   bool any12 = false;

@@ -54,6 +54,11 @@ def candidates(B, H, W, Cin, Cout, ks, stride, lds_cap=150 * 1024) -> List[Tuple
             out.add((MT, NT, WM, WN, D, 1, 6))
             if D == 2 and (MT, NT) in ((4, 4), (7, 2), (7, 4), (8, 2)):   # the same through the LDS transposition (ALG 9)
                 out.add((MT, NT, WM, WN, 1, 1, 9))
+    if ks == 1 and stride == 1 and H * W > 1 and (B * H * W // 16) * nT >= 1024:   # stream-K register-direct GEMM (ALG 14, gemm1x1sk.hip):
+        for (MT, NT, D), WM, NI in itertools.product(                                  # WM = waves per block of the persistent grid
+                ((7, 4, 2), (7, 2, 2), (7, 2, 3), (4, 4, 2), (4, 4, 3), (4, 2, 3), (2, 4, 3)), (2, 4, 8), (1, 3, 6)):
+            if WM <= (4 if MT * NT > 16 else 8):
+                out.add((MT, NT, WM, 1, D, NI, 14))
     if ks == 3 and (stride == 2 or os.environ.get("POCO_TUNE_G3_S1")):     # register-direct gather GEMM (ALG 10); R = depth, NI = schedule
         for (MT, NT), (WM, WN), D, NI in itertools.product(
                 ((2, 4), (4, 2), (4, 3), (4, 4), (7, 2), (7, 3), (7, 4), (8, 2)),

@@ -323,6 +323,35 @@ def test_conv1x1_split_f16_experiment(case, cfg, cuda):
     assert err <= 2e-5
 
 
+GEMM1X1_SK_CFG = [(7, 4, 2, 1, 2, 1, 14), (7, 4, 4, 1, 2, 6, 14), (7, 2, 8, 1, 2, 3, 14), (7, 2, 4, 1, 3, 6, 14), (4, 4, 4, 1, 3, 6, 14),
+                  (4, 4, 8, 1, 2, 1, 14), (4, 2, 8, 1, 3, 3, 14), (2, 4, 8, 1, 3, 6, 14), (4, 4, 1, 1, 3, 6, 14)]
+
+
+@pytest.mark.parametrize("cfg", GEMM1X1_SK_CFG, ids=lambda c: "-".join(map(str, c)))
+@pytest.mark.parametrize("case", [c for c in GEMM1X1 if c[5] == 1] + [(64, 14, 14, 1024, 256, 1, True), (7, 7, 7, 2048, 512, 1, False)],
+                         ids=lambda c: "x".join(map(str, c)))
+def test_conv1x1_stream_k_gemm(case, cfg, cuda):
+    """ALG 14 (csrc/gemm1x1sk.hip): the 1x1 stride-1 GEMM with the (tile, K slice) units dealt evenly to a persistent grid of
+    waves; tiles that straddle waves are finished from partial accumulators exchanged through a scratch buffer (flags, agent-scope
+    accesses).  Against the fp64 conv like ALG 6 / 9; cases from one tile for the whole grid (every wave a slice of it) to the
+    bench-size 14x14 1024->256 of 64 crops (1.75 tiles per wave), with and without residual; run twice: the flags are re-armed."""
+    from poco_amd import ops
+    B, H, W, Cin, Cout, stride, has_res = case
+    rng = np.random.default_rng(B * 977 + Cin + Cout)
+    x = rng.standard_normal((B, H, W, Cin)).astype(np.float32)
+    w = (rng.standard_normal((Cout, Cin, 1, 1)) / np.sqrt(Cin)).astype(np.float32)
+    scale = rng.uniform(0.5, 1.5, Cout).astype(np.float32)
+    shift = rng.uniform(-0.5, 0.5, Cout).astype(np.float32)
+    res = rng.standard_normal((B, H, W, Cout)).astype(np.float32) if has_res else None
+    ref = _ref(x, w, scale, shift, 1, res, True)
+    xd = torch.from_numpy(x).to(cuda)
+    rd = None if res is None else torch.from_numpy(res).to(cuda)
+    out = ops.conv2d_nhwc(xd, w, scale, shift, 1, rd, True, cfg=cfg)
+    again = ops.conv2d_nhwc(xd, w, scale, shift, 1, rd, True, cfg=cfg)
+    assert torch.equal(out, again)                      # deterministic split, flags lowered by the finishing waves
+    assert np.abs(out.cpu().numpy() - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max())
+
+
 def test_conv1x1_register_gemm_rejects_3x3(cuda):
     from poco_amd import ops
     x = torch.zeros(1, 8, 8, 16, device=cuda)

@@ -205,7 +205,7 @@ def test_tuned_table_entries_are_valid_configurations(variant):
         for i in convs:
             cfg = m._L.poco_get_conv_cfg       # the active configuration is always retrievable
             c = (C.c_int * 7)()
-            assert cfg(m._h, i, B, c) == 0 and c[6] in (0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 13)
+            assert cfg(m._h, i, B, c) == 0 and c[6] in (0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 14)
 
 
 def test_c_abi_from_plain_c(tmp_path):

@@ -1,0 +1,45 @@
+"""ALG 14 (stream-K 1x1 GEMM, csrc/gemm1x1sk.hip) against the tuned table's entry, shape by shape: parity + solo time.
+    python tools/sk_probe.py [B]"""
+import ctypes as C
+import json
+import sys
+from pathlib import Path
+import numpy as np
+import torch
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+from poco_amd import ops  # noqa: E402
+from poco_amd._lib import check, lib  # noqa: E402
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+SHAPES = [(14, 14, 1024, 256), (14, 14, 256, 1024), (28, 28, 512, 128), (28, 28, 128, 512), (7, 7, 2048, 512), (7, 7, 512, 2048),
+          (7, 7, 1024, 2048), (14, 14, 1024, 512), (28, 28, 512, 256), (56, 56, 256, 128), (56, 56, 256, 64), (56, 56, 64, 256)]
+SK = [(7, 4, w, 1, 2, ni, 14) for w in (2, 4) for ni in (1, 3, 6)] + [(7, 2, w, 1, r, ni, 14) for w in (4, 8) for r in (2, 3) for ni in (1, 3, 6)] + \
+     [(4, 4, w, 1, r, ni, 14) for w in (4, 8) for r in (2, 3) for ni in (1, 3, 6)] + [(4, 2, 8, 1, 3, ni, 14) for ni in (1, 3, 6)] + \
+     [(2, 4, 8, 1, 3, ni, 14) for ni in (1, 3, 6)]
+table = json.loads((Path(__file__).resolve().parent.parent / "poco_amd" / "tuned" / "gfx950.json").read_text())
+L = lib()
+L.poco_tune_conv.argtypes = [C.c_int] * 7 + [C.POINTER(C.c_int), C.c_int, C.c_int, C.POINTER(C.c_float), C.c_void_p]
+dev = torch.device("cuda:0")
+rng = np.random.default_rng(0)
+for (H, W, Cin, Cout) in SHAPES:
+    key = f"{B}x{H}x{W}x{Cin}x{Cout}k1s1"
+    tcfg = tuple(table[key]["cfg"]) if key in table else (0,) * 7
+    # parity on a ragged batch (5 crops) with residual + ReLU: ALG 14 against the library default
+    x = torch.from_numpy(rng.standard_normal((5, H, W, Cin)).astype(np.float32)).to(dev)
+    res = torch.from_numpy(rng.standard_normal((5, H, W, Cout)).astype(np.float32)).to(dev)
+    w = (rng.standard_normal((Cout, Cin, 1, 1)) / np.sqrt(Cin)).astype(np.float32)
+    sh = rng.standard_normal(Cout).astype(np.float32)
+    ref = ops.conv2d_nhwc(x, w, None, sh, 1, res, True, None)
+    worst = 0.0
+    for c in SK:
+        y = ops.conv2d_nhwc(x, w, None, sh, 1, res, True, c)
+        worst = max(worst, (y - ref).abs().max().item())
+    cands = [tcfg] + SK
+    flat = (C.c_int * (7 * len(cands)))(*[v for c in cands for v in c])
+    ms = (C.c_float * len(cands))()
+    check(L.poco_tune_conv(B, H, W, Cin, Cout, 1, 1, flat, len(cands), 30, ms, None), "poco_tune_conv")
+    best = min(range(1, len(cands)), key=lambda i: ms[i] if ms[i] > 0 else 1e9)
+    fl = 2.0 * B * H * W * Cin * Cout
+    print(f"{H}x{W} {Cin}->{Cout}: table {tcfg} {ms[0] * 1e3:.1f} us ({fl / ms[0] / 1e9:.1f} TF) | best ALG 14 {cands[best]} {ms[best] * 1e3:.1f} us "
+          f"({fl / ms[best] / 1e9:.1f} TF) {100 * (ms[0] / ms[best] - 1):+.1f} % | parity max diff {worst:.2e}", flush=True)
+    print("      " + "  ".join(f"{c[:6]}:{ms[i + 1] * 1e3:.0f}" for i, c in enumerate(SK)))
