@@ -409,7 +409,8 @@ class POCO:
                 2: f"conv_dma_persist_kernel<{ks}, {st}, {MT}, {NT}>", 3: f"conv_wino_kernel<{NT}>",
                 4: f"conv_wino2_kernel<{NT}, {3 if MT == 3 else 2}>", 5: "linear_mfma_kernel" if ks == 1 else "conv3x3_splitk_kernel", 6: f"gemm1x1_kernel<{MT}, {NT}, {R}", 7: f"conv_wino4_kernel<{NT}>", 8: f"conv_wino4p_kernel<{NT}, {0 if NI else (1 if R == 4 else 2)}>",
                 9: f"gemm1x1t_kernel<{MT}, {NT}", 10: f"gemm3x3_kernel<{MT}, {NT}, {R}",
-                11: f"wg_gemm_kernel<{MT}, {NT}, {R}>", 13: f"conv_wino4w_kernel<{NT}, {0 if NI else 1}>"}[ALG]
+                11: f"wg_gemm_kernel<{MT}, {NT}, {R}>", 13: f"conv_wino4w_kernel<{NT}, {0 if NI else 1}>",
+                14: f"gemm1x1sk_kernel<{MT}, {NT}, {R}"}[ALG]
 
     def set_conv_cfg(self, op_index: int, B: int, cfg) -> None:
         arr = (C.c_int * 7)(*(tuple(cfg) + (0,) * (7 - len(cfg))))

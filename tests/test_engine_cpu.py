@@ -206,6 +206,7 @@ def test_tuned_table_entries_are_valid_configurations(variant):
             cfg = m._L.poco_get_conv_cfg       # the active configuration is always retrievable
             c = (C.c_int * 7)()
             assert cfg(m._h, i, B, c) == 0 and c[6] in (0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 14)
+            assert m.kernel_symbol(m.conv_desc(i), tuple(c))       # bench.py names every conv's kernel (roofline.dominant): a new ALG needs its symbol
 
 
 def test_c_abi_from_plain_c(tmp_path):
