@@ -30,7 +30,7 @@ struct SKParams {
   const float4* wfrag;   // [Cin/16][Cout16/16][64] float4
   const float* bias;
   int P, W;              // pixels, plane width
-  int nC16, nT16, ntn, ntiles, nwaves;
+  int nC16, nT16, ntn, ntiles, nwaves, ngroups;
   int in_rs, in_ss, res_rs, out_rs, out_ss;
   int act, res_after_act, relu_from;
   FastDiv dW;
@@ -59,8 +59,13 @@ gemm1x1sk_kernel(const SKParams p) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int idx = lane & 15, g = lane >> 4;
   const int wid = blockIdx.x * (blockDim.x >> 6) + wave;
-  const long long U = (long long)p.ntiles * p.nC16;
-  const long long lo = U * wid / p.nwaves, hi = U * (wid + 1) / p.nwaves;
+  // The waves are dealt to the n-tile groups round-robin (wave w -> group w % ng, rank w / ng) and every group streams over ITS tiles
+  // (all pixel tiles of one n-tile group): waves w ... w + ng - 1 of a block then read the same pixels at the same time, as the
+  // wave columns of an ALG 6 block do.  With one tile-major list for all waves the ng reads of a pixel slice are far apart in time
+  // and each comes from memory: 263 MB per launch instead of ~70 (PMC, ResNet-50's four ALG 14 shapes).
+  const int ng = p.ngroups, group = wid % ng, rank = wid / ng, Wg = p.nwaves / ng;
+  const long long U = (long long)(p.ntiles / ng) * p.nC16;
+  const long long lo = U * rank / Wg, hi = U * (rank + 1) / Wg;
   if (lo >= hi) return;
   const int t_first = (int)(lo / p.nC16), c_first = (int)(lo - (long long)t_first * p.nC16);
   const int t_last = (int)((hi - 1) / p.nC16), c_last_end = (int)(hi - 1 - (long long)t_last * p.nC16) + 1;
@@ -70,7 +75,8 @@ gemm1x1sk_kernel(const SKParams p) {
   f32x4 acc[MT][NT];
   const int wslice = p.nT16 * 64;                        // float4 per K slice
   // tile -> pixel offsets of this lane; K loop over slices [cb, ce) into acc
-  auto segment = [&](int t, int cb, int ce) {
+  auto segment = [&](int tl, int cb, int ce) {
+    const int t = ng > 1 ? tl * p.ntn + group : tl;      // ng > 1: local tile tl = pixel tile tl of n-tile group `group`
     const int tm = t / p.ntn, tn = t - tm * p.ntn;
     const int mt0 = tm * MT, nt0 = tn * NT;
 #pragma unroll
@@ -146,7 +152,8 @@ gemm1x1sk_kernel(const SKParams p) {
       if (nfull + u < n) mma(u, false, 0, 0);
   };
   // shift (+ residual) (activation) -> L16 channel slice, as in gemm1x1.hip
-  auto epilogue = [&](int t) {
+  auto epilogue = [&](int tl) {
+    const int t = ng > 1 ? tl * p.ntn + group : tl;
     const int tm = t / p.ntn, tn = t - tm * p.ntn;
     const int nt0 = tn * NT;
 #pragma unroll
@@ -200,8 +207,9 @@ gemm1x1sk_kernel(const SKParams p) {
     segment(t_first, c_first, p.nC16);
     const long long tile_lo = (long long)t_first * p.nC16;
     bool ok = true;
-    for (int v = wid - 1; v >= 0 && U * (v + 1) / p.nwaves > tile_lo; --v) {
-      if (U * v / p.nwaves >= U * (v + 1) / p.nwaves) continue;       // more waves than units: wave v has no work and no partial
+    for (int vr = rank - 1; vr >= 0 && U * (vr + 1) / Wg > tile_lo; --vr) {
+      if (U * vr / Wg >= U * (vr + 1) / Wg) continue;                  // more waves than units: that wave has no work and no partial
+      const int v = vr * ng + group;                                    // global index of the wave with rank vr in this group
       unsigned spins = 0;
       while (__hip_atomic_load(&p.flag[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
         __builtin_amdgcn_s_sleep(1);
@@ -279,6 +287,7 @@ int gemm1x1sk_launch(const ConvDesc& d, const ConvCfg& cfg, hipStream_t stream) 
   int blocks = SK_BLOCKS;
   while (blocks > 1 && (long long)blocks * cfg.WM * 4 > U) blocks /= 2;      // tiny problems: at least 4 slices per wave
   p.nwaves = blocks * cfg.WM;
+  p.ngroups = (p.ntn <= 32 && p.nwaves % p.ntn == 0 && cfg.WM % std::min(p.ntn, cfg.WM) == 0) ? p.ntn : 1;   // see the kernel
   p.flag = reinterpret_cast<unsigned*>(d.sk_scratch);
   p.part = d.sk_scratch + SK_MAX_WAVES;
   p.err_host = d.sk_err_host;

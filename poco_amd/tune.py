@@ -186,21 +186,29 @@ def candidates(B, H, W, Cin, Cout, ks, stride, lds_cap=150 * 1024) -> List[Tuple
     return sorted(out)
 
 
+def _timed(L, B, H, W, Cin, Cout, ks, stride, cands, iters):
+    """ms of every candidate of one poco_tune_conv call.  The FIRST configuration of a call measures ~10 % slow (66.5 against 60.4 us for
+    the same 14x14 1024->256 kernel in slot 0 and in a later slot, tools/sk_probe.py, round 5: the chip is still clocking up / its
+    caches are cold), so slot 0 is a throw-away copy of the first candidate."""
+    from ._lib import check
+    run = [cands[0]] + list(cands)
+    flat = (C.c_int * (7 * len(run)))(*[v for c in run for v in c])
+    ms = (C.c_float * len(run))()
+    check(L.poco_tune_conv(B, H, W, Cin, Cout, ks, stride, flat, len(run), iters, ms, None), "poco_tune_conv")
+    return [ms[i + 1] for i in range(len(cands))]
+
+
 def solo_times(L, B, H, W, Cin, Cout, ks, stride, iters=8, with_default=False):
     """[(ms, cfg)] of every candidate of one shape, each timed on its own (cfg all-zero = the built-in heuristic)."""
     from ._lib import check
     cands = ([(0, 0, 0, 0, 0, 0, 0)] if with_default else []) + candidates(B, H, W, Cin, Cout, ks, stride)
-    flat = (C.c_int * (7 * len(cands)))(*[v for c in cands for v in c])
-    ms = (C.c_float * len(cands))()
-    check(L.poco_tune_conv(B, H, W, Cin, Cout, ks, stride, flat, len(cands), iters, ms, None), "poco_tune_conv")
+    ms = _timed(L, B, H, W, Cin, Cout, ks, stride, cands, iters)
     res = [(ms[i], cands[i]) for i in range(len(cands))]
     # ALG 6 load schedules (NI 2..6) only for its best few tilings under hipcc's schedule (NI = 1)
     g6 = [c for _, c in sorted(r for r in res if r[0] > 0 and r[1][6] == 6 and r[1][5] == 1)[:8]]
     cands6 = [c[:5] + (ni, 6) for c in g6 for ni in range(2, 7) if G1_SCHED_G[ni] * (c[0] + c[1]) <= 4 * c[0] * c[1]]
     if cands6:
-        flat6 = (C.c_int * (7 * len(cands6)))(*[v for c in cands6 for v in c])
-        ms6 = (C.c_float * len(cands6))()
-        check(L.poco_tune_conv(B, H, W, Cin, Cout, ks, stride, flat6, len(cands6), iters, ms6, None), "poco_tune_conv")
+        ms6 = _timed(L, B, H, W, Cin, Cout, ks, stride, cands6, iters)
         res += [(ms6[i], cands6[i]) for i in range(len(cands6))]
     return res
 
@@ -214,9 +222,7 @@ def tune_shape(L, B, H, W, Cin, Cout, ks, stride, iters=8):
     # re-time the top few with more iterations to reduce noise
     top = sorted(res)[:6]
     cands2 = [c for _, c in top]
-    flat2 = (C.c_int * (7 * len(cands2)))(*[v for c in cands2 for v in c])
-    ms2 = (C.c_float * len(cands2))()
-    check(L.poco_tune_conv(B, H, W, Cin, Cout, ks, stride, flat2, len(cands2), iters * 4, ms2, None), "poco_tune_conv")
+    ms2 = _timed(L, B, H, W, Cin, Cout, ks, stride, cands2, iters * 4)
     best_i = min(range(len(cands2)), key=lambda i: ms2[i])
     return cands2[best_i], float(ms2[best_i]), float(base), len(cands)
 

@@ -34,12 +34,13 @@ for (H, W, Cin, Cout) in SHAPES:
     for c in SK:
         y = ops.conv2d_nhwc(x, w, None, sh, 1, res, True, c)
         worst = max(worst, (y - ref).abs().max().item())
-    cands = [tcfg] + SK
+    cands = [tcfg, tcfg] + SK + [tcfg]     # slot 0 is a warm-up: the first configuration of a poco_tune_conv call measures ~10 % slow (clock ramp)
     flat = (C.c_int * (7 * len(cands)))(*[v for c in cands for v in c])
     ms = (C.c_float * len(cands))()
     check(L.poco_tune_conv(B, H, W, Cin, Cout, 1, 1, flat, len(cands), 30, ms, None), "poco_tune_conv")
-    best = min(range(1, len(cands)), key=lambda i: ms[i] if ms[i] > 0 else 1e9)
+    best = min(range(2, len(cands) - 1), key=lambda i: ms[i] if ms[i] > 0 else 1e9)
+    tms = min(ms[1], ms[len(cands) - 1])
     fl = 2.0 * B * H * W * Cin * Cout
-    print(f"{H}x{W} {Cin}->{Cout}: table {tcfg} {ms[0] * 1e3:.1f} us ({fl / ms[0] / 1e9:.1f} TF) | best ALG 14 {cands[best]} {ms[best] * 1e3:.1f} us "
-          f"({fl / ms[best] / 1e9:.1f} TF) {100 * (ms[0] / ms[best] - 1):+.1f} % | parity max diff {worst:.2e}", flush=True)
-    print("      " + "  ".join(f"{c[:6]}:{ms[i + 1] * 1e3:.0f}" for i, c in enumerate(SK)))
+    print(f"{H}x{W} {Cin}->{Cout}: table {tcfg} {tms * 1e3:.1f} us ({fl / tms / 1e9:.1f} TF; as slot 0: {ms[0] * 1e3:.1f}) | best ALG 14 {cands[best]} {ms[best] * 1e3:.1f} us "
+          f"({fl / ms[best] / 1e9:.1f} TF) {100 * (tms / ms[best] - 1):+.1f} % | parity max diff {worst:.2e}", flush=True)
+    print("      " + "  ".join(f"{c[:6]}:{ms[i + 2] * 1e3:.0f}" for i, c in enumerate(SK)))
