@@ -99,6 +99,7 @@ int poco_create(const char* variant, int max_batch, int num_flow_layers, poco_ha
 /* The same with build options: "key=value,key=value" (NULL or "" = defaults = poco_create).  The library reads NO environment
  * variable; every alternative form is chosen here, computes the same model and is compared with the default in tests/:
  *   kcat, kmerge, chain, dual, wg_fuse = 0   the separate-launch form of a fused op group (csrc/engine.hip EngineOpts)
+ *   dual_layout = <100 NI + 10 WM + WN>      ResNet-50's two-source shortcut GEMM: load schedule / waves per block (default 41; 0 = one-wave blocks)
  *   stem_mfma = 0                            the stem conv on the packed-FMA kernels instead of the MFMA implicit GEMM (csrc/stem_mfma.hip)
  *   mlp_fuse = 0, mlp_blocks = <1..256>      cliff head: the regressor chain as separate launches instead of the one persistent launch of
  *                                            csrc/mlp_chain.hip / the number of blocks of that launch (default 256)

@@ -106,6 +106,11 @@ struct EngineOpts {
   bool tail_lanes = true;  // SMPL-LBS + camera | output copies + confidence MLP on two lanes (PARE: the two head branches too)
   bool up_lanes = true;    // PARE: the three upsample chains continue on their branches' lanes
   bool wg_fuse = true;     // ALG 11: consecutive convs of a lane chained through wg_mid_kernel
+  // two-source GEMM (layer2-4 .0 of ResNet-50): 100 NI + 10 WM + WN, 0 = one wave per block.  One-wave blocks were the fastest layout in the
+  // round-2 probe (204 us for layer4.0) but their time depends on how the dispatcher spreads 896 single waves over the 1024 SIMDs - hidden state
+  // left by the kernels before: with other configurations of the 14x14 convs five launches earlier the same launch takes 343 us (round 5,
+  // DESIGN.md 8).  Four-wave blocks (one wave per SIMD by construction) cost ~3 us per launch and do not have that cliff.
+  int dual_layout = 41;
   bool stem_mfma = true;   // stem conv as an implicit GEMM on the MFMA (stem_mfma.hip) instead of the packed-FMA kernels of kernels_misc.hip
   bool mlp_fuse = true;    // CLIFF regressor (fc1 / fc2 / decoders x 3 iterations, state scatter, rot6d) as one persistent launch (mlp_chain.hip)
   int mlp_blocks = 256;    // ... on at most this many blocks (one grid barrier per stage: fewer blocks = cheaper barriers, more = more jobs at once)
@@ -141,6 +146,7 @@ static bool parse_opts(const char* str, EngineOpts* o, std::string* err) {
     else if (k == "wg_fuse") o->wg_fuse = on;
     else if (k == "mlp_fuse") o->mlp_fuse = on;
     else if (k == "stem_mfma") o->stem_mfma = on;
+    else if (k == "dual_layout") o->dual_layout = atoi(v.c_str());
     else if (k == "mlp_blocks") o->mlp_blocks = std::min(256, std::max(1, atoi(v.c_str())));
 #if POCO_EXPERIMENTS
     else if (k == "split_f16") o->split_f16 = on;
@@ -1523,7 +1529,7 @@ int run_op(Engine& e, Op& op, int B, const IO& io, hipStream_t s) {
       const Act& a = e.acts[op.in.act];
       const Act& x = e.acts[op.in2.act];
       return launch_gemm1x1_dual(aptr(e, op.in), a.C, op.Cin, aptr(e, op.in2), x.C, op.C, x.H, x.W, op.stride, op.wdev, op.bdev,
-                                 aptr(e, op.out), e.acts[op.out.act].C, op.Cout, B, a.H, a.W, op.actfn, s);
+                                 aptr(e, op.out), e.acts[op.out.act].C, op.Cout, B, a.H, a.W, op.actfn, s, e.opts.dual_layout);
     }
     case OP_MLP: {
       MlpProgram p{};

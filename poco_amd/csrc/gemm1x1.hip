@@ -273,7 +273,7 @@ int gemm1x1_launch(const ConvDesc& d, const ConvCfg& cfg, hipStream_t stream) {
 // [B,H2,W2,Cb of b_cs] the block input, sampled at (2y, 2x).  wfrag: conv_pack_weights(ks = 1) over Ca + Cb input channels.
 int launch_gemm1x1_dual(const float* a, int a_cs, int Ca, const float* b, int b_cs, int Cb, int H2, int W2, int stride2,
                         const float* wfrag, const float* bias, float* out, int out_cs, int Cout, int B, int Ho, int Wo, int act,
-                        hipStream_t stream) {
+                        hipStream_t stream, int wave_layout) {
   if ((Ca | Cb | Cout) % 16 || Cout % 64 || (stride2 != 1 && stride2 != 2) || (long)B * Ho * Wo >= (1L << 27)) {
     poco_set_error("gemm1x1_dual: Ca, Cb multiples of 16, Cout a multiple of 64, stride 1|2");
     return POCO_ERR_ARG;
@@ -291,6 +291,7 @@ int launch_gemm1x1_dual(const float* a, int a_cs, int Ca, const float* b, int b_
   // tile 7x4, depth 2, one wave per block, default load schedule: the fastest of the wave layouts / schedules probed per
   // ResNet-50 stage at B = 64 (tools/dual_probe.sh builds with -DG1_DUAL_EXP to repeat that sweep)
   int WM = 1, WN = 1, NI = 1;
+  if (wave_layout > 0) { WM = std::max(1, (wave_layout / 10) % 10); WN = std::max(1, wave_layout % 10); NI = wave_layout >= 100 ? wave_layout / 100 : 1; if (WM * WN > 8 || !(NI == 1 || (NI >= 3 && NI <= 6))) { WM = WN = NI = 1; } }
 #ifdef G1_DUAL_EXP
   static const char* ov = getenv("POCO_G1_DUAL");         // "WM,WN,NI": timing probe, probe builds only
   if (ov) {

@@ -22,7 +22,7 @@ int launch_bneck_chain(const float* t, int t_cs, const float* res, int res_cs, f
 // K-concatenated projection shortcut with a strided second source (gemm1x1.hip)
 int launch_gemm1x1_dual(const float* a, int a_cs, int Ca, const float* b, int b_cs, int Cb, int H2, int W2, int stride2,
                         const float* wfrag, const float* bias, float* out, int out_cs, int Cout, int B, int Ho, int Wo, int act,
-                        hipStream_t stream);
+                        hipStream_t stream, int wave_layout = 0);   // wave_layout = 100 NI + 10 WM + WN (0 = one wave per block, hipcc's load order)
 void launch_maxpool3x3s2(const float* in, float* out, int B, int H, int W, int C, int out_cs, hipStream_t s);
 // x2 bilinear upsample, align_corners=True, NHWC (hrnet.py:440).
 void launch_bilinear_up2x(const float* in, float* out, int B, int H, int W, int C, hipStream_t s);
