@@ -106,6 +106,8 @@ int poco_create(const char* variant, int max_batch, int num_flow_layers, poco_ha
  *   xdep, tail_lanes, up_lanes = 0           the more conservative lane schedules;  seq_phases = <bit mask>, branch_lanes = "0123"
  *   split_f16 = 1                            EXPERIMENT, only in libraries built with `python -m poco_amd.build --experiments` (an unknown
  *                                            key in the shipped one): plain 1x1 convs in split fp16
+ *   debug_wait_spins = <n>, debug_mlp_timeouts = <n>   TEST HOOKS for poco_status: poll bound of the in-kernel waits (default 2^21 polls,
+ *                                            ~3 s) / the first n launches of the fused regressor time out on purpose
  *   flow_ctx_rows = <n>                      context rows poco_realnvp*'s scratch is planned for at finalize (default max_batch)
  *   record_kinematic = 0|1, record_thr = <f> post-processing of poco_outputs_t.record's confidence (defaults 1, 0.40)
  * Unknown keys are an error. */
@@ -126,6 +128,21 @@ int poco_load_tensor(poco_handle_t h, const char* name, const float* host_data, 
 int poco_finalize(poco_handle_t h);
 /* Enqueue one forward pass for B <= max_batch crops on `stream`.  No allocation, no sync. */
 int poco_forward(poco_handle_t h, int B, const poco_inputs_t* in, const poco_outputs_t* out, void* stream);
+
+/* Deferred failures of the forwards enqueued since the last call.  poco_forward only ENQUEUES; two of its kernels contain bounded waits
+ * (the grid barrier of the fused CLIFF regressor, csrc/mlp_chain.hip, and the partial hand-off of the stream-K 1x1 GEMM, ALG 14): one
+ * that runs out ends its launch early - the queue stays alive, the outputs of that forward are invalid - and raises a word in pinned
+ * host memory.  Call this AFTER synchronising the stream (or the event) the forward, or the hipGraph replay of it, was enqueued on and
+ * BEFORE trusting its outputs:
+ *   POCO_OK       nothing timed out;
+ *   POCO_ERR_HIP  a wait timed out (poco_last_error says so).  The word is CLEARED and the device-side state re-armed: the next
+ *                 poco_forward / graph replay runs normally.
+ * Without this call the failure is still not silent for ever: the next poco_forward refuses to enqueue (POCO_ERR_HIP) until
+ * poco_status has been asked - but the forward that failed has already returned POCO_OK, and a hipGraph replay never re-enters
+ * poco_forward, so bindings must ask here (poco_amd/model.py POCO.check_status; tester.py and stream.py do before results are
+ * written).  Cost on the good path: one read of host memory.  Replaces nothing in the reference (PyTorch raises from the
+ * synchronising call); SURVEY.md 8(b): "int status codes, never throw". */
+int poco_status(poco_handle_t h);
 
 /* Independent branches of the network (HRNet branches, fuse terms, head branches) are enqueued on up
  * to 4 HIP streams forked from / joined to `stream` (default 4; 1 = everything on `stream`). */
@@ -184,10 +201,11 @@ int poco_op_conv2d(const float* d_in, int B, int H, int W, int Cin, const float*
                    const float* d_res, int relu, float* d_out, const int* cfg7, void* stream);
 
 /* Time `iters` launches of the same conv (+ReLU) with hipEvents; ms_out = mean ms per launch.
- * cfg_used6 (nullable) receives the tile configuration that ran. */
+ * cfg_used7 (nullable) receives the tile configuration that ran: SEVEN ints {MT,NT,WM,WN,R,NI,ALG} (csrc/common.h
+ * CONV_CFG_INTS) - the caller's array must hold 7. */
 int poco_bench_conv2d(const float* d_in, int B, int H, int W, int Cin, const float* h_weight, int Cout,
                       int ks, int stride, float* d_out, const int* cfg7, int iters, float* ms_out,
-                      int* cfg_used6, void* stream);
+                      int* cfg_used7, void* stream);
 
 /* Part-attention pooling == pocolib/models/layers/keypoint_attention.py:34-48 (KeypointAttention.forward with
  * use_conv = False, softmax over the pixels) as pare_head.py:794-796 calls it (heat-map channel 0 = background is skipped):
@@ -227,9 +245,10 @@ int poco_crop_normalize_f64(const unsigned char* d_frame, int H, int W, const do
 int poco_crop_normalize_multi(const unsigned char* const* d_frames, int nframes, const int* d_frame_idx, int H, int W,
                               const float* d_boxes, int N, double bbox_scale, int res, float* d_out, void* stream);
 
-/* Time `ncfg` tile configurations (6 ints each; MT<=0 = heuristic) for one conv shape on random
- * data; ms_out[i] < 0 = configuration invalid for this shape.  Used by poco_amd/tune.py. */
-int poco_tune_conv(int B, int H, int W, int Cin, int Cout, int ks, int stride, const int* cfgs6, int ncfg,
+/* Time `ncfg` tile configurations (cfgs7 = ncfg x SEVEN ints {MT,NT,WM,WN,R,NI,ALG} each, csrc/common.h CONV_CFG_INTS;
+ * MT<=0 = heuristic) for one conv shape on random data; ms_out[i] < 0 = configuration invalid for this shape.  NULL cfgs7 /
+ * ms_out, ncfg < 1 or channel counts that are not multiples of 16 are POCO_ERR_ARG.  Used by poco_amd/tune.py. */
+int poco_tune_conv(int B, int H, int W, int Cin, int Cout, int ks, int stride, const int* cfgs7, int ncfg,
                    int iters, float* ms_out, void* stream);
 
 #ifdef __cplusplus

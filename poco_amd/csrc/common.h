@@ -90,6 +90,7 @@ struct ConvDesc {
   float* sk_scratch = nullptr;            // ALG 14 (gemm1x1sk.hip): flags + partial accumulators (gemm1x1sk_scratch_floats), zeroed once by the owner
   size_t sk_scratch_floats = 0;
   unsigned* sk_err_host = nullptr;        // ... and the pinned host word its bounded waits raise
+  unsigned sk_max_spins = 0;              // poll bound of those waits (0 = 2^21)
   // ALG 11 chaining (engine only): the previous conv already left this conv's V in scratch half `wg_vsel`; this conv leaves the
   // next conv's V in the other half (wg_mid_kernel) and writes its own output tensor only if somebody else still reads it
   int wg_skip_in = 0, wg_vsel = 0, wg_emit_next = 0, wg_store_y = 1;

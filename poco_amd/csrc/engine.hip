@@ -119,6 +119,8 @@ struct EngineOpts {
   std::string branch_lanes = "0123";   // HR branch i runs on lane branch_lanes[i]
   int wg_max_plane = 8;    // ALG 11 (F(4x4) as 36 position GEMMs, V / M staged in memory) is offered for planes up to this size (<= 16)
   int flow_ctx_rows = 0;   // context rows the RealNVP scratch is planned for at finalize (0 = max_batch: one context per crop)
+  int debug_wait_spins = 0;    // TEST HOOKS for poco_status (tests/test_model_gpu.py): poll bound of the in-kernel waits (0 = 2^21 polls ~ 3 s) ...
+  int debug_mlp_timeouts = 0;  // ... and: the first n launches of the fused regressor leave one block out of their first grid barrier, i.e. time out
   int rec_kinematic = 1;   // poco_outputs_t.record: kinematic accumulation of the per-joint uncertainty (KINEMATIC_UNCERT)
   float rec_thr = 0.40f;   // ... and the sensitivity threshold of get_global_uncert (poco_utils.py:50)
 };
@@ -155,6 +157,8 @@ static bool parse_opts(const char* str, EngineOpts* o, std::string* err) {
     else if (k == "branch_lanes") o->branch_lanes = v;
     else if (k == "flow_ctx_rows") o->flow_ctx_rows = atoi(v.c_str());
     else if (k == "wg_max_plane") o->wg_max_plane = std::min(16, std::max(1, atoi(v.c_str())));
+    else if (k == "debug_wait_spins") o->debug_wait_spins = std::max(0, atoi(v.c_str()));
+    else if (k == "debug_mlp_timeouts") o->debug_mlp_timeouts = std::max(0, atoi(v.c_str()));
     else if (k == "record_kinematic") o->rec_kinematic = on;
     else if (k == "record_thr") o->rec_thr = (float)atof(v.c_str());
     else { *err = "unknown engine option '" + k + "'"; return false; }
@@ -199,7 +203,8 @@ struct Engine {
   int uncert_feat_dim = 0;
   float* sk_scratch[4] = {};          // ALG 14 (stream-K 1x1 GEMM): flags + partials, one buffer per lane
   unsigned* mlp_sync = nullptr;       // OP_MLP: grid-barrier counters (device) ...
-  unsigned* mlp_err_host = nullptr;   // ... and the sticky time-out word (pinned host memory the kernels can write; shared with ALG 14)
+  unsigned* mlp_err_host = nullptr;   // ... and the time-out word (pinned host memory the kernels can write; shared with ALG 14): poco_status reads and clears it
+  int mlp_timeouts_left = 0;          // test hook (option debug_mlp_timeouts)
   std::string err;
 
   ~Engine() {
@@ -876,7 +881,8 @@ constexpr int XU_DIM = 3296;                                   // PARE uncert in
 
 void build_smpl(Builder& b) {
   Engine& e = b.e;
-  const int V = 6890;
+  constexpr int V = 6890;
+  static_assert(V <= SMPL_MAX_V, "smpl_joints_kernel's unrolled vertex rounds (kernels.h SMPL_JOINTS_ITERS) must cover the body model");
   const HostParam* vt = b.P("smpl.v_template", {V, 3});
   const HostParam* sd = b.P("smpl.shapedirs", {V, 3, 10});
   const HostParam* pd = b.P("smpl.posedirs", {207, V * 3});
@@ -1440,7 +1446,7 @@ int run_op(Engine& e, Op& op, int B, const IO& io, hipStream_t s) {
       d.out = aptr(e, op.out); d.out_cs = ao.C; d.out_co = 0;
       d.wfrag = op.wdev; d.bias = op.bdev; d.wfrag_wino = op.wdev_wino; d.wfrag_wino4 = op.wdev_wino4; d.wfrag_wino4p = op.wdev_wino4p; d.wfrag_wino4w = op.wdev_wino4w;
       d.wfrag_wino4g = op.wdev_wino4g; d.scratch = e.wino4g_scratch[op.lane & 3]; d.scratch_floats = e.wino4g_scratch_need;
-      d.sk_scratch = e.sk_scratch[op.lane & 3]; d.sk_scratch_floats = gemm1x1sk_scratch_floats(); d.sk_err_host = e.mlp_err_host;
+      d.sk_scratch = e.sk_scratch[op.lane & 3]; d.sk_scratch_floats = d.sk_scratch ? gemm1x1sk_scratch_floats() : 0; d.sk_err_host = e.mlp_err_host; d.sk_max_spins = (unsigned)e.opts.debug_wait_spins;
       d.B = B; d.H = ai.H; d.W = ai.W; d.Cin = op.Cin; d.Cout = op.Cout; d.ks = op.ks; d.stride = op.stride;
       d.act = op.actfn; d.res_after_act = op.res_after; d.relu_from = op.relu_from;
       auto it = op.cfg.find(B);
@@ -1534,6 +1540,8 @@ int run_op(Engine& e, Op& op, int B, const IO& io, hipStream_t s) {
     case OP_MLP: {
       MlpProgram p{};
       p.B = B; p.sync = e.mlp_sync; p.err_host = e.mlp_err_host;
+      p.max_spins = (unsigned)e.opts.debug_wait_spins;
+      if (e.mlp_timeouts_left > 0) { --e.mlp_timeouts_left; p.debug_skip_arrival = 1; }
       int nl = 0, nr = 0, last = -1;
       for (const Op& su : op.sub) {
         if (su.stage < last || su.stage >= MLP_MAX_STAGES) { poco_set_error("forward: " + op.name + ": sub-ops out of stage order"); return POCO_ERR_STATE; }
@@ -1712,6 +1720,7 @@ extern "C" int poco_load_tensor(poco_handle_t h, const char* name, const float* 
   return POCO_OK;
 }
 
+static int ensure_sk_scratch(Engine* e, int lane);
 extern "C" int poco_finalize(poco_handle_t h) {
   Engine* e = H(h);
   if (!e) return POCO_ERR_ARG;
@@ -1748,10 +1757,13 @@ extern "C" int poco_finalize(poco_handle_t h) {
       POCO_HIP_CHECK(hipMalloc(&e->mlp_sync, 1024));
       POCO_HIP_CHECK(hipMemset(e->mlp_sync, 0, 1024));
     }
-  for (int k = 0; k < 4; ++k) {          // ALG 14: flags (zero between launches) + partial accumulators, per lane
-    POCO_HIP_CHECK(hipMalloc(&e->sk_scratch[k], gemm1x1sk_scratch_floats() * sizeof(float)));
-    POCO_HIP_CHECK(hipMemset(e->sk_scratch[k], 0, (size_t)SK_MAX_WAVES * sizeof(float)));
-  }
+  e->mlp_timeouts_left = e->opts.debug_mlp_timeouts;
+  // (ALG 14's flags + partials - 33 MB per lane - are allocated when a stream-K configuration is first accepted for an op of that
+  // lane: ensure_sk_scratch; configurations set before finalize get theirs here)
+  for (const Op& op : e->ops)
+    for (const auto& kv : op.cfg)
+      if (kv.second.ALG == 14)
+        if (int rc = ensure_sk_scratch(e, op.lane)) return rc;
   POCO_HIP_CHECK(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
   for (Op& op : e->ops)
     if (op.wait_mask) {
@@ -1846,6 +1858,40 @@ static int sized_struct_copy(const T* src, T* dst, const char* what) {
   return POCO_OK;
 }
 
+// ALG 14 (stream-K 1x1 GEMM): flags (zero between launches) + partial accumulators of the lane the op runs on, allocated when the first
+// stream-K configuration is accepted for an op of that lane (poco_set_conv_cfg: before any forward / graph capture that could use it) -
+// engines whose table holds no ALG 14 entry (every HRNet-PARE engine, the 8-engines-on-one-GPU rehearsal) never pay the 134 MB.
+static int ensure_sk_scratch(Engine* e, int lane) {
+  float*& q = e->sk_scratch[lane & 3];
+  if (q) return POCO_OK;
+  POCO_HIP_CHECK(hipMalloc(&q, gemm1x1sk_scratch_floats() * sizeof(float)));
+  POCO_HIP_CHECK(hipMemset(q, 0, (size_t)SK_MAX_WAVES * sizeof(float)));
+  return POCO_OK;
+}
+
+// See include/poco_hip.h.  The in-kernel waits (grid barrier of the fused regressor, partial hand-off of the stream-K GEMM) are bounded; one
+// that runs out raises a word in pinned host memory and its launch ends early - outputs invalid, queue alive.  The caller synchronises the
+// stream and asks here: the word is read AND cleared, and whatever the aborted launch may have left behind on the device (stream-K flags still
+// raised, the regressor's arrival counters if blocks left in different stages) is re-armed, so that the next forward is a normal one.
+extern "C" int poco_status(poco_handle_t h) {
+  Engine* e = H(h);
+  if (!e) { poco_set_error("poco_status: bad handle"); return POCO_ERR_ARG; }
+  if (!e->finalized || !e->mlp_err_host) return POCO_OK;
+  volatile unsigned* w = reinterpret_cast<volatile unsigned*>(e->mlp_err_host);
+  if (*w == 0u) return POCO_OK;
+  // nothing of this engine may be running while the device state is reset: the documented contract is "after a stream synchronise"; make it
+  // true here rather than trust it (this is the failure path, not the hot path)
+  POCO_HIP_CHECK(hipDeviceSynchronize());
+  *w = 0u;
+  if (e->mlp_sync) POCO_HIP_CHECK(hipMemset(e->mlp_sync, 0, 1024));
+  for (float* q : e->sk_scratch)
+    if (q) POCO_HIP_CHECK(hipMemset(q, 0, (size_t)SK_MAX_WAVES * sizeof(float)));
+  poco_set_error("poco_status: a bounded in-kernel wait (grid barrier of the fused regressor, mlp_chain.hip, or partial hand-off of a stream-K GEMM, "
+                 "ALG 14) timed out since the last call: the outputs of the forwards enqueued since then are INVALID.  The engine has been re-armed "
+                 "and can run again; if it recurs, build it with the option mlp_fuse=0 / a table without ALG 14 entries");
+  return POCO_ERR_HIP;
+}
+
 extern "C" int poco_forward(poco_handle_t h, int B, const poco_inputs_t* in, const poco_outputs_t* out, void* stream) {
   Engine* e = H(h);
   if (!e || !in || !out) { poco_set_error("poco_forward: bad arguments"); return POCO_ERR_ARG; }
@@ -1856,8 +1902,9 @@ extern "C" int poco_forward(poco_handle_t h, int B, const poco_inputs_t* in, con
   if (!e->finalized) { poco_set_error("poco_forward: call poco_finalize first"); return POCO_ERR_STATE; }
   if (B < 1 || B > e->max_batch) { poco_set_error("poco_forward: batch " + std::to_string(B) + " outside 1.." + std::to_string(e->max_batch)); return POCO_ERR_ARG; }
   if (e->mlp_err_host && *reinterpret_cast<volatile unsigned*>(e->mlp_err_host)) {
+    // (a caller that never asks poco_status still cannot run on top of an aborted forward unnoticed)
     poco_set_error("poco_forward: a bounded wait of the fused regressor (mlp_chain.hip) or of a stream-K GEMM (ALG 14) timed out in an earlier "
-                   "forward - its outputs are invalid; rebuild the engine with the option mlp_fuse=0 / without ALG 14 table entries");
+                   "forward - its outputs are invalid; synchronise the stream and call poco_status(), which reports it and re-arms the engine");
     return POCO_ERR_HIP;
   }
   hipStream_t caller = (hipStream_t)stream;
@@ -1927,6 +1974,7 @@ extern "C" int poco_profile_ops(poco_handle_t h, int B, const poco_inputs_t* in,
       POCO_HIP_CHECK(hipEventRecord(ev[i + 1], s));
     }
     POCO_HIP_CHECK(hipStreamSynchronize(s));
+    if (int rc = poco_status(h)) return rc;      // a timed-out wait makes the times (and outputs) of this pass meaningless
     if (it == 0) continue;   // warm-up
     for (int i = 0; i < n; ++i) { float ms = 0; POCO_HIP_CHECK(hipEventElapsedTime(&ms, ev[i], ev[i + 1])); acc[i] += ms; }
   }
@@ -1962,6 +2010,8 @@ extern "C" int poco_set_conv_cfg(poco_handle_t h, int op_index, int B, const int
     poco_set_error("poco_set_conv_cfg: configuration does not fit op '" + op.name + "' at this batch size");
     return POCO_ERR_ARG;
   }
+  if (c.ALG == 14 && e->finalized)
+    if (int rc = ensure_sk_scratch(e, op.lane)) return rc;
   e->ops[op_index].cfg[B] = c;
   return POCO_OK;
 }

@@ -37,6 +37,7 @@ struct SKParams {
   float* part;           // [nwaves][MT * NT][64] float4
   unsigned* flag;        // [nwaves], zero between launches
   unsigned* err_host;    // pinned host word: a wait timed out
+  unsigned max_spins;    // poll bound of a wait
 };
 
 __device__ __forceinline__ float4 sk_ld4(const float* p) {
@@ -213,9 +214,13 @@ gemm1x1sk_kernel(const SKParams p) {
       unsigned spins = 0;
       while (__hip_atomic_load(&p.flag[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
         __builtin_amdgcn_s_sleep(1);
-        if (++spins > (1u << 21)) { ok = false; break; }
+        if (++spins > p.max_spins) { ok = false; break; }
       }
       if (!ok) break;
+      // ordering made explicit: the partial loads below are relaxed agent-scope accesses like the flag poll, so nothing in
+      // the language keeps the compiler from hoisting them above the poll - this barrier does (the hardware issues them in program
+      // order and the producer's s_waitcnt vmcnt(0) ordered its side; no cache maintenance is wanted: all of it bypasses the L2s)
+      asm volatile("" ::: "memory");
       const float* slot = reinterpret_cast<const float*>(p.part) + ((size_t)v * MT * NT * 64 + lane) * 4;
 #pragma unroll
       for (int m = 0; m < MT; ++m)
@@ -291,6 +296,7 @@ int gemm1x1sk_launch(const ConvDesc& d, const ConvCfg& cfg, hipStream_t stream) 
   p.flag = reinterpret_cast<unsigned*>(d.sk_scratch);
   p.part = d.sk_scratch + SK_MAX_WAVES;
   p.err_host = d.sk_err_host;
+  p.max_spins = d.sk_max_spins ? d.sk_max_spins : (1u << 21);
   const dim3 grid(blocks), block(cfg.WM * 64);
   // cfg.NI: 1 = hipcc's order; 3 = a load per 4 MFMAs from the start of the slice; 6 = per 4 at its end (gemm1x1.hip g1_sched)
 #define SK_CASE(mt, nt, dd) if (cfg.MT == mt && cfg.NT == nt && cfg.R == dd) { \

@@ -88,12 +88,19 @@ struct MlpProgram {
   int nstages, B;
   unsigned* sync;            // device, 1 KiB: arrival counters (mlp_chain.hip); zero before the first launch, re-armed by the kernel
   unsigned* err_host;        // pinned host word (device-visible): set when a grid barrier timed out
+  unsigned max_spins;        // bound of a barrier's poll loop (0 = the default, 2^21 polls ~ 3 s); engine option debug_wait_spins
+  int debug_skip_arrival;    // test hook (engine option debug_mlp_timeouts): block 0 does not arrive at the first barrier, i.e. every block times out
   long long* trace;          // nullable (tools/probe/mlp_probe.hip): block 0 writes wall_clock64() at the start, after each stage's jobs and after each barrier
 };
 int mlp_chain_grid(const MlpProgram& p, int max_blocks);
 int launch_mlp_chain(const MlpProgram& p, int max_blocks, hipStream_t s);
+// blocks of mlp_chain_kernel the device can hold at once (CUs x blocks per CU, queried once): the hand-rolled grid barrier needs
+// every block of the grid resident
+int mlp_chain_resident_blocks();
 
 // ---- SMPL (kernels_smpl.hip) -------------------------------------------------------------------------
+constexpr int SMPL_JOINTS_ITERS = 7;                     // smpl_joints_kernel: 1024 threads x this many hard-unrolled vertex rounds ...
+constexpr int SMPL_MAX_V = SMPL_JOINTS_ITERS * 1024;     // ... i.e. body models of up to 7168 vertices (SMPL: 6890); larger ones are refused at load time
 constexpr int SMPL_KB = 220;   // K of the blend GEMM: 207 pose + 10 shape + 1 template, padded to a multiple of 4
 struct SmplDev {
   int V;                       // 6890

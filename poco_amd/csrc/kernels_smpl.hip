@@ -79,6 +79,8 @@ smpl_chain_kernel(SmplDev m, SmplIO io, int B) {
 constexpr int SKIN_CH = 28;
 __global__ void __launch_bounds__(512)
 smpl_skin_kernel(SmplDev m, SmplIO io, int B) {
+  // 64 crops x 24 affines of 12 floats = 73.7 KB of the CU's 160 KB (this file is built for gfx950 only: poco_amd/build.py ARCH)
+  static_assert(sizeof(float) * 64 * 288 <= 160 * 1024, "smpl_skin_kernel: the 64-crop affine tile must fit the LDS of a gfx950 CU");
   __shared__ __attribute__((aligned(16))) float As[64][288];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -167,7 +169,7 @@ smpl_joints_kernel(SmplDev m, SmplIO io, int B) {
   // vertices tid, tid + 1024, ...: all 12 loads of an iteration are independent of the previous one's - unrolled so that they are
   // requested together (a rolled loop is 7 dependent memory round trips per crop); past-the-end lanes re-read vertex V - 1 with weight 0
 #pragma unroll
-  for (int it = 0; it < 7; ++it) {
+  for (int it = 0; it < SMPL_JOINTS_ITERS; ++it) {     // (V <= SMPL_MAX_V is checked where the body model is loaded)
     const int vv = tid + it * 1024;
     const int v = min(vv, m.V - 1);
     const float keep = vv < m.V ? 1.f : 0.f;

@@ -96,6 +96,7 @@ mlp_chain_kernel(const MlpProgram p) {
   // on that) count on their own word, the last of a group bumps the global one: 2.9 instead of 3.9 us at 256 blocks
   const unsigned grp = blockIdx.x & 7u, ngrp = min((unsigned)G, 8u), ngrp_blocks = ((unsigned)G - grp + 7u) / 8u;
   unsigned target = 0, grp_target = 0;
+  const unsigned max_spins = p.max_spins ? p.max_spins : (1u << 21);
   int nt_trace = 0;
   auto stamp = [&]() { if (p.trace && blockIdx.x == 0 && threadIdx.x == 0) p.trace[nt_trace++] = wall_clock64(); };
   stamp();
@@ -212,7 +213,7 @@ mlp_chain_kernel(const MlpProgram p) {
     target += ngrp; grp_target += ngrp_blocks;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's (write-through) stores of the stage are acknowledged
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0 && !(p.debug_skip_arrival && s == 0 && blockIdx.x == 0)) {
       const unsigned old = __hip_atomic_fetch_add(&p.sync[16 + 16 * grp], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (old + 1 == grp_target) __hip_atomic_fetch_add(&p.sync[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -222,7 +223,9 @@ mlp_chain_kernel(const MlpProgram p) {
       unsigned spins = 0;
       while (ld_agent(&p.sync[0]) < target) {
         __builtin_amdgcn_s_sleep(1);
-        if (++spins > (1u << 21)) { good = 0; break; }
+        // bounded: a time-out (or another block's: checked every 256 polls, so that one late block does not cost every stage its own
+        // full wait) ends the launch with the error word raised instead of a hung queue
+        if (++spins > max_spins || ((spins & 255u) == 0u && ld_agent(&p.sync[2]))) { good = 0; break; }
       }
       if (!good) {
         __hip_atomic_store(&p.sync[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -261,6 +264,15 @@ int mlp_chain_grid(const MlpProgram& p, int max_blocks) {
   return std::max(1, std::min(need, max_blocks));
 }
 
+int mlp_chain_resident_blocks() {
+  static int cached = 0;
+  if (cached > 0) return cached;
+  int per_cu = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mlp_chain_kernel, MLP_WAVES * 64, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+  cached = std::max(1, poco_num_cus() * per_cu);
+  return cached;
+}
+
 int launch_mlp_chain(const MlpProgram& p, int max_blocks, hipStream_t s) {
   if (p.nstages < 1 || p.nstages > MLP_MAX_STAGES || p.B < 1 || !p.sync) { poco_set_error("mlp_chain: bad program"); return POCO_ERR_ARG; }
   for (int st = 0; st < p.nstages; ++st) {
@@ -269,7 +281,9 @@ int launch_mlp_chain(const MlpProgram& p, int max_blocks, hipStream_t s) {
       poco_set_error("mlp_chain: stage " + std::to_string(st) + " out of range"); return POCO_ERR_ARG;
     }
   }
-  const int grid = mlp_chain_grid(p, max_blocks);
+  // every block of the grid must be resident at once: clamp to what THIS device holds - a partitioned / smaller part
+  // (CPX: 32 CUs) would otherwise spin every barrier into its time-out.  Results do not depend on the grid (fixed-order reductions).
+  const int grid = mlp_chain_grid(p, std::min(max_blocks, mlp_chain_resident_blocks()));
   hipLaunchKernelGGL(mlp_chain_kernel, dim3(grid), dim3(MLP_WAVES * 64), 0, s, p);
   POCO_HIP_CHECK(hipGetLastError());
   return POCO_OK;

@@ -140,13 +140,13 @@ extern "C" int poco_op_conv2d(const float* d_in, int B, int H, int W, int Cin, c
 
 extern "C" int poco_bench_conv2d(const float* d_in, int B, int H, int W, int Cin, const float* h_weight,
                                  int Cout, int ks, int stride, float* d_out, const int* cfg7, int iters,
-                                 float* ms_out, int* cfg_used6, void* stream) {
-  if (cfg_used6) {
+                                 float* ms_out, int* cfg_used7, void* stream) {
+  if (cfg_used7) {
     ConvDesc d{};
     d.B = B; d.H = H; d.W = W; d.Cin = Cin; d.Cout = Cout; d.ks = ks; d.stride = stride;
     ConvCfg c = (cfg7 && cfg7[0] > 0) ? conv_cfg_from(cfg7) : conv_default_cfg(d);
-    cfg_used6[0] = c.MT; cfg_used6[1] = c.NT; cfg_used6[2] = c.WM;
-    cfg_used6[3] = c.WN; cfg_used6[4] = c.R;  cfg_used6[5] = c.NI; cfg_used6[6] = c.ALG;
+    cfg_used7[0] = c.MT; cfg_used7[1] = c.NT; cfg_used7[2] = c.WM;
+    cfg_used7[3] = c.WN; cfg_used7[4] = c.R;  cfg_used7[5] = c.NI; cfg_used7[6] = c.ALG;
   }
   return conv_common(d_in, B, H, W, Cin, h_weight, nullptr, nullptr, Cout, ks, stride, nullptr, 1, d_out,
                      cfg7, iters, ms_out, (hipStream_t)stream);
@@ -154,10 +154,10 @@ extern "C" int poco_bench_conv2d(const float* d_in, int B, int H, int W, int Cin
 
 // Time a list of tile configurations for one conv shape (weights/activations allocated and filled
 // here once).  ms_out[i] < 0 marks a configuration that is invalid for the shape.
-extern "C" int poco_tune_conv(int B, int H, int W, int Cin, int Cout, int ks, int stride, const int* cfgs6,
+extern "C" int poco_tune_conv(int B, int H, int W, int Cin, int Cout, int ks, int stride, const int* cfgs7,
                               int ncfg, int iters, float* ms_out, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  if (!cfgs6 || !ms_out || ncfg < 1 || Cin % 16 || Cout % 16) {
+  if (!cfgs7 || !ms_out || ncfg < 1 || Cin % 16 || Cout % 16) {
     poco_set_error("poco_tune_conv: bad arguments");
     return POCO_ERR_ARG;
   }
@@ -174,13 +174,13 @@ extern "C" int poco_tune_conv(int B, int H, int W, int Cin, int Cout, int ks, in
   for (auto& v : hb) v = rnd() * 0.1f;
   DevBuf din, dw, db, dout, dwu, dwu4, dwu4g, dscr;
   bool any11 = false;
-  for (int i = 0; i < ncfg; ++i) any11 = any11 || cfgs6[CONV_CFG_INTS * i + 6] == 11;
+  for (int i = 0; i < ncfg; ++i) any11 = any11 || cfgs7[CONV_CFG_INTS * i + 6] == 11;
   if (ks == 3 && stride == 1) {
     std::vector<float> hu((size_t)16 * Cin * Cout);
     for (auto& v : hu) v = rnd() * ws;
     POCO_HIP_CHECK(dwu.upload(hu));
     bool any7 = false;
-    for (int i = 0; i < ncfg; ++i) any7 = any7 || cfgs6[CONV_CFG_INTS * i + 6] == 7 || cfgs6[CONV_CFG_INTS * i + 6] == 8 || cfgs6[CONV_CFG_INTS * i + 6] == 13;
+    for (int i = 0; i < ncfg; ++i) any7 = any7 || cfgs7[CONV_CFG_INTS * i + 6] == 7 || cfgs7[CONV_CFG_INTS * i + 6] == 8 || cfgs7[CONV_CFG_INTS * i + 6] == 13;
     if (any7) {
       std::vector<float> hu4((size_t)36 * Cin * Cout + 2 * 9 * 256);          // (+ the slack ALG 13 reads behind the last n-tile)
       for (auto& v : hu4) v = rnd() * ws;
@@ -205,7 +205,7 @@ extern "C" int poco_tune_conv(int B, int H, int W, int Cin, int Cout, int ks, in
   }
   DevBuf dsk;
   bool any14 = false;
-  for (int i = 0; i < ncfg; ++i) any14 = any14 || cfgs6[CONV_CFG_INTS * i + 6] == 14;
+  for (int i = 0; i < ncfg; ++i) any14 = any14 || cfgs7[CONV_CFG_INTS * i + 6] == 14;
   if (any14) {                                            // stream-K 1x1 GEMM: flags (zero) + partials, the pinned error word
     static unsigned* sk_err = nullptr;
     if (!sk_err) { POCO_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&sk_err), 64, hipHostMallocMapped)); *sk_err = 0; }
@@ -217,7 +217,7 @@ extern "C" int poco_tune_conv(int B, int H, int W, int Cin, int Cout, int ks, in
   }
   DevBuf dwh;
   bool any12 = false;
-  for (int i = 0; i < ncfg; ++i) any12 = any12 || cfgs6[CONV_CFG_INTS * i + 6] == 12;
+  for (int i = 0; i < ncfg; ++i) any12 = any12 || cfgs7[CONV_CFG_INTS * i + 6] == 12;
 #if POCO_EXPERIMENTS
   if (any12 && ks == 1 && Cin % 32 == 0) {               // split-fp16 experiment: timing only, hi / lo halves of random weights
     std::vector<float> hw2((size_t)Cout * Cin), ph(gemm1x1h_packed_floats(Cin, Cout));
@@ -232,7 +232,7 @@ extern "C" int poco_tune_conv(int B, int H, int W, int Cin, int Cout, int ks, in
   POCO_HIP_CHECK(hipEventCreate(&e0));
   POCO_HIP_CHECK(hipEventCreate(&e1));
   for (int i = 0; i < ncfg; ++i) {
-    const int* c = cfgs6 + CONV_CFG_INTS * i;
+    const int* c = cfgs7 + CONV_CFG_INTS * i;
     ConvCfg cfg = conv_cfg_from(c);
     if (c[0] <= 0) cfg = conv_default_cfg(d);
     ms_out[i] = -1.f;

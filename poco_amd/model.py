@@ -60,6 +60,7 @@ def _bind():
     L.poco_load_tensor.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int]
     L.poco_finalize.argtypes = [C.c_void_p]
     L.poco_forward.argtypes = [C.c_void_p, C.c_int, C.POINTER(_Inputs), C.POINTER(_Outputs), C.c_void_p]
+    L.poco_status.argtypes = [C.c_void_p]
     L.poco_num_ops.argtypes = [C.c_void_p]
     L.poco_op_sched.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_int]
     L.poco_op_info.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_size_t, C.POINTER(C.c_double), C.POINTER(C.c_int)]
@@ -351,6 +352,18 @@ class POCO:
         res["log_phi"] = None
         res["gt_pose_cond_idx"] = []
         return res
+
+    def check_status(self, sync: bool = False) -> None:
+        """poco_status (include/poco_hip.h): raises PocoHipError if a bounded in-kernel wait (grid barrier of the fused regressor,
+        stream-K hand-off) timed out in a forward since the last call - the outputs of those forwards are invalid; the engine is
+        re-armed and usable again afterwards.  Call it after the stream / event the forward (or graph replay) ran on has been
+        synchronised and before its outputs are used; `sync=True` synchronises the current stream first.  `model(batch)` and
+        `graph_forward` only enqueue, exactly like the reference's `self.model(batch)` on a CUDA device, so they cannot check
+        themselves; tester.py and stream.py call this before results are written."""
+        if sync:
+            torch.cuda.current_stream().synchronize()
+        if self._finalized:
+            check(self._L.poco_status(self._h), "poco_status")
 
     def release_graphs(self) -> None:
         """Drop every captured hipGraph of graph_forward."""

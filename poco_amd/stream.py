@@ -142,7 +142,7 @@ class CropStream:
     def run(self, groups: Sequence[Tuple[int, np.ndarray]], host_buf: int = 0,
             keep: Sequence[int] = ()) -> Tuple[torch.Tensor, int]:
         """Crops + forward + packed record D2H (async).  Returns (pinned host records, n); the caller must
-        torch.cuda.current_stream().synchronize() (or wait on its own event) before reading them.
+        torch.cuda.current_stream().synchronize() (or wait on its own event) and then call check() before reading them.
         `host_buf` (0/1) selects the pinned staging buffers of this run; alternate it between consecutive runs that
         are in flight together.  `keep`: ring slots whose frame a later run() will crop from again (a frame with more
         people than fit into this batch); all other slots in `groups` become free for upload() once this run's
@@ -156,6 +156,12 @@ class CropStream:
             for slot, _ in groups:
                 if slot not in keep:
                     self._pending[slot] = False
+
+    def check(self) -> None:
+        """Call after the event / stream synchronise that makes a run()'s records readable and BEFORE using them: raises if a bounded
+        in-kernel wait timed out in one of the forwards since the last check (poco_status, include/poco_hip.h) - a graph replay never
+        re-enters poco_forward, so nothing else would report it.  One read of host memory on the good path."""
+        self.m.check_status()
 
     def _run(self, groups, host_buf, keep):
         st = torch.cuda.current_stream()

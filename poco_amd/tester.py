@@ -137,6 +137,7 @@ class POCOTester:
             # one D2H per tensor postprocess() reads (not uncert_feat / body_feat2 / pose6d / cam_t: MBs per batch that nothing
             # downstream uses), sliced per frame below
             out = {n: v.cpu() for n, v in out.items() if torch.is_tensor(v) and n not in DEVICE_ONLY_KEYS}
+            self.model.check_status()          # (the copies above synchronised the stream) a timed-out in-kernel wait = invalid rows: raise, write nothing
             off = 0
             for e, lo, k in pieces:
                 sl = {n: (v[off:off + k] if torch.is_tensor(v) else v) for n, v in out.items()}
@@ -205,6 +206,7 @@ class POCOTester:
             batch = {k: torch.cat([b[k] for b in pend_batches], 0) for k in pend_batches[0]}
             out = self.model(batch, want_segm=False)
             host = {k: out[k].cpu().numpy() for k in keys}
+            self.model.check_status()          # after the synchronising copies, before the rows are stored
             for row, (pid, slot) in enumerate(pend_meta):
                 for k in keys:
                     store[pid][k][slot] = host[k][row]

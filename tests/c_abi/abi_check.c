@@ -15,6 +15,8 @@ typedef int (*num_tensors_fn)(poco_handle_t);
 typedef int (*tensor_info_fn)(poco_handle_t, int, char*, size_t, int64_t*, int*, int*);
 typedef int (*load_tensor_fn)(poco_handle_t, const char*, const float*, const int64_t*, int);
 typedef int (*forward_fn)(poco_handle_t, int, const poco_inputs_t*, const poco_outputs_t*, void*);
+typedef int (*tune_fn)(int, int, int, int, int, int, int, const int*, int, int, float*, void*);
+typedef int (*status_fn)(poco_handle_t);
 
 int main(int argc, char** argv) {
   if (argc < 2) return 2;
@@ -29,6 +31,9 @@ int main(int argc, char** argv) {
   forward_fn forward = (forward_fn)dlsym(so, "poco_forward");
   create_ex_fn create_ex = (create_ex_fn)dlsym(so, "poco_create_ex");
   version_fn version = (version_fn)dlsym(so, "poco_abi_version");
+  tune_fn tune = (tune_fn)dlsym(so, "poco_tune_conv");
+  status_fn status = (status_fn)dlsym(so, "poco_status");
+  if (!tune || !status) return 4;
   if (!last_error || !create || !destroy || !num_tensors || !tensor_info || !load_tensor || !forward || !create_ex || !version) return 4;
   if (version() != POCO_ABI_VERSION) { fprintf(stderr, "library ABI %d, header ABI %d\n", version(), POCO_ABI_VERSION); return 15; }
 
@@ -63,10 +68,19 @@ int main(int argc, char** argv) {
   if (forward(h, 1, &in, &out, 0) != 3) return 22;
   in.struct_size = sizeof(uint64_t);                                                          /* too short to hold even `img` */
   if (forward(h, 1, &in, &out, 0) != 1 || !strstr(last_error(), "poco_inputs_t.struct_size")) return 23;
+  if (status(h) != 0) return 26;                                                              /* nothing ran, nothing timed out */
   destroy(h);
+  {
+    /* a tile configuration is SEVEN ints {MT,NT,WM,WN,R,NI,ALG} (the header said six until round 5: a client written from it
+     * under-allocated by one int per configuration); the argument check runs before anything touches a GPU */
+    int cfgs7[2 * 7] = {4, 2, 2, 2, 8, 1, 1, 4, 2, 2, 2, 8, 1, 0};
+    float ms[2] = {0.f, 0.f};
+    if (tune(1, 8, 8, 15, 16, 3, 1, cfgs7, 2, 1, ms, 0) != 1 || !strstr(last_error(), "poco_tune_conv")) return 24;   /* Cin % 16 != 0 */
+    if (tune(1, 8, 8, 16, 16, 3, 1, cfgs7, 0, 1, ms, 0) != 1) return 25;                                               /* ncfg < 1 */
+  }
   if (create_ex("resnet50-cliff", 4, 1, "no_such_option=1", &h) == 0) return 16;     /* unknown build option is an error ... */
   if (strstr(last_error(), "no_such_option") == 0) return 17;                         /* ... that names it */
-  if (create_ex("resnet50-cliff", 4, 1, "dual=0,flow_ctx_rows=96", &h) != 0) return 18;
+  if (create_ex("resnet50-cliff", 4, 1, "dual=0,flow_ctx_rows=96,debug_wait_spins=1000,debug_mlp_timeouts=1", &h) != 0) return 18;
   if (num_tensors(h) != n) return 19;                                                 /* the separate-launch form consumes the same tensors */
   destroy(h);
   printf("ok %d\n", n);

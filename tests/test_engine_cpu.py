@@ -150,6 +150,25 @@ def test_binding_field_lists_match_the_header():
         assert struct().struct_size == 8 * len(names)                  # filled in by the constructor
 
 
+def test_header_states_seven_ints_per_tile_configuration():
+    """the header documented poco_tune_conv's `cfgs6` as "6 ints each" and poco_bench_conv2d's `cfg_used6` while the
+    library reads / writes CONV_CFG_INTS = 7 per configuration - a C client written from the header under-allocated (OOB read, 4-byte
+    overflow).  Every configuration parameter is named cfg*7 now, and the number in the name is the number the library uses."""
+    import re
+    root = Path(__file__).resolve().parent.parent
+    hdr = (root / "include" / "poco_hip.h").read_text()
+    n = int(re.search(r"constexpr int CONV_CFG_INTS = (\d+);", (root / "poco_amd" / "csrc" / "common.h").read_text()).group(1))
+    assert n == 7
+    params = re.findall(r"\bint\s*\*\s*(cfg\w*)", hdr)
+    assert len(params) >= 6 and all(p.endswith(str(n)) for p in params), params
+    assert "6 ints" not in hdr and "cfgs6" not in hdr and "cfg_used6" not in hdr
+    assert "SEVEN ints" in hdr
+    capi = (root / "poco_amd" / "csrc" / "ops_capi.hip").read_text()
+    assert "cfgs6" not in capi and "cfg_used6" not in capi
+    from poco_amd import ops
+    assert "* 7" in Path(ops.__file__).read_text() or "7)" in Path(ops.__file__).read_text()
+
+
 def test_forward_refuses_structs_without_a_valid_size_word():
     """the size word is checked before anything else is read (and before the finalize check, so no GPU is needed)"""
     from poco_amd.model import _Inputs, _Outputs

@@ -152,6 +152,10 @@ def test_folder_mode_cross_image_batching_host_logic():
 
         def __init__(self):
             self.calls = []
+            self.status_checks = 0
+
+        def check_status(self, sync=False):                       # poco_status: asked once per forward, after the D2H copies
+            self.status_checks += 1
 
         def __call__(self, batch, want_segm=False):
             n = batch["img"].shape[0]
@@ -176,6 +180,7 @@ def test_folder_mode_cross_image_batching_host_logic():
             assert np.array_equal(r["tag"], np.array([100 * i + j for j in range(people[i])], np.float32))
             assert np.array_equal(r["tag"], r["cx"]) and (r["wh"] == (20 + i) * 1000 + 10 + i).all()
     assert t.model.calls == [4, 4, 4, 4]                       # 16 crops: four full forwards instead of five per-image ones
+    assert t.model.status_checks == 4                          # ... each followed by one poco_status query before its rows are used
     # a generator input is consumed lazily: a result comes out as soon as its frame's last crop has been regressed
     t.model.calls.clear()
     seen = []
