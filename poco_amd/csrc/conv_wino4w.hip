@@ -1,29 +1,40 @@
-// ALG 13 (round 5): Winograd F(4x4,3x3) on the fp32 MFMA with WHOLE-POSITION MFMA waves - no exchange, no item start
-// (3x3 stride-1 convs on planes >= 14x14; pocolib/models/backbone/hrnet.py:42-58, hrnet_cls.py BasicBlock convs).
+// ALG 13: Winograd F(4x4,3x3) on the fp32 MFMA with WHOLE-POSITION MFMA waves (round 5) whose weights go STRAIGHT INTO REGISTERS
+// (round 6) - no exchange, no item start, no U ring (3x3 stride-1 convs on planes >= 14x14; pocolib/models/backbone/hrnet.py:42-58,
+// hrnet_cls.py BasicBlock convs, resnet.py:101-121 conv2).
 //
 // ALG 8 (conv_wino4p.hip) splits the 36 Winograd positions of a 16-tile group over four MFMA waves (9 positions x NT n-tiles
 // each: 108 accumulators at the 168-register budget of a 12-wave block), so the output transform A^T M A needs all four
-// waves: NT exchange rounds through LDS per item (8 ds_write_b128 + 8 ds_read_b128 + ~110 VALU per wave and round, two
-// block-wide barriers each), an exchange area that overlays the V buffers and U ring - so the next item's first slices can
-// only be prepared after the rounds - and the s_memtime traces of round 5 put 12-13 k clk of exchange + 2-7 k clk of item
-// start next to 33 k clk of K loop on the 56x56 48->48 launch (43 % of a launch is fixed cost).
-//
-// Here a block is 2 NT + 2 waves (NT = 3: eight, i.e. two per SIMD and a 256-register budget):
-//   * MFMA wave (grp, n) owns ALL 36 positions of one 16-tile group for ONE 16-channel n-tile: 36 accumulators (144
-//     registers), per 4-channel slice nine quads of { ds_read_b128 V, ds_read_b128 U, 4 MFMAs }.  Its output transform
-//     A^T M A is register-only, it applies bias / residual / ReLU and stores its 4x4 pixel blocks itself: no exchange, no
-//     barrier, no LDS traffic at the end of an item.
-//   * producer wave pw = the input transform V = B^T d B of group pw, all 36 positions per (tile, channel) lane, the packed-fp32
-//     scheme of ALG 8 (15 ds_read2_b32 window reads, ~72 v_pk_* instructions, 9 ds_write_b128 in the pair order of the
-//     results, slot swizzle w4p_sigma).
-//   * the slice pipeline is CONTINUOUS ACROSS ITEMS: global slice t = (item k, slice s) uses U ring slot t % 3, raw ring slot
-//     t % 3 and V buffer t & 1; at slice t the MFMA waves request U(t + 2) and raw(t + 4) and the producers build V(t + 1) and
-//     read the window of slice t + 2 - whichever item those belong to.  One barrier per slice, nothing else: an item boundary
-//     costs the MFMA waves their register-only epilogue and nobody a pipeline refill.  (Padding positions of a patch differ
-//     from item to item: the wave that requests the first three slices of an item also zero-fills the padding lanes of the ring
-//     slots they go to.)
+// waves: NT exchange rounds through LDS per item and an exchange area that overlays the V buffers and U ring (VERDICT r4 weak #2:
+// 43 % of a launch was fixed cost).  Here a block of 8 waves (two per SIMD, a 256-register budget) is
+//   * 2 NT MFMA waves: wave (grp, n) owns ALL 36 positions of one 16-tile group for ONE 16-channel n-tile: 36 accumulators (144
+//     registers), per 4-channel slice nine quads of { ds_read_b128 V, 4 MFMAs, global_load_dwordx4 U of the next slice }.  Its
+//     output transform A^T M A is register-only, it applies bias / residual / ReLU and stores its 4x4 pixel blocks itself: no
+//     exchange, no barrier, no LDS traffic at the end of an item.
+//   * 2 producer waves: pw = the input transform V = B^T d B of group pw, all 36 positions per (tile, channel) lane, in packed fp32
+//     (15 ds_read2_b32 window reads, ~72 v_pk_* instructions, 9 ds_write_b128 in the pair order of the results, slot swizzle
+//     w4p_sigma).  NT = 3: both on SIMD 3 (wave ids 3 and 7), which carries no MFMA wave, and they also request the raw patch;
+//   * NT = 2: two more waves (ids 6, 7 = SIMDs 2 / 3) that do nothing but request the raw patch (LDS-DMA), so that every SIMD
+//     carries one MFMA wave + one helper.
+//   * the slice pipeline is CONTINUOUS ACROSS ITEMS: global slice t = (item k, slice s) uses raw ring slot t % RD and V buffer
+//     t & 1; at slice t the requesters ask for raw(t + RD + 1), the producers build V(t + 1) and read the window of slice t + 2,
+//     and the MFMA waves request U(t + 1) quad by quad - whichever item those belong to.  One barrier per slice, nothing else.
+//     (Padding positions of a patch differ from item to item: whoever requests the first RD slices of an item also zero-fills the
+//     padding lanes of the ring slots they go to.)
 //   * items are walked n-group-innermost (item = m * nb_n + n-group): the n-groups of one tile strip run on neighbouring
 //     blocks of one XCD at the same time and read their patch from one L2.
+//
+// Round 6, what the s_memtime trace of the round-5 kernel showed (tools/w4w_trace.py; 56x56 48->48, NT = 3, clk per slice): the MFMA
+// waves were done issuing after 1190 (older wave of a SIMD) / 1900 clk (younger) and then sat 1600-2300 clk at the slice barrier -
+// waiting for the PRODUCERS, whose chain per slice was ~1500 clk of LDS-DMA requests (20 one-KiB pieces each, 13.5 of them U) + 650-900
+// of transform + 330 of window reads + 330 of vmcnt wait = ~3100 clk on a SIMD of their own.  Handing the U requests to the MFMA waves
+// instead does not help (+1 ... +5 %: every LDS-DMA piece blocks the MFMA pipe of its SIMD for ~47 clk).  But the U stream does not
+// need the LDS at all: the packed fragments of a (slice, n-tile) ARE the A operands of one MFMA wave - nine float4 per lane, one
+// contiguous KiB per quad - and nobody else uses them except the same-n wave of the other tile group (an L1 / L2 hit).  So every
+// MFMA wave loads its nine quads with global_load_dwordx4 straight into the registers its MFMAs read: no U ring (81 KB of LDS), no U
+// requests (27 of a slice's 41 LDS-DMA pieces), nine instead of 18 ds_read_b128 per wave and slice.  Same box, us per launch, 64
+// crops: 56x56 48->48 48.7 -> 46.9 (flat items 50.0 -> 47.5), 28x28 96->96 44.8 -> 41.9 (46.1 -> 42.6), 14x14 192->192 71.4 -> 64.7,
+// 56x56 480->128 840 -> 807.  The freed LDS buys a 4-deep raw ring (a request has three slices to land instead of two: the producers'
+// 330-400 clk of vmcnt wait per slice).
 //
 // Weights: U = G g G^T in float64 on the host (BN scale folded), packed per (4-channel slice, n-tile) as one 9 KiB block of nine
 // quads [q][64 lanes] float4, lane = (co & 15) + 16 (ci & 3), quad q / element i = position (w4w_row, w4w_nu) - the order in
@@ -37,31 +48,23 @@ using w4::at_c;
 
 #include "conv_wino4p_geo.h"
 
-#ifndef W4W_DMAW
-#define W4W_DMAW 9    // who requests the LDS-DMA of the coming slices (see W4WDuty)
-#endif
-
 #ifndef W4W_EXP
-#define W4W_EXP 0     // timing probes (results are garbage): 1 no LDS-DMA in the K loop, 2 producers skip transform + window reads, 4 MFMA waves
-#endif                // skip their operand reads, 8 MFMA waves skip the MFMAs
-#ifndef W4W_DMALAST
-#define W4W_DMALAST 0     // (1: 72.5 vs 71.6 us on 14x14 192->192, 855 vs 803 on 480->128 - the requests need their two slices to land)
-#endif
-#ifndef W4W_WIN2
-#define W4W_WIN2 0
-#endif
-#ifndef W4W_GATHER
-#define W4W_GATHER 1  // raw pieces requested as one exec-masked asm block per issuer (w4::dma_gather); 0 = one dma16_sv per piece
-#endif
+#define W4W_EXP 0     // timing probes (results are garbage): 1 no patch LDS-DMA in the K loop, 2 producers skip transform + window reads, 4 MFMA waves
+#endif                // skip their operand reads, 8 MFMA waves skip the MFMAs, 16 MFMA waves skip their U loads
 #ifndef W4W_PF
-#define W4W_PF 4      // operand quads requested ahead of the MFMAs that use them (PF + 1 register sets of 8).  Same box, us per launch on the
-                      // five solo shapes: PF 2 47.5 / 46.8 / 77.5 / 86.7 / 881, PF 4 46.9 / 46.3 / 77.0 / 84.1 / 868, PF 6 48.3 / 47.5 / 78.6 / 87.3 / 890, PF 8 (spills) 52.8 / ...
+#define W4W_PF 4      // V operand quads requested ahead of the MFMAs that use them (PF + 1 register sets of 4)
 #endif
-#ifndef W4W_HOLD
-#define W4W_HOLD 0    // quads of a slice whose MFMAs run behind the slice barrier (see the K loop): 2 is 1-2 % slower than 0 (registers)
+#ifndef W4W_RD
+#define W4W_RD 3      // depth of the raw-patch ring in LDS (3: a request has two slices to land, 4: three - measured 1-3 % slower per launch)
 #endif
-#ifndef W4W_LAYOUT
-#define W4W_LAYOUT 1
+#ifndef W4W_STATICNP
+#define W4W_STATICNP 1   // every requester issues exactly MAXP = 8 patch pieces per slice (pieces that do not exist go out with an empty exec
+#endif                   // mask: no traffic, but they count in vmcnt), so the landing waits are the constants vmcnt(0 / 8 / 16) instead of a dispatch on a run-time count
+#ifndef W4W_NT2LAYOUT
+#define W4W_NT2LAYOUT 0  // NT = 2 wave placement: 0 = one MFMA wave per SIMD, producers on SIMDs 0 / 1, requesters on 2 / 3; 1 = the MFMA waves paired on
+#endif                   // SIMDs 0 / 1 (ids 0, 1, 4, 5), producers (ids 2, 3) and requesters (ids 6, 7) on SIMDs 2 / 3, which carry no MFMA wave
+#ifndef W4W_DMAWAVES
+#define W4W_DMAWAVES 1   // NT = 2: two extra waves (SIMDs 2 / 3) request the raw patch; 0: the producers do (as at NT = 1 / 3)
 #endif
 #ifndef W4W_TRACE
 #define W4W_TRACE 0   // 1: block 0 sums s_memtime phases of its waves over its first item (tools/w4w_trace.py)
@@ -95,15 +98,20 @@ __host__ __device__ constexpr int w4w_slot(int xi, int nu) {
   return 4 * (3 * m + 2) + (nu == 1 ? 0 : nu == 3 ? 1 : nu == 2 ? 2 : 3);
 }
 
-__device__ __forceinline__ void w4w_wait_vm(int n) {     // s_waitcnt vmcnt(n), n wave-uniform, 0 .. 31
-#define W4W_WVM(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
-  switch (n) {
-    W4W_WVM(0) W4W_WVM(1) W4W_WVM(2) W4W_WVM(3) W4W_WVM(4) W4W_WVM(5) W4W_WVM(6) W4W_WVM(7) W4W_WVM(8) W4W_WVM(9) W4W_WVM(10) W4W_WVM(11)
-    W4W_WVM(12) W4W_WVM(13) W4W_WVM(14) W4W_WVM(15) W4W_WVM(16) W4W_WVM(17) W4W_WVM(18) W4W_WVM(19) W4W_WVM(20) W4W_WVM(21) W4W_WVM(22)
-    W4W_WVM(23) W4W_WVM(24) W4W_WVM(25) W4W_WVM(26) W4W_WVM(27) W4W_WVM(28) W4W_WVM(29) W4W_WVM(30) W4W_WVM(31)
-    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-  }
-#undef W4W_WVM
+// s_waitcnt vmcnt(n), n wave-uniform, 0 .. 16 (more: 0 = over-wait).  The count is an immediate, so this is a dispatch: as a dense
+// switch hipcc emitted a 32-way decision tree through condition-code copies (~300 clk per call on a producer's critical path, traced);
+// a hand-written binary tree is four scalar compares.
+__device__ __forceinline__ void w4w_wait_vm(int n) {
+#define W4W_W(k) asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory")
+  if (n < 8) {
+    if (n < 4) { if (n < 2) { if (n == 0) W4W_W(0); else W4W_W(1); } else { if (n == 2) W4W_W(2); else W4W_W(3); } }
+    else { if (n < 6) { if (n == 4) W4W_W(4); else W4W_W(5); } else { if (n == 6) W4W_W(6); else W4W_W(7); } }
+  } else if (n < 16) {
+    if (n < 12) { if (n < 10) { if (n == 8) W4W_W(8); else W4W_W(9); } else { if (n == 10) W4W_W(10); else W4W_W(11); } }
+    else { if (n < 14) { if (n == 12) W4W_W(12); else W4W_W(13); } else { if (n == 14) W4W_W(14); else W4W_W(15); } }
+  } else if (n == 16) W4W_W(16);
+  else W4W_W(0);
+#undef W4W_W
 }
 
 // y = A^T x for the six values x0 .. x5 of one transform row / column ([Lavin & Gray]: A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0;
@@ -130,52 +138,33 @@ __device__ __forceinline__ int w4w_item_id(const W4WParams& p, int it, int* ngro
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// LDS-DMA duty (global_load_lds_dwordx4) of the coming slices, shared by NW issuing waves: issuer dw takes raw pieces dw, dw + NW, ...
-// and U pieces dw, dw + NW, ... of every slice.  Who issues (W4W_DMAW): an LDS-DMA piece costs the issuing wave ~100 clk of issue
-// time and blocks the MFMA pipe of its SIMD for ~47 clk (s_memtime traces), and with 2 NT MFMA waves + 2 producers the
-// SIMDs are unevenly loaded - NT = 3: SIMDs 0 / 1 carry two MFMA waves (72 MFMAs = 2304 clk per slice, the floor of the kernel),
-// SIMDs 2 / 3 one MFMA wave + one producer.
+// wave roles.  Waves land on SIMD (wave id % 4).
+//   NT = 3: producers = wave ids 3 and 7, i.e. BOTH on SIMD 3, every other SIMD carries two MFMA waves (72 MFMAs = 2304 clk per slice, the
+//           floor of the kernel); the producers also request the patch (an LDS-DMA piece blocks the MFMA pipe of the SIMD it is issued from
+//           for ~47 clk - on SIMD 3 there is none).
+//   NT = 2: MFMA waves = ids 0 .. 3 (one per SIMD), producers = ids 4, 5 (SIMDs 0 / 1), patch requesters = ids 6, 7 (SIMDs 2 / 3).
+//   NT = 1: MFMA waves = ids 0, 1, producers = ids 2, 3 (their own SIMDs; they request the patch too).
 // ---------------------------------------------------------------------------------------------------------------------
-
-// WHO requests what (W4W_DMAW) and WHERE the producers sit (W4W_LAYOUT).  The 9 NT U pieces of a slice are dealt round-robin to
-// NWU issuers, the rawF4 / 64 patch pieces to NWR issuers; an issuer is an MFMA wave (by its MFMA index m = 0 .. 2 NT - 1) or a
-// producer.  Waves land on SIMD (wave id % 4):
-//   W4W_LAYOUT 0: MFMA waves = wave ids 0 .. 2 NT - 1, producers = the last two.  NT = 3: SIMDs 0 / 1 carry two MFMA waves, SIMDs 2 / 3
-//                 one MFMA wave + one producer.
-//   W4W_LAYOUT 1 (NT = 3 only): producers = wave ids 3 and 7, i.e. BOTH on SIMD 3, and every other SIMD carries two MFMA waves:
-//                 the MFMA work is balanced over three SIMDs (72 MFMAs = 2304 clk per slice each) and the producers' VALU / LDS /
-//                 LDS-DMA instructions have a SIMD of their own (fp32 MFMAs run on the SIMD's vector ALUs; an LDS-DMA piece blocks the
-//                 MFMA pipe of the SIMD it is issued from for ~47 clk - on SIMD 3 there is none).
-//   mode   U issuers                 raw issuers
-//   0      MFMA 2, 3 + producers     MFMA 2, 3 + producers
-//   1      all MFMA                  all MFMA
-//   6      producers                 all MFMA
-//   7      producers                 producers
-//   8      all MFMA                  producers
-//   9      NT = 3: mode 7 (the producers request everything: they own SIMD 3 in layout 1 and the three MFMA SIMDs do nothing but MFMAs and
-//          operand reads - 14x14 192->192 76.8 -> 71.3 us, 28x28 96->96 46.4 -> 44.5, 480->128 882 -> 807); NT < 3: mode 6 (the producers
-//          share their SIMDs with MFMA waves there: 56x56 64->64 83.7 us against 99.7 with mode 7)
-struct W4WPlan { int mu0, nmu, kpu, mr0, nmr, kpr; };
-template <int NT> constexpr W4WPlan w4w_plan() {
-  constexpr int M = 2 * NT;
-  if (W4W_DMAW == 1) return {0, M, 0, 0, M, 0};
-  if (W4W_DMAW == 6) return {0, 0, 1, 0, M, 0};
-  if (W4W_DMAW == 7) return {0, 0, 1, 0, 0, 1};
-  if (W4W_DMAW == 8) return {0, M, 0, 0, 0, 1};
-  if (W4W_DMAW == 9) return NT == 3 ? W4WPlan{0, 0, 1, 0, 0, 1} : W4WPlan{0, 0, 1, 0, M, 0};      // shipped: see the table above
-  if (NT == 1) return {0, 2, 1, 0, 2, 1};
-  return {2, 2, 1, 2, 2, 1};
-}
-template <int NT> constexpr int w4w_nwu() { return w4w_plan<NT>().nmu + 2 * w4w_plan<NT>().kpu; }
-template <int NT> constexpr int w4w_nwr() { return w4w_plan<NT>().nmr + 2 * w4w_plan<NT>().kpr; }
-// wave id -> role: producer index (0 / 1) or -1; MFMA index m
-template <int NT> __device__ __forceinline__ int w4w_producer_of(int wave) {
-  if constexpr (W4W_LAYOUT == 1 && NT == 3) return (wave & 3) == 3 ? wave >> 2 : -1;
-  return wave >= 2 * NT ? wave - 2 * NT : -1;
-}
-template <int NT> __device__ __forceinline__ int w4w_mfma_index(int wave) {
-  if constexpr (W4W_LAYOUT == 1 && NT == 3) return wave - (wave >> 2);
-  return wave;
+template <int NT> constexpr int w4w_dma_waves() { return (NT == 2 && W4W_DMAWAVES) ? 2 : 0; }
+template <int NT> constexpr int w4w_block_waves() { return 2 * NT + 2 + w4w_dma_waves<NT>(); }
+enum { W4W_ROLE_MFMA = 0, W4W_ROLE_PRODUCER = 1, W4W_ROLE_DMA = 2 };
+template <int NT> __device__ __forceinline__ int w4w_role(int wave, int* index) {
+  if constexpr (NT == 3) {
+    if ((wave & 3) == 3) { *index = wave >> 2; return W4W_ROLE_PRODUCER; }
+    *index = wave - (wave >> 2);
+    return W4W_ROLE_MFMA;
+  } else if constexpr (NT == 2 && W4W_NT2LAYOUT == 1 && w4w_dma_waves<2>() == 2) {
+    // a producer's VALU stream advances one instruction per MFMA while an MFMA wave of its SIMD is streaming (transform 1880 clk
+    // instead of 650, traced): keep the helpers off the MFMA SIMDs
+    if ((wave & 2) == 0) { *index = (wave & 1) + (wave >> 2) * 2; return W4W_ROLE_MFMA; }      // ids 0, 1, 4, 5 -> MFMA 0 .. 3
+    *index = wave & 1;
+    return wave < 4 ? W4W_ROLE_PRODUCER : W4W_ROLE_DMA;
+  } else {
+    if (wave < 2 * NT) { *index = wave; return W4W_ROLE_MFMA; }
+    if (wave < 2 * NT + 2) { *index = wave - 2 * NT; return W4W_ROLE_PRODUCER; }
+    *index = wave - 2 * NT - 2;
+    return W4W_ROLE_DMA;
+  }
 }
 
 // np (wave-uniform, 0 .. MAXN) gather pieces
@@ -188,35 +177,41 @@ __device__ __forceinline__ void w4w_gather_n(int np, const void* sbase, const un
   }
 }
 
-template <int NT, int FLAT>
-struct W4WDuty {
-  static constexpr int NWU = w4w_nwu<NT>(), NWR = w4w_nwr<NT>();
-  static constexpr int MAXP = (16 + NWR - 1) / NWR;                    // raw pieces per raw issuer (rawF4 <= 1024 slots)
-  static constexpr int NUP = (9 * NT + NWU - 1) / NWU;                 // U pieces per U issuer and slice
+// ---------------------------------------------------------------------------------------------------------------------
+// The raw-patch requests (LDS-DMA, global_load_lds_dwordx4), shared by two requesters: requester dw takes pieces dw, dw + 2, ... of every
+// slice, all of them in ONE exec-masked asm block (w4::dma_gather: padding lanes masked off).  A CURSOR (item, slice, ring slot) walks
+// the global slice sequence RD + 1 slices ahead of the MFMAs: RD slices before the first barrier, one behind the second (the window of
+// slice 0 has been read by then), one per slice from there on - raw(t + RD + 1) goes to the slot of raw(t + 1), whose window was read
+// during slice t - 1.  Its window is read during slice t + RD - 1, so it must have landed at the barrier that ends slice t + RD - 2:
+// at the end of a slice the requests of the last RD - 2 slices may still be in flight (wait()).
+// ---------------------------------------------------------------------------------------------------------------------
+template <int FLAT>
+struct W4WRaw {
+  static constexpr int NW = 2, MAXP = 8, RD = W4W_RD;      // (rawF4 <= 1024 slots = 16 pieces)
+  static_assert(RD == 3 || RD == 4, "raw ring depth");
   int goff[MAXP];
-  bool live[MAXP];
-  unsigned long long lmask[MAXP];                                       // lanes of a piece that carry an in-image position
-  int dwu, dwr;                                                         // this wave's index among the U / raw issuers, -1 = none (wave-uniform)
-  // the patch of item `it`: global float offsets of this issuer's raw pieces (lane = slot inside the piece), -1 = padding
-  __device__ __forceinline__ void setup(const W4WParams& pp, int it, int lane) {
-    if (dwr < 0) return;
+  unsigned long long lmask[MAXP];                           // lanes of a piece that carry an in-image position
+  int dw, it, s, slot, step, end, prev;
+  __device__ __forceinline__ void setup(const W4WParams& pp, int lane) {      // the patch of item `it`: global float offsets of this requester's pieces
     int ng;
     const int id = w4w_item_id(pp, it, &ng);
-    raw_piece_offsets<MAXP, FLAT>(pp.g, id, dwr, NWR, lane, goff);
+    raw_piece_offsets<MAXP, FLAT>(pp.g, id, dw, NW, lane, goff);
 #pragma unroll
-    for (int k = 0; k < MAXP; ++k) { lmask[k] = __ballot(goff[k] >= 0); live[k] = lmask[k] != 0ull; }
+    for (int k = 0; k < MAXP; ++k) lmask[k] = __ballot(goff[k] >= 0);
   }
-  // 4-channel slice c4 of the patch -> raw ring slot; zero = also clear the padding lanes of the slot (first use by this item)
-  __device__ __forceinline__ int issue_raw(const W4PParams& p, float4* smem, int lane, int c4, int slot, bool zero) const {
-    if (dwr < 0) return 0;
-    const int dw = dwr;
-    constexpr int NW = NWR;
-    int cnt = 0;
+  __device__ __forceinline__ void init(const W4WParams& pp, const Walk& wk, int dw_, int lane) {
+    dw = dw_; it = wk.first; s = 0; slot = 0; step = wk.step; end = wk.end; prev = 0;
+    setup(pp, lane);
+  }
+  // the cursor's slice -> its ring slot; returns the number of requests (wave-uniform)
+  __device__ __forceinline__ int issue(const W4WParams& pp, float4* smem, int lane) {
+    if (it >= end) return 0;
+    const W4PParams& p = pp.g;
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) float4*)smem;
-    const float* sbase = p.in + (size_t)(c4 >> 2) * p.in_ss + (c4 & 3) * 4;
+    const float* sbase = p.in + (size_t)(s >> 2) * p.in_ss + (s & 3) * 4;
     const unsigned sb = lds_base + (unsigned)(slot * p.rawF4) * 16u;
     const int npieces_raw = p.rawF4 >> 6;
-    if (zero) {
+    if (s < RD) {                                           // first use of this slot by this item: clear its padding lanes
 #pragma unroll
       for (int k = 0; k < MAXP; ++k) {
         const int piece = dw + NW * k;
@@ -227,120 +222,104 @@ struct W4WDuty {
         }
       }
     }
-    if constexpr (W4W_GATHER != 0 && w4w_plan<NT>().nmr == 0) {
-      // (only where the producers alone request the patch: on the MFMA waves the always-issued empty pieces and exec switches cost
-      // more than the per-piece branches - 48.8 vs 47.4 us)
-      // all of this issuer's pieces in one (two) asm block(s); the number of pieces dw, dw + NW, ... < npieces_raw is wave-uniform
-      static_assert(MAXP <= 8, "at most 8 raw pieces per issuer");
-      unsigned voff[8];
-      unsigned long long mask[8];
+    unsigned voff[8];
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        voff[k] = k < MAXP ? (unsigned)goff[k] * 4u : 0u;
-        mask[k] = k < MAXP ? lmask[k] : 0ull;
-      }
-      const int np = dw < npieces_raw ? (npieces_raw - 1 - dw) / NW + 1 : 0;            // pieces of this issuer
-      const unsigned dst0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(sb + (unsigned)dw * 1024u));
-      w4w_gather_n<MAXP>(np, sbase, voff, mask, dst0, NW * 1024u);
-      return np;
-    }
-#pragma unroll
-    for (int k = 0; k < MAXP; ++k) {
-      const int piece = dw + NW * k;
-      if (piece < npieces_raw && live[k]) {
-        if (goff[k] >= 0)
-          w4::dma16_sv(sbase, (unsigned)goff[k] * 4u, (unsigned)__builtin_amdgcn_readfirstlane((int)(sb + (unsigned)piece * 1024u)));
-        ++cnt;
-      }
-    }
-    return cnt;
-  }
-  // U of slice c4, n-tiles nt0 .. nt0 + NT - 1 -> U ring slot.  The 9 NT one-KiB pieces of a (slice, n-group) are CONTIGUOUS in the
-  // packed fragments ([c4][n-tile][9 quads][64] float4), so piece i is base + i KiB: one 64-bit scalar add per piece.  An n-group that
-  // reaches beyond the tensor (Cout = 112: 7 n-tiles at NT = 3) reads on into the next slice's fragments / the slack behind the
-  // last one (conv_wino4w_packed_floats) - those waves' results are never stored.
-  __device__ __forceinline__ int issue_u(const W4PParams& p, float4* smem, int lane, int nt0, int c4, int slot) const {
-    if (dwu < 0) return 0;
-    const int dw = dwu;
-    constexpr int NW = NWU;
-    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) float4*)smem;
-    const unsigned dst0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds_base + (unsigned)(p.uoff + slot * NT * W4W_UBLK) * 16u + (unsigned)dw * 1024u));
-    const float4* src = p.ufrag + (((size_t)c4 * p.nT16 + nt0) * 9 + dw) * 64;
-    // pieces dw, dw + NW, ...: the first NUP - 1 exist for every issuer, the last one only while dw + NW (NUP - 1) < 9 NT
-    unsigned voff[7];
-#pragma unroll
-    for (int k = 0; k < 7; ++k) voff[k] = (unsigned)lane * 16u + (unsigned)(k * NW) * 1024u;
-    constexpr int NA = NUP <= 7 ? NUP : 7;                      // first call: up to 7 pieces
-    const bool full = dw + NW * (NUP - 1) < 9 * NT;             // (wave-uniform)
-    if constexpr (NUP <= 7) {
-      if (full) w4::dma_stream<NA>(src, voff, dst0, NW * 1024u);
-      else if constexpr (NA > 1) w4::dma_stream<(NA > 1 ? NA - 1 : 1)>(src, voff, dst0, NW * 1024u);
-      return full ? NUP : NUP - 1;
+    for (int k = 0; k < 8; ++k) voff[k] = (unsigned)goff[k] * 4u;
+    int np = dw < npieces_raw ? (npieces_raw - 1 - dw) / NW + 1 : 0;                  // pieces of this requester (a piece whose mask is empty still issues)
+    const unsigned dst0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(sb + (unsigned)dw * 1024u));
+    if constexpr (W4W_STATICNP != 0) {
+      np = MAXP;
+      if (!(W4W_EXP & 1)) w4::dma_gather<MAXP>(sbase, voff, lmask, dst0, NW * 1024u);
     } else {
-      static_assert(NUP <= 14, "two calls of up to 7 pieces");
-      w4::dma_stream<7>(src, voff, dst0, NW * 1024u);
-      constexpr int NB = NUP - 7;
-      const float4* src2 = src + (size_t)(7 * NW) * 64;
-      const unsigned dst2 = dst0 + 7u * NW * 1024u;
-      if (full) w4::dma_stream<NB>(src2, voff, dst2, NW * 1024u);
-      else if constexpr (NB > 1) w4::dma_stream<(NB > 1 ? NB - 1 : 1)>(src2, voff, dst2, NW * 1024u);
-      return full ? NUP : NUP - 1;
+      if (!(W4W_EXP & 1)) w4w_gather_n<MAXP>(np, sbase, voff, lmask, dst0, NW * 1024u);
     }
+    slot = slot + 1 == RD ? 0 : slot + 1;
+    if (++s == p.nC4) {
+      s = 0; it += step;
+      if (it < end) setup(pp, lane);
+    }
+    return (W4W_EXP & 1) ? 0 : np;
   }
-  // once per block, before P0: raw(0..2), U(0), U(1) of the first item
-  __device__ __forceinline__ void prologue(const W4WParams& pp, float4* smem, int lane, int it0) {
-    const W4PParams& p = pp.g;
-    setup(pp, it0, lane);
+  // s_waitcnt vmcnt(n) for a count of this requester
+  __device__ __forceinline__ static void wait_n(int n) {
+    if constexpr (W4W_STATICNP != 0) {                      // n is 0, MAXP or 2 MAXP
+      if (n == 2 * MAXP) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      else if (n == MAXP) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      static_assert(MAXP == 8, "the constants above");
+    } else w4w_wait_vm(n);
+  }
+  // Before the first barrier (P0): raw(0 .. RD - 1) requested, raw(0) and raw(1) landed (their windows are read between P0 and P1);
+  // before the second (P1): raw(2) landed (its window is read during slice 0).  Younger requests stay in flight - the cold start of
+  // a launch is a burst of RD slices per CU, and only the first two gate the first transform.
+  int n_pro[RD];
+  __device__ __forceinline__ void prologue(const W4WParams& pp, float4* smem, int lane) {
 #pragma unroll
-    for (int c = 0; c < 3; ++c)
-      if (c < p.nC4) issue_raw(p, smem, lane, c, c, true);
-    int ng0;
-    (void)w4w_item_id(pp, it0, &ng0);
-    issue_u(p, smem, lane, ng0 * NT, 0, 0);
-    if (p.nC4 > 1) issue_u(p, smem, lane, ng0 * NT, 1, 1);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    for (int c = 0; c < RD; ++c) n_pro[c] = issue(pp, smem, lane);
+    int young = 0;
+#pragma unroll
+    for (int c = 2; c < RD; ++c) young += n_pro[c];
+    wait_n(young);
   }
-  // global slice t = (item it, slice s): U(t + 2) -> slot r2 (of U(t - 1)); raw(t + 4) -> slot r1 (of raw(t + 1), whose window was read
-  // during slice t - 1) - of this item or of the next one, whose patch takes over at s = S - 4.  Returns the number of requests.
-  __device__ __forceinline__ int slice_requests(const W4WParams& pp, float4* smem, int lane, int it_next, bool hasB, int s, int r1,
-                                                int r2, int nt0A, int nt0B) {
-    const W4PParams& p = pp.g;
-    const int S = p.nC4;
-    int nvm = 0;
-    if (s + 2 < S) nvm += issue_u(p, smem, lane, nt0A, s + 2, r2);
-    else if (hasB) nvm += issue_u(p, smem, lane, nt0B, s + 2 - S, r2);
-    if (s + 4 == S && hasB) setup(pp, it_next, lane);
-    if (s + 4 < S) nvm += issue_raw(p, smem, lane, s + 4, r1, false);
-    else if (hasB) nvm += issue_raw(p, smem, lane, s + 4 - S, r1, s + 4 - S < 3);
-    return nvm;
+  __device__ __forceinline__ void prologue_p1(const W4WParams& pp, float4* smem, int lane) {     // between P0 and P1
+    int young = 0;
+#pragma unroll
+    for (int c = 3; c < RD; ++c) young += n_pro[c];
+    wait_n(young);
+  }
+  // behind P1: raw(RD) -> slot 0 (the window of slice 0 has been read)
+  __device__ __forceinline__ void after_p1(const W4WParams& pp, float4* smem, int lane) {
+    const int n = issue(pp, smem, lane);
+    // in flight now: raw(3 .. RD - 1) and raw(RD); the wait at the end of slice 0 allows raw(4 ..) = this batch (+ slice 0's own)
+    prev = n;
+  }
+  // end of a slice in which this wave made `nvm` requests: everything older than the last RD - 2 slices' requests has landed
+  __device__ __forceinline__ void wait(int nvm) {
+    if constexpr (RD == 3) wait_n(nvm);
+    else { wait_n(nvm + prev); prev = nvm; }
   }
 };
 
 // ---------------------------------------------------------------------------------------------------------------------
-// MFMA waves
+// MFMA waves.  U straight from memory into the A-operand registers: the register ring is IN PLACE - quad q of slice t + 1 is requested right
+// behind the four MFMAs that consumed quad q of slice t (an MFMA reads its A / B operands in its first passes, the load's data arrives
+// hundreds of clocks later), so exactly nine loads are in flight per wave and `s_waitcnt vmcnt(8)` in front of quad q means "quad q has
+// landed" (loads return in order; anything else this wave has in flight - the epilogue's loads and stores - was issued later or is
+// older, so the count can only over-wait).  The loads are inline asm: hipcc neither counts them nor drains them at the slice barrier,
+// which is a bare s_barrier here (the LDS reads of a slice are consumed by its MFMAs; __syncthreads() would add a vmcnt(0) behind every
+// item's stores).
 // ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void w4w_uload(f32x4& dst, const void* sbase, unsigned voff, int q) {
+  // quad q = byte offset q KiB: three lane-offset registers (+0 / +4 / +8 KiB) x immediate offsets 0 .. 3 KiB (13-bit signed field)
+#define W4W_UL(imm) asm volatile("global_load_dwordx4 %0, %1, %2 offset:" #imm : "+v"(dst) : "v"(voff), "s"(sbase))
+  switch (q & 3) { case 0: W4W_UL(0); break; case 1: W4W_UL(1024); break; case 2: W4W_UL(2048); break; default: W4W_UL(3072); break; }
+#undef W4W_UL
+}
+
 template <int NT, int FLAT>
 __device__ __forceinline__ void w4w_mfma_wave(const W4WParams& pp, float4* smem, int wave, int lane) {      // wave = MFMA index 0 .. 2 NT - 1
   const W4PParams& p = pp.g;
   const int grp = wave >= NT ? 1 : 0, nn = wave - grp * NT;           // (wave-uniform)
   const int idx = lane & 15, g = lane >> 4;
   const int vlane = w4p_sigma(idx, g);
-  constexpr W4WPlan plan = w4w_plan<NT>();
-  W4WDuty<NT, FLAT> duty;
-  duty.dwu = wave >= plan.mu0 && wave < plan.mu0 + plan.nmu ? wave - plan.mu0 : -1;
-  duty.dwr = wave >= plan.mr0 && wave < plan.mr0 + plan.nmr ? wave - plan.mr0 : -1;
-  const bool is_dma = duty.dwu >= 0 || duty.dwr >= 0;                  // (wave-uniform)
-  const int uF4 = NT * W4W_UBLK;
   const int S = p.nC4;
   const Walk wk = item_walk(p);
   if (wk.first >= wk.end) return;                                     // (whole block: every role takes the same exit)
 
-  if (is_dma) duty.prologue(pp, smem, lane, wk.first);
-  __syncthreads();                                        // P0: the first fetches have landed
+  // U(0) of the block's first item: nine one-KiB quads, lane * 16 B each (the packed fragments of a (slice, n-tile) are 9 KiB in a row)
+  f32x4 ur[9];
+  const unsigned uvo[3] = {(unsigned)lane * 16u, (unsigned)lane * 16u + 4096u, (unsigned)lane * 16u + 8192u};
+  {
+    int ng0;
+    (void)w4w_item_id(pp, wk.first, &ng0);
+    const float4* u0 = p.ufrag + (size_t)(ng0 * NT + nn) * W4W_UBLK;
+#pragma unroll
+    for (int q = 0; q < 9; ++q) { ur[q] = (f32x4){0.f, 0.f, 0.f, 0.f}; if (!(W4W_EXP & 16)) w4w_uload(ur[q], u0, uvo[q >> 2], q); }
+  }
+  __syncthreads();                                        // P0: the first patch slices have landed
   __syncthreads();                                        // P1: V(0) is written, the windows of slices 0 and 1 are in the producers' registers
-  if (is_dma && S > 3) duty.issue_raw(p, smem, lane, 3, 0, false);     // (the window of slice 0 has been read)
 
-  int ring = 0, vb = 0;                                   // global slice t: t % 3, t & 1
+  int vb = 0;                                             // global slice t: V buffer t & 1
   for (int it = wk.first; it < wk.end; it += wk.step) {
     const bool hasB = it + wk.step < wk.end;
     int ngA, ngB = 0;
@@ -354,7 +333,6 @@ __device__ __forceinline__ void w4w_mfma_wave(const W4WParams& pp, float4* smem,
     for (int q = 0; q < 9; ++q)
 #pragma unroll
       for (int i = 0; i < 4; ++i) acc[q][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float4 hu[W4W_HOLD > 0 ? W4W_HOLD : 1], hv[W4W_HOLD > 0 ? W4W_HOLD : 1];       // operands of the deferred quads
 
 #if W4W_TRACE
     const bool trace = blockIdx.x == 0 && it == wk.first;
@@ -362,57 +340,33 @@ __device__ __forceinline__ void w4w_mfma_wave(const W4WParams& pp, float4* smem,
 #endif
     for (int s = 0; s < S; ++s) {
       W4W_T(c0);
-      const int r1 = ring == 2 ? 0 : ring + 1, r2 = r1 == 2 ? 0 : r1 + 1;
-      int nvm = 0;
-      const float4* U = smem + p.uoff + ring * uF4 + nn * W4W_UBLK + lane;
       const float4* V = smem + p.voff + vb * (2 * W4W_UBLK) + grp * W4W_UBLK + vlane;
-      // Operands two quads ahead of the MFMAs that use them.  The MFMAs of the last W4W_HOLD quads of a slice are DEFERRED ACROSS THE
-      // SLICE BARRIER: their operands are read before it (the barrier protects the ring slots against the next requests, and it is
-      // the READS that must be over), the MFMAs themselves run behind it, while the first operands of the next slice are on their way -
-      // right after a barrier every wave of the block asks the LDS for operands at once, and the MFMA pipes used to idle through that
-      // round trip (~300 clk of a ~2900-clk slice on every SIMD).  The last slice of an item keeps nothing back (its accumulators go to
-      // the epilogue).
-      constexpr int PF = W4W_PF, NH = W4W_HOLD;
-      float4 ub[PF + 1], vq[PF + 1];
+      // U of global slice t + 1: the next slice of this item, slice 0 of the block's next item (an n-group that reaches beyond the tensor -
+      // Cout = 112: 7 n-tiles at NT = 3 - reads on into the next slice's fragments / the slack behind the last one,
+      // conv_wino4w_packed_floats: those waves' results are never stored), or - behind the block's very last slice - a reload of the current
+      // one that nobody uses (the number of loads in flight stays nine, so the vmcnt(8) below stays exact)
+      const float4* un = p.ufrag + (s + 1 < S ? (size_t)(s + 1) * p.nT16 + (nt0A + nn) : hasB ? (size_t)(nt0B + nn) : (size_t)s * p.nT16 + (nt0A + nn)) * W4W_UBLK;
+      constexpr int PF = W4W_PF;
+      float4 vq[PF + 1];
 #pragma unroll
-      for (int q = 0; q < PF; ++q) { ub[q] = (W4W_EXP & 4) ? make_float4(1.f, 2.f, (float)s, 3.f) : U[q * 64]; vq[q] = (W4W_EXP & 4) ? make_float4(1.f, 2.f, 3.f, (float)q) : V[q * 64]; }
-      // The LDS-DMA of the coming slices: requested while the first operands are on their way.
-      // U(t + 2) -> slot of U(t - 1); raw(t + 4) -> slot of raw(t + 1), whose window was read during slice t - 1.
-      if (is_dma) {
-        __builtin_amdgcn_sched_barrier(0);
-        if (!(W4W_EXP & 1)) nvm = duty.slice_requests(pp, smem, lane, it + wk.step, hasB, s, r1, r2, nt0A, nt0B);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      if (NH > 0 && s > 0) {
-#pragma unroll
-        for (int h = 0; h < NH; ++h)
-#pragma unroll
-          for (int i = 0; i < 4; ++i)
-            acc[9 - NH + h][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4c(hu[h], i), f4c(hv[h], i), acc[9 - NH + h][i], 0, 0, 0);
-      }
+      for (int q = 0; q < PF; ++q) vq[q] = (W4W_EXP & 4) ? make_float4(1.f, 2.f, 3.f, (float)q) : V[q * 64];
 #pragma unroll
       for (int q = 0; q < 9; ++q) {
-        if (q + PF < 9) {
-          ub[(q + PF) % (PF + 1)] = (W4W_EXP & 4) ? make_float4(1.f, (float)s, 2.f, 3.f) : U[(q + PF) * 64];
-          vq[(q + PF) % (PF + 1)] = (W4W_EXP & 4) ? make_float4(1.f, 2.f, 3.f, (float)q) : V[(q + PF) * 64];
-        }
-        const float4 u = ub[q % (PF + 1)], v = vq[q % (PF + 1)];
-        if (q < 9 - NH || s + 1 == S) {
+        if (q + PF < 9) vq[(q + PF) % (PF + 1)] = (W4W_EXP & 4) ? make_float4(1.f, 2.f, 3.f, (float)q) : V[(q + PF) * 64];
+        const float4 v = vq[q % (PF + 1)];
+        if (!(W4W_EXP & 16)) asm volatile("s_waitcnt vmcnt(8)" : "+v"(ur[q]));          // quad q of this slice has landed (eight younger loads may be in flight)
 #pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            if (W4W_EXP & 8) acc[q][i][0] += f4c(u, i) * f4c(v, i);
-            else acc[q][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4c(u, i), f4c(v, i), acc[q][i], 0, 0, 0);
-          }
-        } else {
-          hu[q - (9 - NH)] = u; hv[q - (9 - NH)] = v;
+        for (int i = 0; i < 4; ++i) {
+          if (W4W_EXP & 8) acc[q][i][0] += ur[q][i] * f4c(v, i);
+          else acc[q][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(ur[q][i], f4c(v, i), acc[q][i], 0, 0, 0);
         }
+        if (!(W4W_EXP & 16)) w4w_uload(ur[q], un, uvo[q >> 2], q);                        // ... and its registers take quad q of the next slice
       }
       W4W_T(c1);
-      if (is_dma) w4w_wait_vm(nvm);                       // what this wave requested BEFORE this slice has landed: U(t + 1), raw(t + 3)
-      ring = r1;
       vb ^= 1;
       W4W_T(c2);
-      __syncthreads();                                    // everybody is done with slice t; V(t + 1), U(t + 1), raw(t + 2) are in place
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // (the slice's LDS reads were consumed by its MFMAs: free)
+      __builtin_amdgcn_s_barrier();                       // everybody is done with slice t; V(t + 1), raw(t + 2) are in place
       __builtin_amdgcn_sched_barrier(0);
       W4W_T(c3);
       W4W_ACC(0, c0, c1); W4W_ACC(1, c1, c2); W4W_ACC(2, c2, c3);
@@ -497,7 +451,7 @@ __device__ __forceinline__ void w4w_mfma_wave(const W4WParams& pp, float4* smem,
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// producer waves: input transform V = B^T d B, all 36 positions of tile group pw
+// producer waves: input transform V = B^T d B, all 36 positions of tile group pw (+ the patch requests where no DMA waves exist)
 // ---------------------------------------------------------------------------------------------------------------------
 template <int NT, int FLAT>
 __device__ __forceinline__ void w4w_producer(const W4WParams& pp, float4* smem, int pw, int lane) {
@@ -507,6 +461,7 @@ __device__ __forceinline__ void w4w_producer(const W4WParams& pp, float4* smem, 
   const int vlane = w4p_sigma(idx, g);
   const int rawF4 = p.rawF4;
   const int S = p.nC4;
+  constexpr int RD = W4W_RD;
   const Walk wk = item_walk(p);
   if (wk.first >= wk.end) return;
 
@@ -524,14 +479,9 @@ __device__ __forceinline__ void w4w_producer(const W4WParams& pp, float4* smem, 
         w.woff[k][c] = (pos + (pos >> (FLAT ? 4 : 3))) * 4 + g;
       }
   };
-  // W4W_WIN2 = 1: TWO window register sets used alternately (by the parity of the global slice: no copies) - the window of slice t + 2 is
-  // requested at the top of slice t and its latency hides behind the transform of window t + 1.
   // (Tried in the first layout: TWO window register sets, the window of slice t + 2 requested at the top of slice t ahead of the transform of window
   // t + 1 - 3-7 % slower per launch: the 15 reads then queue in front of the MFMA waves' first operand reads of the slice.)
   f32x2 dA[6][3];
-#if W4W_WIN2
-  f32x2 dB[6][3];
-#endif
   auto load_window = [&](f32x2 (&d)[6][3], const Win& w, int rslot) __attribute__((always_inline)) {
     const float* rawf = reinterpret_cast<const float*>(smem + rslot * rawF4);
 #pragma unroll
@@ -577,91 +527,108 @@ __device__ __forceinline__ void w4w_producer(const W4WParams& pp, float4* smem, 
     }
   };
 
-  // this wave's share of the LDS-DMA duty (W4W_DMAW): issuer index behind the MFMA waves'
-  constexpr W4WPlan plan = w4w_plan<NT>();
-  constexpr bool kIssue = plan.kpu > 0 || plan.kpr > 0;
-  W4WDuty<NT, FLAT> duty;
-  duty.dwu = plan.kpu > 0 ? plan.nmu + pw : -1;
-  duty.dwr = plan.kpr > 0 ? plan.nmr + pw : -1;
+  constexpr bool kIssue = w4w_dma_waves<NT>() == 0;        // this wave requests the patch itself
+  W4WRaw<FLAT> raw;
   Win A, B;
   win_of(wk.first, A);
-  if constexpr (kIssue) duty.prologue(pp, smem, lane, wk.first);
-  __syncthreads();                                        // P0: raw(0..2), U(0..1) of the first item have landed
+  if constexpr (kIssue) { raw.init(pp, wk, pw, lane); raw.prologue(pp, smem, lane); }
+  __syncthreads();                                        // P0: raw(0), raw(1) of the first item have landed
   load_window(dA, A, 0);
   transform(dA, 0);
   if (S > 1) load_window(dA, A, 1);                       // dA = window of slice t + 1 at the top of slice t
+  if constexpr (kIssue) raw.prologue_p1(pp, smem, lane);  // raw(2) has landed
   __syncthreads();                                        // P1
-  if constexpr (kIssue) {
-    if (S > 3) duty.issue_raw(p, smem, lane, 3, 0, false);
-  }
-  // fp32 MFMAs run on the SIMD's vector ALUs: without a higher issue priority the MFMA wave of this SIMD starves this wave's
+  if constexpr (kIssue) raw.after_p1(pp, smem, lane);     // raw(RD) -> slot 0 (the window of slice 0 has been read)
+  // fp32 MFMAs run on the SIMD's vector ALUs: without a higher issue priority an MFMA wave of this SIMD starves this wave's
   // VALU / LDS instructions until it reaches the slice barrier
   __builtin_amdgcn_s_setprio(3);
-  int ring = 0, vb = 0;
+  int ring = 0, vb = 0;                                   // global slice t: t % RD, t & 1
   for (int it = wk.first; it < wk.end; it += wk.step) {
     const bool hasB = it + wk.step < wk.end;
     if (hasB) win_of(it + wk.step, B);
-    int ngA, ngB = 0;
-    (void)w4w_item_id(pp, it, &ngA);
-    if (hasB) (void)w4w_item_id(pp, it + wk.step, &ngB);
 #if W4W_TRACE
     const bool trace = blockIdx.x == 0 && it == wk.first;
-    unsigned long long tr[4] = {0, 0, 0, 0};
+    unsigned long long tr[5] = {0, 0, 0, 0, 0};
 #endif
     for (int s = 0; s < S; ++s) {
       W4W_T(q0);
-      const int r1 = ring == 2 ? 0 : ring + 1, r2 = r1 == 2 ? 0 : r1 + 1;
+      const int r1 = ring + 1 == RD ? 0 : ring + 1, r2 = r1 + 1 == RD ? 0 : r1 + 1;
       int nvm = 0;
-      if constexpr (kIssue && !W4W_DMALAST) { if (!(W4W_EXP & 1)) nvm = duty.slice_requests(pp, smem, lane, it + wk.step, hasB, s, r1, r2, ngA * NT, ngB * NT); }
+      if constexpr (kIssue) nvm = raw.issue(pp, smem, lane);          // raw(t + RD + 1) -> slot r1
+      W4W_T(qa);
       // V(t + 1) from the window fetched during the previous slice, then the window of slice t + 2 (raw(t + 2) landed before the
       // barrier that ended slice t - 1) - of this item or of the next one
       if (!(W4W_EXP & 2)) {
-#if W4W_WIN2
-      auto step = [&](f32x2 (&cur)[6][3], f32x2 (&nxt)[6][3]) __attribute__((always_inline)) {
-        if (s + 2 < S) load_window(nxt, A, r2);
-        else if (hasB) load_window(nxt, B, r2);
-        __builtin_amdgcn_sched_barrier(0);
-        if (s + 1 < S || hasB) transform(cur, vb ^ 1);
-      };
-      if (vb) step(dB, dA); else step(dA, dB);
-      W4W_T(q1);
-#else
-      if (s + 1 < S || hasB) transform(dA, vb ^ 1);
-      W4W_T(q1);
-      if (s + 2 < S) load_window(dA, A, r2);
-      else if (hasB) load_window(dA, B, r2);
-#endif
+        if (s + 1 < S || hasB) transform(dA, vb ^ 1);
       }
-      // W4W_DMALAST: the requests of the coming slices go out behind the window reads, whose latency (~650 clk under the MFMA waves'
-      // operand traffic) they cover - U(t + 2) / raw(t + 4) have two slices to land either way
-      if constexpr (kIssue && W4W_DMALAST) {
-        __builtin_amdgcn_sched_barrier(0);
-        if (!(W4W_EXP & 1)) nvm = duty.slice_requests(pp, smem, lane, it + wk.step, hasB, s, r1, r2, ngA * NT, ngB * NT);
+      W4W_T(q1);
+      if (!(W4W_EXP & 2)) {
+        if (s + 2 < S) load_window(dA, A, r2);
+        else if (hasB) load_window(dA, B, r2);
       }
-      if (kIssue) w4w_wait_vm(nvm);                       // what this wave requested BEFORE this slice has landed
+      W4W_T(qb);
+      if constexpr (kIssue) raw.wait(nvm);
       ring = r1;
       vb ^= 1;
       W4W_T(q2);
       __syncthreads();
       W4W_T(q3);
-      W4W_ACC(0, q0, q1); W4W_ACC(1, q1, q2); W4W_ACC(2, q2, q3);
+      W4W_ACC(0, q0, qa); W4W_ACC(1, qa, q1); W4W_ACC(2, q1, qb); W4W_ACC(3, qb, q2); W4W_ACC(4, q2, q3);
     }
 #if W4W_TRACE
-    if (trace && lane == 0) for (int k = 0; k < 3; ++k) g_w4w_trace[32 + 4 * pw + k] = tr[k];
+    if (trace && lane == 0) for (int k = 0; k < 5; ++k) g_w4w_trace[32 + 5 * pw + k] = tr[k];
 #endif
     if (hasB) A = B;
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// patch requesters (NT = 2): nothing but the LDS-DMA of the coming slices, in step with the block's barriers
+// ---------------------------------------------------------------------------------------------------------------------
+template <int NT, int FLAT>
+__device__ __forceinline__ void w4w_dma_wave(const W4WParams& pp, float4* smem, int dw, int lane) {
+  const W4PParams& p = pp.g;
+  const Walk wk = item_walk(p);
+  if (wk.first >= wk.end) return;
+  W4WRaw<FLAT> raw;
+  raw.init(pp, wk, dw, lane);
+  raw.prologue(pp, smem, lane);
+  __syncthreads();                                        // P0
+  raw.prologue_p1(pp, smem, lane);
+  __syncthreads();                                        // P1
+  raw.after_p1(pp, smem, lane);
+#if W4W_TRACE
+  unsigned long long tr[2] = {0, 0};
+  int nsl = 0;
+#endif
+  for (int it = wk.first; it < wk.end; it += wk.step)
+    for (int s = 0; s < p.nC4; ++s) {
+      W4W_T(d0);
+      const int nvm = raw.issue(pp, smem, lane);
+      W4W_T(d1);
+      raw.wait(nvm);
+      __syncthreads();
+      W4W_T(d2);
+#if W4W_TRACE
+      if (blockIdx.x == 0 && it == wk.first) { tr[0] += d1 - d0; tr[1] += d2 - d1; ++nsl; }
+#endif
+    }
+#if W4W_TRACE
+  if (blockIdx.x == 0 && lane == 0) { g_w4w_trace[48 + 2 * dw] = tr[0]; g_w4w_trace[49 + 2 * dw] = tr[1]; }
+#endif
+}
+
 template <int NT, int FLAT>      // FLAT: 0 rectangular items, 1 flat items
-__global__ void __launch_bounds__(128 * NT + 128)
+__global__ void __launch_bounds__(64 * w4w_block_waves<NT>())
 conv_wino4w_kernel(const W4WParams p) {
   extern __shared__ float4 smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int pw = w4w_producer_of<NT>(wave);
-  if (pw < 0) w4w_mfma_wave<NT, FLAT>(p, smem, w4w_mfma_index<NT>(wave), lane);
-  else w4w_producer<NT, FLAT>(p, smem, pw, lane);
+  int index;
+  const int role = w4w_role<NT>(wave, &index);
+  if (role == W4W_ROLE_MFMA) w4w_mfma_wave<NT, FLAT>(p, smem, index, lane);
+  else if (role == W4W_ROLE_PRODUCER) w4w_producer<NT, FLAT>(p, smem, index, lane);
+  else if constexpr (w4w_dma_waves<NT>() > 0) w4w_dma_wave<NT, FLAT>(p, smem, index, lane);
 }
 
 struct W4WLayout { int uoff, voff, totalF4; };
@@ -673,9 +640,8 @@ bool w4w_geo(const ConvDesc& d, const ConvCfg& cfg, w4::Geo* g, W4WLayout* L, Fl
   if (g->rawF4 > 1024) return false;
   // 32-bit byte offsets in the epilogue
   if ((long)d.B * d.H * d.W * std::max(std::max(d.in_cs, d.out_cs), d.res_cs) >= (1L << 30)) return false;
-  const int uF4 = cfg.NT * W4W_UBLK;
-  L->uoff = 3 * g->rawF4;
-  L->voff = L->uoff + 3 * uF4;
+  L->uoff = W4W_RD * g->rawF4;                                  // (no U ring: the MFMA waves load U into registers)
+  L->voff = L->uoff;
   L->totalF4 = L->voff + 4 * W4W_UBLK;
   return (size_t)L->totalF4 * sizeof(float4) <= 160 * 1024;
 }
@@ -719,8 +685,7 @@ int conv_wino4w_launch(const ConvDesc& d, const ConvCfg& cfg, hipStream_t stream
   const bool flat = cfg.NI == 0;
   if (!w4w_geo(d, cfg, &g, &L, &fg) || !d.wfrag_wino4w) {
     poco_set_error("conv(winograd 4x4, whole-position waves): needs ks = 3, stride 1, NT 1..3, WM = 2, WN = 1, R % 4 == 0, "
-                   "NI*(R/4)*ceil(W/4) <= 32 tiles (or R = 4 MS, NI = 0: flat items), a patch of <= 1024 slots that fits the LDS next "
-                   "to the U ring, tensors below 2^30 elements and the ALG 13 weight fragments");
+                   "NI*(R/4)*ceil(W/4) <= 32 tiles (or R = 4 MS, NI = 0: flat items), a patch of <= 1024 slots, tensors below 2^30 elements and the ALG 13 weight fragments");
     return POCO_ERR_ARG;
   }
   if (d.act == 3 || d.act == 2) { poco_set_error("conv(winograd 4x4): activation must be none or ReLU"); return POCO_ERR_ARG; }
@@ -766,7 +731,7 @@ int conv_wino4w_launch(const ConvDesc& d, const ConvCfg& cfg, hipStream_t stream
       configured[cfg.NT + 4 * mode] = true;
     }
   }
-  hipLaunchKernelGGL(fn, dim3((unsigned)g4, 1), dim3(128 * cfg.NT + 128), lds, stream, pp);
+  hipLaunchKernelGGL(fn, dim3((unsigned)g4, 1), dim3(64 * (cfg.NT == 3 ? w4w_block_waves<3>() : cfg.NT == 2 ? w4w_block_waves<2>() : w4w_block_waves<1>())), lds, stream, pp);
   POCO_HIP_CHECK(hipGetLastError());
   return POCO_OK;
 }

@@ -1,5 +1,5 @@
 """Same-box A/B of one shape's configuration inside the whole forward (hipGraph replays, alternating, `rounds` times):
-  python tools/ab_shape_cfg.py variant B HxWxCinxCout "cfgA" "cfgB" [rounds]"""
+  python tools/ab_shape_cfg.py variant B HxWxCinxCout "cfgA" "cfgB" [rounds] [engine options "k=v,k=v"]"""
 import sys, time
 from pathlib import Path
 import torch
@@ -12,7 +12,7 @@ cfgs = [tuple(int(x) for x in c.split(",")) for c in sys.argv[4:6]]
 rounds = int(sys.argv[6]) if len(sys.argv) > 6 else 3
 dev = torch.device("cuda:0")
 batch = util.cuda_batch(synth.synth_batch(B, 1), dev)
-m = util.make_engine(variant, max_batch=B)
+m = util.make_engine(variant, max_batch=B, options=sys.argv[7] if len(sys.argv) > 7 else None)
 m(batch)
 idxs = [i for i, _ in enumerate(m.ops()) if m.conv_desc(i) is not None and tuple(m.conv_desc(i)[:6]) == (H, W, Cin, Cout, 3, 1)]
 print(f"{len(idxs)} ops of shape {H}x{W} {Cin}->{Cout}; table cfg {tuple(m.conv_cfg(idxs[0], B))}")

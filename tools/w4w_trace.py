@@ -21,4 +21,8 @@ for (B, H, W, Cin, Cout), cfg in [((64, 56, 56, 48, 48), (1, 3, 2, 1, 8, 1, 13))
     for w in range(2 * nt):
         print(f"  MFMA wave {w}: per slice issue+MFMA {buf[4*w]/S:.0f} | wait_vm {buf[4*w+1]/S:.0f} | barrier {buf[4*w+2]/S:.0f} | epilogue {buf[4*w+3]}")
     for pw in range(2):
-        print(f"  producer {pw}: per slice transform+V store {buf[32+4*pw]/S:.0f} | window reads {buf[33+4*pw]/S:.0f} | barrier {buf[34+4*pw]/S:.0f}")
+        b = 32 + 5 * pw
+        print(f"  producer {pw}: per slice LDS-DMA requests {buf[b]/S:.0f} | transform + V store {buf[b+1]/S:.0f} | window reads {buf[b+2]/S:.0f} | wait_vm {buf[b+3]/S:.0f} | barrier {buf[b+4]/S:.0f}")
+    if nt == 2:
+        for dw in range(2):
+            print(f"  patch requester {dw}: per slice requests {buf[48+2*dw]/S:.0f} | wait + barrier {buf[49+2*dw]/S:.0f}")
