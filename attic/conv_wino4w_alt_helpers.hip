@@ -60,13 +60,6 @@ using w4::at_c;
 #ifndef W4W_STATICNP
 #define W4W_STATICNP 1   // every requester issues exactly MAXP = 8 patch pieces per slice (pieces that do not exist go out with an empty exec
 #endif                   // mask: no traffic, but they count in vmcnt), so the landing waits are the constants vmcnt(0 / 8 / 16) instead of a dispatch on a run-time count
-#ifndef W4W_YIELD
-#define W4W_YIELD 1      // NT < 3: s_sleep(W4W_YIELD) behind every MFMA quad of an MFMA wave that shares its SIMD with a producer - a producer advances about one
-                         // VALU instruction per MFMA while the MFMA wave of its SIMD streams (traced: transform 1880 clk instead of 650); 1: 56x56 64->64 88.8 -> 86.3 us, 2 / 4: slower
-#endif
-#ifndef W4W_DMAWAVES
-#define W4W_DMAWAVES 1   // NT = 2: two extra waves (SIMDs 2 / 3) request the raw patch; 0: the producers do (as at NT = 1 / 3)
-#endif
 #ifndef W4W_TRACE
 #define W4W_TRACE 0   // 1: block 0 sums s_memtime phases of its waves over its first item (tools/w4w_trace.py)
 #endif
@@ -140,15 +133,16 @@ __device__ __forceinline__ int w4w_item_id(const W4WParams& p, int it, int* ngro
 
 // ---------------------------------------------------------------------------------------------------------------------
 // wave roles.  Waves land on SIMD (wave id % 4).
-//   NT = 3: producers = wave ids 3 and 7, i.e. BOTH on SIMD 3, every other SIMD carries two MFMA waves (72 MFMAs = 2304 clk per slice, the
-//           floor of the kernel); the producers also request the patch (an LDS-DMA piece blocks the MFMA pipe of the SIMD it is issued from
-//           for ~47 clk - on SIMD 3 there is none).
-//   NT = 2: MFMA waves = ids 0 .. 3 (one per SIMD), producers = ids 4, 5 (SIMDs 0 / 1), patch requesters = ids 6, 7 (SIMDs 2 / 3).
-//   NT = 1: MFMA waves = ids 0, 1, producers = ids 2, 3 (their own SIMDs; they request the patch too).
+//   NT = 3: eight waves.  Producers = wave ids 3 and 7, i.e. BOTH on SIMD 3, every other SIMD carries two MFMA waves (72 MFMAs = 2304 clk
+//           per slice, the floor of the kernel); the producers also request the patch (an LDS-DMA piece blocks the MFMA pipe of the SIMD it
+//           is issued from for ~47 clk - on SIMD 3 there is none).
+//   NT < 3: 2 NT MFMA waves (ids 0 .. 2 NT - 1) + FOUR helpers (the next four ids: with NT = 2 every SIMD carries one MFMA wave and one
+//           helper).  Helper h = (tile group h & 1, phase h >> 1) builds V of its group for every OTHER slice - the slices of its phase -
+//           and requests its share of their patches: see w4w_helper.
 // ---------------------------------------------------------------------------------------------------------------------
-template <int NT> constexpr int w4w_dma_waves() { return (NT == 2 && W4W_DMAWAVES) ? 2 : 0; }
-template <int NT> constexpr int w4w_block_waves() { return 2 * NT + 2 + w4w_dma_waves<NT>(); }
-enum { W4W_ROLE_MFMA = 0, W4W_ROLE_PRODUCER = 1, W4W_ROLE_DMA = 2 };
+template <int NT> constexpr int w4w_block_waves() { return NT == 3 ? 8 : 2 * NT + 4; }
+template <int NT> constexpr int w4w_ring_depth() { return NT == 3 ? W4W_RD : 5; }      // raw-patch ring slots in LDS
+enum { W4W_ROLE_MFMA = 0, W4W_ROLE_PRODUCER = 1, W4W_ROLE_HELPER = 2 };
 template <int NT> __device__ __forceinline__ int w4w_role(int wave, int* index) {
   if constexpr (NT == 3) {
     if ((wave & 3) == 3) { *index = wave >> 2; return W4W_ROLE_PRODUCER; }
@@ -156,9 +150,8 @@ template <int NT> __device__ __forceinline__ int w4w_role(int wave, int* index) 
     return W4W_ROLE_MFMA;
   } else {
     if (wave < 2 * NT) { *index = wave; return W4W_ROLE_MFMA; }
-    if (wave < 2 * NT + 2) { *index = wave - 2 * NT; return W4W_ROLE_PRODUCER; }
-    *index = wave - 2 * NT - 2;
-    return W4W_ROLE_DMA;
+    *index = wave - 2 * NT;
+    return W4W_ROLE_HELPER;
   }
 }
 
@@ -180,10 +173,9 @@ __device__ __forceinline__ void w4w_gather_n(int np, const void* sbase, const un
 // during slice t - 1.  Its window is read during slice t + RD - 1, so it must have landed at the barrier that ends slice t + RD - 2:
 // at the end of a slice the requests of the last RD - 2 slices may still be in flight (wait()).
 // ---------------------------------------------------------------------------------------------------------------------
-template <int FLAT>
+template <int FLAT, int RD_, int STRIDE = 1>     // STRIDE 2: the cursor walks every other slice (a helper's phase)
 struct W4WRaw {
-  static constexpr int NW = 2, MAXP = 8, RD = W4W_RD;      // (rawF4 <= 1024 slots = 16 pieces)
-  static_assert(RD == 3 || RD == 4, "raw ring depth");
+  static constexpr int NW = 2, MAXP = 8, RD = RD_;         // (rawF4 <= 1024 slots = 16 pieces)
   int goff[MAXP];
   unsigned long long lmask[MAXP];                           // lanes of a piece that carry an in-image position
   int dw, it, s, slot, step, end, prev;
@@ -228,12 +220,18 @@ struct W4WRaw {
     } else {
       if (!(W4W_EXP & 1)) w4w_gather_n<MAXP>(np, sbase, voff, lmask, dst0, NW * 1024u);
     }
-    slot = slot + 1 == RD ? 0 : slot + 1;
-    if (++s == p.nC4) {
-      s = 0; it += step;
+    advance(pp, lane);
+    return (W4W_EXP & 1) ? 0 : np;
+  }
+  __device__ __forceinline__ void advance_one(const W4WParams& pp, int lane) { slot = 1; s = 1; (void)pp; (void)lane; }      // (from the start: slice 1)
+  __device__ __forceinline__ void advance(const W4WParams& pp, int lane) {     // STRIDE slices on (the number of slices of an item is a multiple of 4)
+    slot += STRIDE;
+    if (slot >= RD) slot -= RD;
+    s += STRIDE;
+    if (s >= pp.g.nC4) {
+      s -= pp.g.nC4; it += step;
       if (it < end) setup(pp, lane);
     }
-    return (W4W_EXP & 1) ? 0 : np;
   }
   // s_waitcnt vmcnt(n) for a count of this requester
   __device__ __forceinline__ static void wait_n(int n) {
@@ -247,7 +245,7 @@ struct W4WRaw {
   // Before the first barrier (P0): raw(0 .. RD - 1) requested, raw(0) and raw(1) landed (their windows are read between P0 and P1);
   // before the second (P1): raw(2) landed (its window is read during slice 0).  Younger requests stay in flight - the cold start of
   // a launch is a burst of RD slices per CU, and only the first two gate the first transform.
-  int n_pro[RD];
+  int n_pro[RD > 4 ? 4 : RD];
   __device__ __forceinline__ void prologue(const W4WParams& pp, float4* smem, int lane) {
 #pragma unroll
     for (int c = 0; c < RD; ++c) n_pro[c] = issue(pp, smem, lane);
@@ -270,6 +268,7 @@ struct W4WRaw {
   }
   // end of a slice in which this wave made `nvm` requests: everything older than the last RD - 2 slices' requests has landed
   __device__ __forceinline__ void wait(int nvm) {
+    static_assert(STRIDE != 1 || RD == 3 || RD == 4, "the producers' schedule");
     if constexpr (RD == 3) wait_n(nvm);
     else { wait_n(nvm + prev); prev = nvm; }
   }
@@ -356,7 +355,6 @@ __device__ __forceinline__ void w4w_mfma_wave(const W4WParams& pp, float4* smem,
           else acc[q][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(ur[q][i], f4c(v, i), acc[q][i], 0, 0, 0);
         }
         if (!(W4W_EXP & 16)) w4w_uload(ur[q], un, uvo[q >> 2], q);                        // ... and its registers take quad q of the next slice
-        if constexpr (W4W_YIELD > 0 && NT < 3) { if (wave < 2) __builtin_amdgcn_s_sleep(W4W_YIELD); }
       }
       W4W_T(c1);
       vb ^= 1;
@@ -447,7 +445,7 @@ __device__ __forceinline__ void w4w_mfma_wave(const W4WParams& pp, float4* smem,
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// producer waves: input transform V = B^T d B, all 36 positions of tile group pw (+ the patch requests where no DMA waves exist)
+// producer waves (NT = 3): input transform V = B^T d B, all 36 positions of tile group pw, and the patch requests
 // ---------------------------------------------------------------------------------------------------------------------
 template <int NT, int FLAT>
 __device__ __forceinline__ void w4w_producer(const W4WParams& pp, float4* smem, int pw, int lane) {
@@ -523,8 +521,8 @@ __device__ __forceinline__ void w4w_producer(const W4WParams& pp, float4* smem, 
     }
   };
 
-  constexpr bool kIssue = w4w_dma_waves<NT>() == 0;        // this wave requests the patch itself
-  W4WRaw<FLAT> raw;
+  constexpr bool kIssue = true;                            // this wave requests the patch itself
+  W4WRaw<FLAT, RD> raw;
   Win A, B;
   win_of(wk.first, A);
   if constexpr (kIssue) { raw.init(pp, wk, pw, lane); raw.prologue(pp, smem, lane); }
@@ -579,38 +577,142 @@ __device__ __forceinline__ void w4w_producer(const W4WParams& pp, float4* smem, 
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// patch requesters (NT = 2): nothing but the LDS-DMA of the coming slices, in step with the block's barriers
+// helpers (NT < 3, round 6).  With 2 NT <= 4 MFMA waves there is no SIMD to spare for the producers: a producer that shares its SIMD
+// with an MFMA wave advances ONE VALU instruction per MFMA while that wave streams its 36 MFMAs (fp32 MFMAs run on the SIMD's vector
+// ALUs; traced at NT = 2: transform 1880 clk instead of the 650 of NT = 3's producers, slice 2600 clk for 1152 clk of MFMAs).  Instead
+// of two producers that need V(t + 1) finished within slice t, FOUR helpers take two slices each: helper (group, phase) builds V(T) of
+// its group for every T = phase (mod 2) and requests its half of the patch pieces of those slices.  Per global slice t (one barrier
+// each, in step with the MFMA waves):
+//   (t & 1) == phase  "part 1" for T = t + 2: read the window of raw(T) (landed before the barrier that ended slice t - 1), request
+//                     raw(T + 4) (into the slot of raw(T - 1), whose window the other phase read during slice t - 1), first transform stage
+//   (t & 1) != phase  "part 2" for T = t + 1: second transform stage, V(T) -> buffer T & 1 (read by the MFMAs during slice T; its previous
+//                     content V(T - 2) was read during slice T - 2), then wait until only this period's eight requests are in flight:
+//                     raw(T + 2), requested a period ago, is read after the next barrier.
+// Ring of 5 raw slots (raw(T) lives from its request at slice T - 6 to its window read at slice T - 2), V double-buffered as at NT = 3.
 // ---------------------------------------------------------------------------------------------------------------------
 template <int NT, int FLAT>
-__device__ __forceinline__ void w4w_dma_wave(const W4WParams& pp, float4* smem, int dw, int lane) {
+__device__ __forceinline__ void w4w_helper(const W4WParams& pp, float4* smem, int h, int lane) {
   const W4PParams& p = pp.g;
+  const int grp = h & 1, ph = h >> 1;          // (wave-uniform)
+  const int idx = lane >> 2, g = lane & 3;   // transform lane order: 8 tiles x 4 channels per 32-lane half (see w4p_sigma)
+  const int vlane = w4p_sigma(idx, g);
+  const int rawF4 = p.rawF4;
+  const int S = p.nC4;
+  constexpr int RD = w4w_ring_depth<NT>();
+  static_assert(RD == 5, "the helpers' schedule");
   const Walk wk = item_walk(p);
   if (wk.first >= wk.end) return;
-  W4WRaw<FLAT> raw;
-  raw.init(pp, wk, dw, lane);
-  raw.prologue(pp, smem, lane);
-  __syncthreads();                                        // P0
-  raw.prologue_p1(pp, smem, lane);
-  __syncthreads();                                        // P1
-  raw.after_p1(pp, smem, lane);
-#if W4W_TRACE
-  unsigned long long tr[2] = {0, 0};
-  int nsl = 0;
-#endif
-  for (int it = wk.first; it < wk.end; it += wk.step)
-    for (int s = 0; s < p.nC4; ++s) {
-      W4W_T(d0);
-      const int nvm = raw.issue(pp, smem, lane);
-      W4W_T(d1);
-      raw.wait(nvm);
-      __syncthreads();
-      W4W_T(d2);
-#if W4W_TRACE
-      if (blockIdx.x == 0 && it == wk.first) { tr[0] += d1 - d0; tr[1] += d2 - d1; ++nsl; }
-#endif
+  const int nitems = (wk.end - wk.first + wk.step - 1) / wk.step;
+  const int NTOT = nitems * S;                 // global slices of this block
+
+  // window offsets of the lane's tile in the item the cursor (w_it, w_s) stands in
+  int woff[6][3];
+  int w_it = wk.first, w_s = ph, w_slot = ph;  // slice T of this helper: item, slice inside it, ring slot T % 5
+  auto win_setup = [&]() __attribute__((always_inline)) {
+    int ng;
+    const int id = w4w_item_id(pp, w_it, &ng);
+    const Tile tl = tile_of<FLAT>(p, id, grp, idx);
+#pragma unroll
+    for (int k = 0; k < 6; ++k)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const int pos = tl.base + k * p.PW + 2 * c;
+        woff[k][c] = (pos + (pos >> (FLAT ? 4 : 3))) * 4 + g;
+      }
+  };
+  auto win_advance = [&]() __attribute__((always_inline)) {      // T += 2
+    w_slot += 2; if (w_slot >= RD) w_slot -= RD;
+    w_s += 2;
+    if (w_s >= S) { w_s -= S; w_it += wk.step; if (w_it < wk.end) win_setup(); }
+  };
+  f32x2 t[6][3];                               // stage-1 results, carried from part 1 to part 2
+  auto part1_window = [&]() __attribute__((always_inline)) {     // window of the cursor's slice + transform down the columns
+    const float* rawf = reinterpret_cast<const float*>(smem + w_slot * rawF4);
+    f32x2 d[6][3];
+#pragma unroll
+    for (int k = 0; k < 6; ++k)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float* q = rawf + woff[k][c];
+        d[k][c] = (f32x2){q[0], q[4]};
+      }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const f32x2 d0 = d[0][c], d1 = d[1][c], d2 = d[2][c], d3 = d[3][c], d4 = d[4][c], d5 = d[5][c];
+      t[0][c] = pk_fma(d0, 4.f, pk_fma(d2, -5.f, d4));                       // 4 d0 - 5 d2 + d4
+      const f32x2 a = pk_fma(d2, -4.f, d4), cc = pk_fma(d1, 4.f, -d3);       // rows 1, 2 = (d4 - 4 d2) -+ (4 d1 - d3)
+      t[1][c] = a - cc;
+      t[2][c] = a + cc;
+      const f32x2 b = d4 - d2, e = d1 - d3;                                  // rows 3, 4 = (d4 - d2) -+ 2 (d1 - d3)
+      t[3][c] = pk_fma(e, -2.f, b);
+      t[4][c] = pk_fma(e, 2.f, b);
+      t[5][c] = pk_fma(d1, 4.f, pk_fma(d3, -5.f, d5));                       // 4 d1 - 5 d3 + d5
     }
+  };
+  auto part2_store = [&](int vbuf) __attribute__((always_inline)) {          // along the rows, 9 ds_write_b128 in the order (w4w_row / w4w_nu)
+    float4* Vg = smem + p.voff + vbuf * (2 * W4W_UBLK) + grp * W4W_UBLK + vlane;
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+      f32x2 Ap[2], Bp[2], Cp[2];                              // rows 2m, 2m + 1: (v0, v5), (v1, v3), (v2, v4)
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const f32x2 T0 = t[2 * m + r][0], T1 = t[2 * m + r][1], T2 = t[2 * m + r][2];
+        Ap[r] = pk_fma(T0, 4.f, pk_fma(T1, -5.f, T2));                            // 4 t0 - 5 t2 + t4 | 4 t1 - 5 t3 + t5
+        const f32x2 ab = pk_fma2(T1.xx, (f32x2){-4.f, -1.f}, T2.xx);             // t4 - 4 t2 | t4 - t2
+        const f32x2 cf = pk_fma2(T0.yy, (f32x2){4.f, 2.f}, T1.yy * (f32x2){-1.f, -2.f});   // 4 t1 - t3 | 2 t1 - 2 t3
+        Bp[r] = ab - cf;
+        Cp[r] = ab + cf;
+      }
+      Vg[(3 * m) * 64] = make_float4(Ap[0].x, Ap[0].y, Bp[0].x, Bp[0].y);
+      Vg[(3 * m + 1) * 64] = make_float4(Cp[0].x, Cp[0].y, Ap[1].x, Ap[1].y);
+      Vg[(3 * m + 2) * 64] = make_float4(Bp[1].x, Bp[1].y, Cp[1].x, Cp[1].y);
+    }
+  };
+
+  // patch requests: this helper's pieces (requester index = tile group) of the slices of its phase, walked by a cursor two slices at a time
+  W4WRaw<FLAT, RD, 2> raw;
+  raw.init(pp, wk, grp, lane);
+  if (ph) raw.advance_one(pp, lane);                      // phase 1 starts at slice 1 / slot 1
+  (void)raw.issue(pp, smem, lane);                        // raw(ph)
+  (void)raw.issue(pp, smem, lane);                        // raw(ph + 2)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  win_setup();
+  __syncthreads();                                        // P0: raw(0 .. 3) have landed
+  part1_window();                                         // T = ph
+  if (ph == 0) part2_store(0);                            // V(0)
+  win_advance();
+  __syncthreads();                                        // P1: V(0) is written, the windows of raw(0) and raw(1) have been read
+  int inflight = raw.issue(pp, smem, lane);               // raw(4 + ph) -> the slot of raw(4 + ph - 5): free (slot 4 / the slot of raw(0))
+  __builtin_amdgcn_s_setprio(3);                          // (ahead of the MFMA wave of this SIMD wherever the VALU has a free slot)
 #if W4W_TRACE
-  if (blockIdx.x == 0 && lane == 0) { g_w4w_trace[48 + 2 * dw] = tr[0]; g_w4w_trace[49 + 2 * dw] = tr[1]; }
+  const bool trace = blockIdx.x == 0;
+  unsigned long long tr[5] = {0, 0, 0, 0, 0};
+#endif
+  for (int tg = 0; tg < NTOT; ++tg) {
+    W4W_T(h0);
+    if ((tg & 1) == ph) {                                 // part 1 for T = tg + 2
+      if (tg + 2 < NTOT) {
+        if (!(W4W_EXP & 2)) part1_window();
+        win_advance();
+        W4W_T(h1);
+        inflight = raw.issue(pp, smem, lane);             // raw(T + 4)
+        W4W_T(h2);
+        W4W_ACC(0, h0, h1); W4W_ACC(1, h1, h2);
+      } else inflight = 0;
+    } else {                                              // part 2 for T = tg + 1
+      if (tg + 1 < NTOT && !(W4W_EXP & 2)) part2_store((tg + 1) & 1);
+      W4W_T(h1);
+      W4WRaw<FLAT, RD, 2>::wait_n(inflight);              // everything older than this period's requests has landed
+      W4W_T(h2);
+      W4W_ACC(2, h0, h1); W4W_ACC(3, h1, h2);
+    }
+    W4W_T(h3);
+    __syncthreads();
+    W4W_T(h4);
+    W4W_ACC(4, h3, h4);
+  }
+#if W4W_TRACE
+  if (trace && lane == 0) { for (int k = 0; k < 5; ++k) g_w4w_trace[32 + 5 * h + k] = tr[k]; g_w4w_trace[62] = (unsigned long long)NTOT; }
 #endif
 }
 
@@ -623,8 +725,8 @@ conv_wino4w_kernel(const W4WParams p) {
   int index;
   const int role = w4w_role<NT>(wave, &index);
   if (role == W4W_ROLE_MFMA) w4w_mfma_wave<NT, FLAT>(p, smem, index, lane);
-  else if (role == W4W_ROLE_PRODUCER) w4w_producer<NT, FLAT>(p, smem, index, lane);
-  else if constexpr (w4w_dma_waves<NT>() > 0) w4w_dma_wave<NT, FLAT>(p, smem, index, lane);
+  else if constexpr (NT == 3) w4w_producer<NT, FLAT>(p, smem, index, lane);
+  else w4w_helper<NT, FLAT>(p, smem, index, lane);
 }
 
 struct W4WLayout { int uoff, voff, totalF4; };
@@ -636,7 +738,7 @@ bool w4w_geo(const ConvDesc& d, const ConvCfg& cfg, w4::Geo* g, W4WLayout* L, Fl
   if (g->rawF4 > 1024) return false;
   // 32-bit byte offsets in the epilogue
   if ((long)d.B * d.H * d.W * std::max(std::max(d.in_cs, d.out_cs), d.res_cs) >= (1L << 30)) return false;
-  L->uoff = W4W_RD * g->rawF4;                                  // (no U ring: the MFMA waves load U into registers)
+  L->uoff = (cfg.NT == 3 ? w4w_ring_depth<3>() : w4w_ring_depth<2>()) * g->rawF4;      // (no U ring: the MFMA waves load U into registers)
   L->voff = L->uoff;
   L->totalF4 = L->voff + 4 * W4W_UBLK;
   return (size_t)L->totalF4 * sizeof(float4) <= 160 * 1024;

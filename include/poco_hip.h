@@ -106,7 +106,7 @@ int poco_create(const char* variant, int max_batch, int num_flow_layers, poco_ha
  *   xdep, tail_lanes, up_lanes = 0           the more conservative lane schedules;  seq_phases = <bit mask>, branch_lanes = "0123"
  *   split_f16 = 1                            EXPERIMENT, only in libraries built with `python -m poco_amd.build --experiments` (an unknown
  *                                            key in the shipped one): plain 1x1 convs in split fp16
- *   w4_min_plane = <7..14>                   smallest plane the tile-owning F(4x4) kernels (ALG 8 / 13) are prepared for (default 14; 7 = also the 7x7 planes)
+ *   w4_min_plane = <7..14>                   smallest plane the whole-position F(4x4) kernel (ALG 13) is prepared for (default 7; 14 = no fragments for the 7x7 planes)
  *   debug_wait_spins = <n>, debug_mlp_timeouts = <n>   TEST HOOKS for poco_status: poll bound of the in-kernel waits (default 2^21 polls,
  *                                            ~3 s) / the first n launches of the fused regressor time out on purpose
  *   flow_ctx_rows = <n>                      context rows poco_realnvp*'s scratch is planned for at finalize (default max_batch)

@@ -117,7 +117,9 @@ struct EngineOpts {
   bool split_f16 = false;  // EXPERIMENT (never the default): plain 1x1 convs on the split-fp16 GEMM (gemm1x1h.hip)
   int seq_mask = 0;        // bit mask: run the tagged kind of parallel region on one lane
   std::string branch_lanes = "0123";   // HR branch i runs on lane branch_lanes[i]
-  int w4_min_plane = 14;   // ALG 8 / 13 (F(4x4), blocks own tiles x all positions) are offered for planes from this size up (7: also the 7x7 planes, +21 MB of fragments per 384->384 conv)
+  int w4_min_plane = 7;    // ALG 13 (F(4x4), blocks own tiles x all positions) is offered for planes from this size up; ALG 8 from 14x14.  Round 6: the 7x7 planes of
+                           // HRNet-W48 run on ALG 13 at >= 64 crops (rectangular items of 8 whole images: time +-0 against ALG 11, which stages V and M through memory -
+                           // 128 MB per conv); 14 = round-5 behaviour (no ALG 13 fragments for the 7x7 convs: 21 MB each at 384->384)
   int wg_max_plane = 8;    // ALG 11 (F(4x4) as 36 position GEMMs, V / M staged in memory) is offered for planes up to this size (<= 16)
   int flow_ctx_rows = 0;   // context rows the RealNVP scratch is planned for at finalize (0 = max_batch: one context per crop)
   int debug_wait_spins = 0;    // TEST HOOKS for poco_status (tests/test_model_gpu.py): poll bound of the in-kernel waits (0 = 2^21 polls ~ 3 s) ...
@@ -434,15 +436,17 @@ struct Builder {
         conv_wino_transform_weights(wp, Cout, Cin, &wt);
         conv_pack_weights(wt.data(), scale.data(), Cout, Cin, 4, Cout16, pu.data());
         op.wdev_wino = upload(pu);
-        if (ain.H >= e.opts.w4_min_plane && ain.W >= e.opts.w4_min_plane) {          // F(4x4,3x3): 56x56 / 28x28 planes, and 14x14 (16 tiles per image, 31 % padding) with ALG 8
+        if (ain.H >= e.opts.w4_min_plane && ain.W >= e.opts.w4_min_plane) {          // F(4x4,3x3): 56x56 / 28x28 planes, 14x14 (16 tiles per image, 31 % padding), 7x7 with ALG 13 only
           std::vector<float> pu4(conv_wino4_packed_floats(Cin, Cout16));
           if (ain.H >= 28 && ain.W >= 28) {
             conv_wino4_pack_weights(wp, scale.data(), Cout, Cin, Cout16, pu4.data());
             op.wdev_wino4 = upload(pu4);
           }
-          pu4.resize(conv_wino4p_packed_floats(Cin, Cout16));                             // other order (+ slack for the streamed requests)
-          conv_wino4p_pack_weights(wp, scale.data(), Cout, Cin, Cout16, pu4.data());
-          op.wdev_wino4p = upload(pu4);
+          if (ain.H >= 14 && ain.W >= 14) {
+            pu4.resize(conv_wino4p_packed_floats(Cin, Cout16));                           // other order (+ slack for the streamed requests)
+            conv_wino4p_pack_weights(wp, scale.data(), Cout, Cin, Cout16, pu4.data());
+            op.wdev_wino4p = upload(pu4);
+          }
           pu4.resize(conv_wino4w_packed_floats(Cin, Cout16));                             // ALG 13: whole-position waves (+ slack)
           conv_wino4w_pack_weights(wp, scale.data(), Cout, Cin, Cout16, pu4.data());
           op.wdev_wino4w = upload(pu4);
@@ -2006,7 +2010,7 @@ extern "C" int poco_set_conv_cfg(poco_handle_t h, int op_index, int B, const int
   if (B < 1 || lds == 0 || lds > 160 * 1024 || ((c.ALG == 3 || c.ALG == 4) && (op.wdev_wino == nullptr && e->finalized)) ||
       ((c.ALG == 3 || c.ALG == 4) && (op.actfn == 3 || op.actfn == 2)) ||
       (c.ALG == 7 && ((op.wdev_wino4 == nullptr && e->finalized) || ai.H < 28 || ai.W < 28 || op.actfn >= 2)) ||
-      (c.ALG == 8 && ((op.wdev_wino4p == nullptr && e->finalized) || ai.H < e->opts.w4_min_plane || ai.W < e->opts.w4_min_plane || op.actfn >= 2)) ||
+      (c.ALG == 8 && ((op.wdev_wino4p == nullptr && e->finalized) || ai.H < 14 || ai.W < 14 || op.actfn >= 2)) ||
       (c.ALG == 13 && ((op.wdev_wino4w == nullptr && e->finalized) || ai.H < e->opts.w4_min_plane || ai.W < e->opts.w4_min_plane || op.actfn >= 2)) ||
       (c.ALG == 11 && ((op.wdev_wino4g == nullptr && e->finalized) || ai.H > e->opts.wg_max_plane || ai.W > e->opts.wg_max_plane || ai.H * ai.W <= 1 || op.actfn >= 2))) {     // (its scratch is sized for max_batch; poco_forward refuses larger batches)
     poco_set_error("poco_set_conv_cfg: configuration does not fit op '" + op.name + "' at this batch size");
