@@ -54,6 +54,10 @@ using w4::at_c;
 #ifndef W4W_PF
 #define W4W_PF 4      // V operand quads requested ahead of the MFMAs that use them (PF + 1 register sets of 4)
 #endif
+#ifndef W4W_HOLD
+#define W4W_HOLD 1    // NT < 3: the four MFMAs of a slice's LAST quad are issued behind the slice barrier, in front of the next slice's first quad, whose V
+#endif                // operands are still on their way from the LDS then (their own operands are in registers; the last slice of an item keeps nothing back).
+                      // Same box: 56x56 64->64 85 -> 79 us, 56x56 32->32 28.1 -> 26.7; at NT = 3 it is 2-3 % SLOWER (two MFMA waves per SIMD cover the gap already)
 #ifndef W4W_RD
 #define W4W_RD 3      // depth of the raw-patch ring in LDS (3: a request has two slices to land, 4: three - measured 1-3 % slower per launch)
 #endif
@@ -333,6 +337,11 @@ __device__ __forceinline__ void w4w_mfma_wave(const W4WParams& pp, float4* smem,
     const bool trace = blockIdx.x == 0 && it == wk.first;
     unsigned long long tr[4] = {0, 0, 0, 0};
 #endif
+#if W4W_HOLD
+    constexpr int NH = NT < 3 ? W4W_HOLD : 0;               // quads held back across the slice barrier
+    float4 vhold[NH > 0 ? NH : 1];
+    const float4* uhold = p.ufrag;
+#endif
     for (int s = 0; s < S; ++s) {
       W4W_T(c0);
       const float4* V = smem + p.voff + vb * (2 * W4W_UBLK) + grp * W4W_UBLK + vlane;
@@ -345,11 +354,25 @@ __device__ __forceinline__ void w4w_mfma_wave(const W4WParams& pp, float4* smem,
       float4 vq[PF + 1];
 #pragma unroll
       for (int q = 0; q < PF; ++q) vq[q] = (W4W_EXP & 4) ? make_float4(1.f, 2.f, 3.f, (float)q) : V[q * 64];
+#if W4W_HOLD
+      if (NH > 0 && s > 0) {                               // the previous slice's last quads (operands in registers since before the barrier)
+#pragma unroll
+        for (int h = 0; h < NH; ++h) {
+          constexpr int q0 = 9 - NH;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) acc[q0 + h][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(ur[q0 + h][i], f4c(vhold[h], i), acc[q0 + h][i], 0, 0, 0);
+          w4w_uload(ur[q0 + h], uhold, uvo[(q0 + h) >> 2], q0 + h);
+        }
+      }
+#endif
 #pragma unroll
       for (int q = 0; q < 9; ++q) {
         if (q + PF < 9) vq[(q + PF) % (PF + 1)] = (W4W_EXP & 4) ? make_float4(1.f, 2.f, 3.f, (float)q) : V[(q + PF) * 64];
         const float4 v = vq[q % (PF + 1)];
         if (!(W4W_EXP & 16)) asm volatile("s_waitcnt vmcnt(8)" : "+v"(ur[q]));          // quad q of this slice has landed (eight younger loads may be in flight)
+#if W4W_HOLD
+        if (NH > 0 && q >= 9 - NH && s + 1 < S) { vhold[q - (9 - NH)] = v; uhold = un; continue; }      // deferred across the barrier
+#endif
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           if (W4W_EXP & 8) acc[q][i][0] += ur[q][i] * f4c(v, i);
