@@ -58,6 +58,9 @@ using w4::at_c;
 #define W4W_HOLD 1    // NT < 3: the four MFMAs of a slice's LAST quad are issued behind the slice barrier, in front of the next slice's first quad, whose V
 #endif                // operands are still on their way from the LDS then (their own operands are in registers; the last slice of an item keeps nothing back).
                       // Same box: 56x56 64->64 85 -> 79 us, 56x56 32->32 28.1 -> 26.7; at NT = 3 it is 2-3 % SLOWER (two MFMA waves per SIMD cover the gap already)
+#ifndef W4W_ASMMAX
+#define W4W_ASMMAX 1  // the epilogue's ReLU clamp as ONE v_max_f32 per value (inline asm): fmaxf() compiles to two (hipcc first quiets a possible signalling NaN
+#endif                // with v_max x, x, x - 64 extra VALU instructions per wave and item in a VALU-bound epilogue); packed residual / bias adds on f32x4
 #ifndef W4W_RD
 #define W4W_RD 3      // depth of the raw-patch ring in LDS (3: a request has two slices to land, 4: three - measured 1-3 % slower per launch)
 #endif
@@ -132,11 +135,20 @@ __device__ __forceinline__ void w4w_at(const f32x4& x0, const f32x4& x1, const f
 
 struct W4WParams {
   W4PParams g;          // geometry, tensors, LDS offsets (xoff unused)
-  FastDiv dNbn;         // item -> (tile strip m, n-group): n-group innermost
+  FastDiv dNbn;         // walk index -> (tile strip m, n-group), n-group innermost ...
+  FastDiv dNbm;         // ... or tile strip innermost
+  int minner;           // 1: tile strips innermost (see conv_wino4w_launch)
 };
 
-// walk index -> the item id the shared geometry helpers expect (m + n-group * nblocks_m)
+// walk index -> the item id the shared geometry helpers expect (m + n-group * nblocks_m).  The persistent walk hands every XCD a contiguous
+// range of walk indices: n-group-innermost, an XCD owns some tile strips with ALL their n-groups (their patch comes through its L2 once, the
+// whole U stream once per XCD); strip-innermost, it owns some n-groups with all strips (its share of U once, every patch once per XCD).
 __device__ __forceinline__ int w4w_item_id(const W4WParams& p, int it, int* ngroup) {
+  if (p.minner) {
+    const uint32_t n = fdiv((uint32_t)it, p.dNbm);
+    *ngroup = (int)n;
+    return it;                                            // (it = n * nblocks_m + m already is the helpers' id)
+  }
   const uint32_t m = fdiv((uint32_t)it, p.dNbn);
   *ngroup = it - (int)m * p.g.nb_n;
   return (int)m + *ngroup * p.g.nblocks_m;
@@ -447,6 +459,18 @@ __device__ __forceinline__ void w4w_mfma_wave(const W4WParams& pp, float4* smem,
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           f32x4 v = yc[i] + (f32x4){sh.x, sh.y, sh.z, sh.w};
+#if W4W_ASMMAX
+          auto clampv = [&](f32x4& x) __attribute__((always_inline)) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { float y; asm("v_max_f32 %0, %1, %2" : "=v"(y) : "v"(x[c]), "v"(lo)); x[c] = y; }
+          };
+          if (has_res) {
+            const float4 r = rr[j & 1][i];
+            const f32x4 rv = {r.x, r.y, r.z, r.w};
+            if (p.res_after_act) { clampv(v); v = v + rv; }
+            else { v = v + rv; clampv(v); }
+          } else clampv(v);
+#else
           if (has_res) {
             const float4 r = rr[j & 1][i];
             if (p.res_after_act) {
@@ -457,6 +481,7 @@ __device__ __forceinline__ void w4w_mfma_wave(const W4WParams& pp, float4* smem,
           } else {
             v[0] = fmaxf(v[0], lo); v[1] = fmaxf(v[1], lo); v[2] = fmaxf(v[2], lo); v[3] = fmaxf(v[3], lo);
           }
+#endif
           if (ntok && okx[j] && oky[i]) *reinterpret_cast<float4*>(ob + (ooff[i] + xoffb[j])) = make_float4(v[0], v[1], v[2], v[3]);
         }
       }
@@ -724,6 +749,14 @@ int conv_wino4w_launch(const ConvDesc& d, const ConvCfg& cfg, hipStream_t stream
   p.dTX = make_fastdiv(g.TX); p.dTslab = make_fastdiv(g.tps);
   p.nblocks_m = flat ? g.S : (g.S + g.NI - 1) / g.NI; p.nb_n = (p.nT16 + cfg.NT - 1) / cfg.NT;
   pp.dNbn = make_fastdiv(p.nb_n);
+  pp.dNbm = make_fastdiv(p.nblocks_m);
+  // Walk order by what it costs in L2 fills (8 XCDs, each with its own 4 MB L2): n-group-innermost = activations once + 8 x the U stream,
+  // strip-innermost = U once + 8 x the activations.  56x56 48->48: U 0.3 MB against 38 MB of activations; 7x7 384->384: U 21 MB against 4.8 MB
+  // (PMC, 64 crops: 182 MB per launch n-group-innermost)
+  {
+    const double ubytes = 36.0 * d.Cin * d.Cout * 4.0, abytes = (double)d.B * d.H * d.W * d.Cin * 4.0;
+    pp.minner = (p.nb_n > 1 && ubytes > abytes) ? 1 : 0;
+  }
   if (flat) {
     p.TY = fg.TY; p.ntiles = fg.ntiles; p.fragW = fg.fragW;
     p.dTY = make_fastdiv(fg.TY); p.dFragW = make_fastdiv(fg.fragW);

@@ -532,7 +532,8 @@ def test_conv_winograd_f4x4_flat_items(case, nt, cuda):
 @pytest.mark.parametrize("flat", [0, 1])
 @pytest.mark.parametrize("nt", [1, 2, 3])
 @pytest.mark.parametrize("case", WINO4 + [(64, 28, 28, 16, 32, True), (9, 56, 56, 16, 16, False), (33, 14, 14, 32, 32, True),
-                                          (64, 14, 14, 48, 112, True), (3, 56, 56, 64, 128, True)],
+                                          (64, 14, 14, 48, 112, True), (3, 56, 56, 64, 128, True),
+                                          (5, 14, 14, 64, 112, True)],      # U stream > activations: items walked strip-innermost (round 6)
                          ids=lambda c: "x".join(map(str, c)))
 def test_conv_winograd_f4x4_whole_position_waves(case, nt, flat, cuda):
     """ALG 13 (round 5, conv_wino4w.hip): every MFMA wave owns all 36 positions of a 16-tile group for one n-tile, the output
