@@ -248,7 +248,8 @@ int poco_crop_normalize_multi(const unsigned char* const* d_frames, int nframes,
 
 /* Time `ncfg` tile configurations (cfgs7 = ncfg x SEVEN ints {MT,NT,WM,WN,R,NI,ALG} each, csrc/common.h CONV_CFG_INTS;
  * MT<=0 = heuristic) for one conv shape on random data; ms_out[i] < 0 = configuration invalid for this shape.  NULL cfgs7 /
- * ms_out, ncfg < 1 or channel counts that are not multiples of 16 are POCO_ERR_ARG.  Used by poco_amd/tune.py. */
+ * ms_out, ncfg < 1 or channel counts that are not multiples of 16 are POCO_ERR_ARG.  iters < 0: |iters| launches of the RESIDUAL form (the
+ * input doubles as the residual: conv2 of a BasicBlock; needs Cin == Cout, stride 1).  Used by poco_amd/tune.py. */
 int poco_tune_conv(int B, int H, int W, int Cin, int Cout, int ks, int stride, const int* cfgs7, int ncfg,
                    int iters, float* ms_out, void* stream);
 

@@ -41,6 +41,7 @@
 // which the producer's packed transform leaves its register pairs.
 #include "conv_wino4_common.h"
 #include <cstdlib>
+#include <type_traits>
 
 namespace {
 
@@ -61,6 +62,15 @@ using w4::at_c;
 #ifndef W4W_ASMMAX
 #define W4W_ASMMAX 1  // the epilogue's ReLU clamp as ONE v_max_f32 per value (inline asm): fmaxf() compiles to two (hipcc first quiets a possible signalling NaN
 #endif                // with v_max x, x, x - 64 extra VALU instructions per wave and item in a VALU-bound epilogue); packed residual / bias adds on f32x4
+#ifndef W4W_RESEARLY
+#define W4W_RESEARLY 1 // residual (conv2 of a BasicBlock): the loads of output columns 0 / 1 go out at the START of the epilogue, under the first transform stage,
+#endif                 // those of columns 2 / 3 as soon as columns 0 / 1 are stored; 0 = round 5: column j + 1 requested when column j is computed
+#ifndef W4W_ATPK
+#define W4W_ATPK 1    // output transform on register pairs (see w4w_at)
+#endif
+#ifndef W4W_PEEL
+#define W4W_PEEL 1    // the first slice of an item accumulates onto a literal zero (the MFMA's C operand) instead of onto 144 registers zeroed with 144 v_mov_b32
+#endif
 #ifndef W4W_RD
 #define W4W_RD 3      // depth of the raw-patch ring in LDS (3: a request has two slices to land, 4: three - measured 1-3 % slower per launch)
 #endif
@@ -124,13 +134,30 @@ __device__ __forceinline__ void w4w_wait_vm(int n) {
 
 // y = A^T x for the six values x0 .. x5 of one transform row / column ([Lavin & Gray]: A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0;
 // 0 1 -1 8 -8 1]) in even / odd form: 10 operations
+__device__ __forceinline__ void w4w_at2(f32x2 x0, f32x2 x1, f32x2 x2, f32x2 x3, f32x2 x4, f32x2 x5, f32x2 (&y)[4]) {
+  const f32x2 s1 = x1 + x2, d1 = x1 - x2, s2 = x3 + x4, d2 = x3 - x4;
+  y[0] = x0 + s1 + s2;
+  y[1] = pk_fma(d2, 2.f, d1);
+  y[2] = pk_fma(s2, 4.f, s1);
+  y[3] = pk_fma(d2, 8.f, d1) + x5;
+}
+// (on register PAIRS: as f32x4 arithmetic hipcc emitted the two differences as eight scalar v_sub_f32 per transform - 80 of an epilogue's ~480
+// vector instructions; on f32x2 they are v_pk_add_f32 with a negated operand)
 __device__ __forceinline__ void w4w_at(const f32x4& x0, const f32x4& x1, const f32x4& x2, const f32x4& x3, const f32x4& x4, const f32x4& x5,
                                        f32x4 (&y)[4]) {
+#if W4W_ATPK
+  f32x2 lo[4], hi[4];
+  w4w_at2(x0.xy, x1.xy, x2.xy, x3.xy, x4.xy, x5.xy, lo);
+  w4w_at2(x0.zw, x1.zw, x2.zw, x3.zw, x4.zw, x5.zw, hi);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) y[i] = (f32x4){lo[i].x, lo[i].y, hi[i].x, hi[i].y};
+#else
   const f32x4 s1 = x1 + x2, d1 = x1 - x2, s2 = x3 + x4, d2 = x3 - x4;
   y[0] = x0 + s1 + s2;
   y[1] = d1 + 2.f * d2;
   y[2] = s1 + 4.f * s2;
   y[3] = d1 + 8.f * d2 + x5;
+#endif
 }
 
 struct W4WParams {
@@ -341,7 +368,7 @@ __device__ __forceinline__ void w4w_mfma_wave(const W4WParams& pp, float4* smem,
 
     f32x4 acc[9][4];
 #pragma unroll
-    for (int q = 0; q < 9; ++q)
+    for (int q = (W4W_PEEL ? 9 - (NT < 3 ? W4W_HOLD : 0) : 0); q < 9; ++q)        // (W4W_PEEL: only the quads whose first MFMAs are deferred need a zeroed accumulator)
 #pragma unroll
       for (int i = 0; i < 4; ++i) acc[q][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
@@ -354,7 +381,8 @@ __device__ __forceinline__ void w4w_mfma_wave(const W4WParams& pp, float4* smem,
     float4 vhold[NH > 0 ? NH : 1];
     const float4* uhold = p.ufrag;
 #endif
-    for (int s = 0; s < S; ++s) {
+    auto slice = [&](const int s, auto first_tag) __attribute__((always_inline)) {
+      constexpr bool kFirst = W4W_PEEL && decltype(first_tag)::value;      // slice 0 of an item: C operand = literal zero
       W4W_T(c0);
       const float4* V = smem + p.voff + vb * (2 * W4W_UBLK) + grp * W4W_UBLK + vlane;
       // U of global slice t + 1: the next slice of this item, slice 0 of the block's next item (an n-group that reaches beyond the tensor -
@@ -387,7 +415,8 @@ __device__ __forceinline__ void w4w_mfma_wave(const W4WParams& pp, float4* smem,
 #endif
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          if (W4W_EXP & 8) acc[q][i][0] += ur[q][i] * f4c(v, i);
+          if (W4W_EXP & 8) acc[q][i][0] = (kFirst ? 0.f : acc[q][i][0]) + ur[q][i] * f4c(v, i);
+          else if constexpr (kFirst) acc[q][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(ur[q][i], f4c(v, i), (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
           else acc[q][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(ur[q][i], f4c(v, i), acc[q][i], 0, 0, 0);
         }
         if (!(W4W_EXP & 16)) w4w_uload(ur[q], un, uvo[q >> 2], q);                        // ... and its registers take quad q of the next slice
@@ -401,7 +430,9 @@ __device__ __forceinline__ void w4w_mfma_wave(const W4WParams& pp, float4* smem,
       __builtin_amdgcn_sched_barrier(0);
       W4W_T(c3);
       W4W_ACC(0, c0, c1); W4W_ACC(1, c1, c2); W4W_ACC(2, c2, c3);
-    }
+    };
+    slice(0, std::true_type{});
+    for (int s = 1; s < S; ++s) slice(s, std::false_type{});
     W4W_T(e0);
 
     // ---- epilogue, registers only: Y = A^T M A, bias, residual, ReLU, 16-byte stores of the lane's 4x4 pixels x 4 channels ----
@@ -433,6 +464,17 @@ __device__ __forceinline__ void w4w_mfma_wave(const W4WParams& pp, float4* smem,
       // Z[xi][.] = A^T applied along nu to row xi of M, row by row: a row of M (24 registers) dies as soon as its row of Z (16)
       // exists - the allocator sees 144 -> 96 live values instead of 144 + 96.  A^T in its even / odd form (w4w_at: 10 packed
       // operations per 6 -> 4 transform instead of the 14 of the term-by-term sums; the epilogue is VALU-bound, two MFMA waves per SIMD)
+#if W4W_RESEARLY
+      float4 rr[2][4];
+      auto res_load = [&](int j) __attribute__((always_inline)) {       // column j -> rr[j & 1]
+        if (has_res) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) rr[j & 1][i] = *reinterpret_cast<const float4*>(rb + (roff[i] + xoffb[j]));
+        }
+      };
+      res_load(0);
+      res_load(1);
+#endif
       f32x4 z[6][4];
 #pragma unroll
       for (int xi = 0; xi < 6; ++xi) {
@@ -443,17 +485,21 @@ __device__ __forceinline__ void w4w_mfma_wave(const W4WParams& pp, float4* smem,
         for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(z[xi][j][0]), "+v"(z[xi][j][1]), "+v"(z[xi][j][2]), "+v"(z[xi][j][3]));    // (row xi is finished here)
       }
       // one output column j at a time: Y[i][j] = sum_xi A^T[i][xi] Z[xi][j]; the residual of column j + 1 travels meanwhile
+#if !W4W_RESEARLY
       float4 rr[2][4];
       if (has_res) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) rr[0][i] = *reinterpret_cast<const float4*>(rb + (roff[i] + xoffb[0]));
       }
+#endif
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
+#if !W4W_RESEARLY
         if (has_res && j + 1 < 4) {
 #pragma unroll
           for (int i = 0; i < 4; ++i) rr[(j + 1) & 1][i] = *reinterpret_cast<const float4*>(rb + (roff[i] + xoffb[j + 1]));
         }
+#endif
         f32x4 yc[4];
         w4w_at(z[0][j], z[1][j], z[2][j], z[3][j], z[4][j], z[5][j], yc);
 #pragma unroll
@@ -484,6 +530,9 @@ __device__ __forceinline__ void w4w_mfma_wave(const W4WParams& pp, float4* smem,
 #endif
           if (ntok && okx[j] && oky[i]) *reinterpret_cast<float4*>(ob + (ooff[i] + xoffb[j])) = make_float4(v[0], v[1], v[2], v[3]);
         }
+#if W4W_RESEARLY
+        if (j + 2 < 4) res_load(j + 2);                     // (its registers are free now; two columns of work ahead of its use)
+#endif
       }
     }
 #if W4W_TRACE
