@@ -144,8 +144,13 @@ struct Lin3Params {
   uint32_t ho_magic, nc_magic; // fast division by Ho and nC16
 };
 
+// <MB, UN>: 16-pixel sub-tiles per block x K steps whose loads a wave has in flight together.  <4, 4> (rounds 4-5): a block owns 64 pixels; <1, 8>
+// (round 6, cfg.R = 2): 16 pixels per block = 4 x the blocks on the small planes and twice the steps in flight per wave - at one crop a
+// 7x7 384->384 conv is 24 blocks whose waves walk 13.5 steps in four dependent rounds of loads (28 us for 5.3 MB of weights)
+template <int MB, int UN>
 __global__ void __launch_bounds__(1024)
 conv3x3_splitk_kernel(const Lin3Params q) {
+  constexpr int LIN_MB = MB, LIN_UNROLL = UN;
   const LinParams& p = q.l;
   extern __shared__ float4 red[];          // [wave][LIN_MB][64] partial accumulators
   const int lane = threadIdx.x & 63;
@@ -281,9 +286,12 @@ int linear_launch(const ConvDesc& d, const ConvCfg& cfg, hipStream_t stream) {
     q.nK = 9 * p.nC16;
     p.act = d.act; p.res_after_act = d.res_after_act; p.relu_from = d.relu_from;
     const int nwaves = cfg.WM;
-    const size_t lds = (size_t)nwaves * LIN_MB * 64 * sizeof(float4);
-    const dim3 grid(p.nT16, (p.P + LIN_MB * 16 - 1) / (LIN_MB * 16));
-    hipLaunchKernelGGL(conv3x3_splitk_kernel, grid, dim3(nwaves * 64), lds, stream, q);
+    const int mb = cfg.R == 2 ? 1 : cfg.R == 3 ? 2 : 4;            // cfg.R: 1 (and anything else) = <4, 4>, 2 = <1, 8>, 3 = <2, 6>
+    const size_t lds = (size_t)nwaves * mb * 64 * sizeof(float4);
+    const dim3 grid(p.nT16, (p.P + mb * 16 - 1) / (mb * 16));
+    if (mb == 1) hipLaunchKernelGGL((conv3x3_splitk_kernel<1, 8>), grid, dim3(nwaves * 64), lds, stream, q);
+    else if (mb == 2) hipLaunchKernelGGL((conv3x3_splitk_kernel<2, 6>), grid, dim3(nwaves * 64), lds, stream, q);
+    else hipLaunchKernelGGL((conv3x3_splitk_kernel<4, 4>), grid, dim3(nwaves * 64), lds, stream, q);
     POCO_HIP_CHECK(hipGetLastError());
     return POCO_OK;
   }

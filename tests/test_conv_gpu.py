@@ -204,12 +204,13 @@ def test_linear_small_m(case, wm, cuda):
     assert np.abs(out - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max())
 
 
+@pytest.mark.parametrize("form", [1, 2, 3])       # cfg.R: 64 pixels per block x 4 K steps in flight (rounds 4-5) | 16 x 8 (round 6) | 32 x 6
 @pytest.mark.parametrize("wm", [1, 4, 16])
 @pytest.mark.parametrize("case", [(1, 7, 7, 384, 384, 1, True), (1, 14, 14, 192, 192, 1, True), (4, 28, 28, 96, 96, 1, False), (1, 56, 56, 48, 48, 1, True),
                                   (1, 56, 56, 48, 96, 2, False), (3, 28, 28, 96, 192, 2, True), (2, 14, 14, 192, 384, 2, False), (1, 13, 9, 32, 16, 1, True),
                                   (2, 15, 15, 32, 48, 2, False), (1, 1, 1, 16, 16, 1, False), (5, 7, 7, 16, 32, 2, True)],
                          ids=lambda c: "x".join(map(str, c)))
-def test_conv3x3_split_k_small_batch(case, wm, cuda):
+def test_conv3x3_split_k_small_batch(case, wm, form, cuda):
     """ALG 5 for 3x3 convs (round 4, csrc/linear_mfma.hip conv3x3_splitk_kernel): the direct conv as a GEMM over K = 9 Cin / 16 steps
     dealt to the wm waves of a block, one LDS reduction in a fixed order - the small-batch form of hrnet.py:42-58 (BasicBlock convs)
     and :208-236 (stride-2 fuse convs).  Exact fp32 fma chains: same tolerance as the direct kernels."""
@@ -224,7 +225,7 @@ def test_conv3x3_split_k_small_batch(case, wm, cuda):
     res = rng.standard_normal((B, Ho, Wo, Cout)).astype(np.float32) if use_res else None
     ref = _ref(x, w, scale, shift, stride, res, True)
     out = ops.conv2d_nhwc(torch.from_numpy(x).to(cuda), w, scale, shift, stride, torch.from_numpy(res).to(cuda) if use_res else None,
-                          True, cfg=(1, 1, wm, 1, 1, 1, 5)).cpu().numpy()
+                          True, cfg=(1, 1, wm, 1, form, 1, 5)).cpu().numpy()
     assert out.shape == ref.shape
     assert np.abs(out - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max()), np.abs(out - ref).max()
 
