@@ -374,7 +374,7 @@ __device__ __forceinline__ void w4w_mfma_wave(const W4WParams& pp, float4* smem,
 
 #if W4W_TRACE
     const bool trace = blockIdx.x == 0 && it == wk.first;
-    unsigned long long tr[4] = {0, 0, 0, 0};
+    unsigned long long tr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
 #if W4W_HOLD
     constexpr int NH = NT < 3 ? W4W_HOLD : 0;               // quads held back across the slice barrier
@@ -475,6 +475,7 @@ __device__ __forceinline__ void w4w_mfma_wave(const W4WParams& pp, float4* smem,
       res_load(0);
       res_load(1);
 #endif
+      W4W_T(ea);
       f32x4 z[6][4];
 #pragma unroll
       for (int xi = 0; xi < 6; ++xi) {
@@ -484,6 +485,8 @@ __device__ __forceinline__ void w4w_mfma_wave(const W4WParams& pp, float4* smem,
 #pragma unroll
         for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(z[xi][j][0]), "+v"(z[xi][j][1]), "+v"(z[xi][j][2]), "+v"(z[xi][j][3]));    // (row xi is finished here)
       }
+      W4W_T(eb);
+      W4W_ACC(4, e0, ea); W4W_ACC(5, ea, eb);
       // one output column j at a time: Y[i][j] = sum_xi A^T[i][xi] Z[xi][j]; the residual of column j + 1 travels meanwhile
 #if !W4W_RESEARLY
       float4 rr[2][4];
@@ -538,7 +541,8 @@ __device__ __forceinline__ void w4w_mfma_wave(const W4WParams& pp, float4* smem,
 #if W4W_TRACE
     W4W_T(e1);
     W4W_ACC(3, e0, e1);
-    if (trace && lane == 0) { for (int k = 0; k < 4; ++k) g_w4w_trace[4 * wave + k] = tr[k]; g_w4w_trace[63] = (unsigned long long)S; }
+    if (trace && lane == 0) { for (int k = 0; k < 4; ++k) g_w4w_trace[4 * wave + k] = tr[k]; g_w4w_trace[63] = (unsigned long long)S;
+                              g_w4w_trace[48 + 2 * wave] = tr[4]; g_w4w_trace[49 + 2 * wave] = tr[5]; }
 #endif
   }
 }
@@ -707,7 +711,7 @@ __device__ __forceinline__ void w4w_dma_wave(const W4WParams& pp, float4* smem, 
 #endif
     }
 #if W4W_TRACE
-  if (blockIdx.x == 0 && lane == 0) { g_w4w_trace[48 + 2 * dw] = tr[0]; g_w4w_trace[49 + 2 * dw] = tr[1]; }
+  if (blockIdx.x == 0 && lane == 0) { g_w4w_trace[58 + 2 * dw] = tr[0]; g_w4w_trace[59 + 2 * dw] = tr[1]; }
 #endif
 }
 

@@ -19,13 +19,10 @@ for (B, H, W, Cin, Cout), cfg in [((64, 56, 56, 48, 48), (1, 3, 2, 1, 8, 1, 13))
     nt = cfg[1]
     print(f"{H}x{W} {Cin}->{Cout} NT={nt}: {ms[0]*1e3:.1f} us/launch; S = {S}")
     for w in range(2 * nt):
-        print(f"  MFMA wave {w}: per slice issue+MFMA {buf[4*w]/S:.0f} | wait_vm {buf[4*w+1]/S:.0f} | barrier {buf[4*w+2]/S:.0f} | epilogue {buf[4*w+3]}")
-    if nt == 3:
-        for pw in range(2):
-            b = 32 + 5 * pw
-            print(f"  producer {pw}: per slice LDS-DMA requests {buf[b]/S:.0f} | transform + V store {buf[b+1]/S:.0f} | window reads {buf[b+2]/S:.0f} | wait_vm {buf[b+3]/S:.0f} | barrier {buf[b+4]/S:.0f}")
-    else:
-        N = int(buf[62]) or 1
-        for h in range(4):
-            b = 32 + 5 * h
-            print(f"  helper {h} (group {h & 1}, phase {h >> 1}), clk per PERIOD of two slices over the block's {N} slices: part 1 window + stage 1 {2*buf[b]/N:.0f} | requests {2*buf[b+1]/N:.0f} | part 2 stage 2 + V store {2*buf[b+2]/N:.0f} | wait_vm {2*buf[b+3]/N:.0f} | two barriers {2*buf[b+4]/N:.0f}")
+        print(f"  MFMA wave {w}: per slice issue+MFMA {buf[4*w]/S:.0f} | wait_vm {buf[4*w+1]/S:.0f} | barrier {buf[4*w+2]/S:.0f} | epilogue {buf[4*w+3]} = set-up {buf[48+2*w]} + first stage {buf[49+2*w]} + columns / stores {buf[4*w+3]-buf[48+2*w]-buf[49+2*w]}")
+    for pw in range(2):
+        b = 32 + 5 * pw
+        print(f"  producer {pw}: per slice LDS-DMA requests {buf[b]/S:.0f} | transform + V store {buf[b+1]/S:.0f} | window reads {buf[b+2]/S:.0f} | wait_vm {buf[b+3]/S:.0f} | barrier {buf[b+4]/S:.0f}")
+    if nt == 2:
+        for dw in range(2):
+            print(f"  patch requester {dw}: per slice requests {buf[58+2*dw]/S:.0f} | wait + barrier {buf[59+2*dw]/S:.0f}")
