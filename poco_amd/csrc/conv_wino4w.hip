@@ -445,10 +445,36 @@ __device__ __forceinline__ void w4w_mfma_wave(const W4WParams& pp, float4* smem,
       const int oyb = tl.oy0, oxb = 4 * tl.tx;
       bool okx[4], oky[4];
       unsigned ooff[4], roff[4], xoffb[4];              // byte offsets of the rows and columns (clamped: dead pixels compute harmlessly, masked at the store)
+      unsigned xoffr[4];                                // FLAT == 2: the residual's column offsets (they carry an image term: its row stride may differ)
+      int imgrow[4], ximg[4];                           // FLAT == 2: first image of the mosaic row / image column of the pixel
+      if constexpr (FLAT == 2) {
+        // mosaic (cfg.R = 4 MS): the tile's VIRTUAL rows / columns -> (image, pixel).  A tile may straddle two images and the border line
+        // between them; image = (mosaic * MS + yimg) * MS + ximg, so the element offset is separable into a row and a column part
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          int xc;
+          mosaic_split((uint32_t)(oxb + j), p.Wp1, p.dWp1, &ximg[j], &xc);
+          okx[j] = tl.valid && xc < p.W && ximg[j] < p.MS;
+          const unsigned xin = (unsigned)(min(xc, p.W - 1) * 16 + g4);
+          xoffb[j] = ((unsigned)(ximg[j] * p.H) * (unsigned)p.out_rs + xin) * 4u;
+          xoffr[j] = ((unsigned)(ximg[j] * p.H) * (unsigned)p.res_rs + xin) * 4u;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          int yimg, yc;
+          mosaic_split((uint32_t)(oyb + i), p.Hp1, p.dHp1, &yimg, &yc);
+          oky[i] = yc < p.H && yimg < p.MS;
+          imgrow[i] = (tl.b * p.MS + yimg) * p.MS;
+          const int orow = imgrow[i] * p.H + min(yc, p.H - 1);
+          ooff[i] = (unsigned)orow * (unsigned)p.out_rs * 4u;
+          roff[i] = (unsigned)orow * (unsigned)p.res_rs * 4u;
+        }
+      } else {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         okx[j] = tl.valid && oxb + j < p.W;
         xoffb[j] = (unsigned)(min(oxb + j, p.W - 1) * 16 + g4) * 4u;
+        xoffr[j] = xoffb[j]; ximg[j] = 0;
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -456,7 +482,14 @@ __device__ __forceinline__ void w4w_mfma_wave(const W4WParams& pp, float4* smem,
         const int orow = tl.b * p.H + min(oyb + i, p.H - 1);
         ooff[i] = (unsigned)orow * (unsigned)p.out_rs * 4u;
         roff[i] = (unsigned)orow * (unsigned)p.res_rs * 4u;
+        imgrow[i] = 0;
       }
+      }
+      // FLAT == 2: pixel (i, j) exists iff its row and column do and its image is one of the B (the last mosaic may be partly empty)
+      auto pix_ok = [&](int i, int j) __attribute__((always_inline)) -> bool {
+        if constexpr (FLAT == 2) return okx[j] && oky[i] && imgrow[i] + ximg[j] < p.B;
+        else return okx[j] && oky[i];
+      };
       const float4 sh = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(p.bias + ntc * 16) + (unsigned)(g4 * 4));
       const char* rb = reinterpret_cast<const char*>(p.res + (size_t)ntc * p.out_ss);
       char* ob = reinterpret_cast<char*>(p.out + (size_t)ntc * p.out_ss);
@@ -469,7 +502,11 @@ __device__ __forceinline__ void w4w_mfma_wave(const W4WParams& pp, float4* smem,
       auto res_load = [&](int j) __attribute__((always_inline)) {       // column j -> rr[j & 1]
         if (has_res) {
 #pragma unroll
-          for (int i = 0; i < 4; ++i) rr[j & 1][i] = *reinterpret_cast<const float4*>(rb + (roff[i] + xoffb[j]));
+          for (int i = 0; i < 4; ++i) {
+            unsigned ro = roff[i] + xoffr[j];
+            if constexpr (FLAT == 2) ro = pix_ok(i, j) ? ro : 0u;          // (an absent image of the last mosaic lies beyond the tensor)
+            rr[j & 1][i] = *reinterpret_cast<const float4*>(rb + ro);
+          }
         }
       };
       res_load(0);
@@ -492,7 +529,7 @@ __device__ __forceinline__ void w4w_mfma_wave(const W4WParams& pp, float4* smem,
       float4 rr[2][4];
       if (has_res) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) rr[0][i] = *reinterpret_cast<const float4*>(rb + (roff[i] + xoffb[0]));
+        for (int i = 0; i < 4; ++i) rr[0][i] = *reinterpret_cast<const float4*>(rb + (roff[i] + xoffr[0]));
       }
 #endif
 #pragma unroll
@@ -500,7 +537,7 @@ __device__ __forceinline__ void w4w_mfma_wave(const W4WParams& pp, float4* smem,
 #if !W4W_RESEARLY
         if (has_res && j + 1 < 4) {
 #pragma unroll
-          for (int i = 0; i < 4; ++i) rr[(j + 1) & 1][i] = *reinterpret_cast<const float4*>(rb + (roff[i] + xoffb[j + 1]));
+          for (int i = 0; i < 4; ++i) rr[(j + 1) & 1][i] = *reinterpret_cast<const float4*>(rb + (roff[i] + xoffr[j + 1]));
         }
 #endif
         f32x4 yc[4];
@@ -531,7 +568,7 @@ __device__ __forceinline__ void w4w_mfma_wave(const W4WParams& pp, float4* smem,
             v[0] = fmaxf(v[0], lo); v[1] = fmaxf(v[1], lo); v[2] = fmaxf(v[2], lo); v[3] = fmaxf(v[3], lo);
           }
 #endif
-          if (ntok && okx[j] && oky[i]) *reinterpret_cast<float4*>(ob + (ooff[i] + xoffb[j])) = make_float4(v[0], v[1], v[2], v[3]);
+          if (ntok && pix_ok(i, j)) *reinterpret_cast<float4*>(ob + (ooff[i] + xoffb[j])) = make_float4(v[0], v[1], v[2], v[3]);
         }
 #if W4W_RESEARLY
         if (j + 2 < 4) res_load(j + 2);                     // (its registers are free now; two columns of work ahead of its use)
@@ -732,7 +769,7 @@ struct W4WLayout { int uoff, voff, totalF4; };
 bool w4w_geo(const ConvDesc& d, const ConvCfg& cfg, w4::Geo* g, W4WLayout* L, FlatGeo* fg = nullptr) {
   if (d.ks != 3 || d.stride != 1 || cfg.NT < 1 || cfg.NT > 3 || cfg.WM != 2 || cfg.WN != 1 || d.Cin % 16 || d.Cout % 16) return false;
   FlatGeo ftmp;
-  if (cfg.NI == 0) { if (cfg.R != 4 || !flat_geo(d, cfg, g, fg ? fg : &ftmp)) return false; }      // (no mosaic items here)
+  if (cfg.NI == 0) { if (!flat_geo(d, cfg, g, fg ? fg : &ftmp)) return false; }                     // flat items; cfg.R = 4 MS: over mosaics of MS x MS images
   else if (!w4::geo(d, cfg, 32, g)) return false;
   if (g->rawF4 > 1024) return false;
   // 32-bit byte offsets in the epilogue
@@ -824,12 +861,13 @@ int conv_wino4w_launch(const ConvDesc& d, const ConvCfg& cfg, hipStream_t stream
   long g4 = (items + rounds - 1) / rounds;
   if (g4 > 8) g4 = std::min(cus, (g4 + 7) / 8 * 8);            // multiple of 8 for the XCD-aware walk
   const size_t lds = (size_t)L.totalF4 * sizeof(float4);
-  const int mode = flat ? 1 : 0;
+  const int mode = !flat ? 0 : fg.MS > 1 ? 2 : 1;
   void (*fn)(const W4WParams) =
-      mode == 1 ? (cfg.NT == 3 ? conv_wino4w_kernel<3, 1> : cfg.NT == 2 ? conv_wino4w_kernel<2, 1> : conv_wino4w_kernel<1, 1>)
+      mode == 2 ? (cfg.NT == 3 ? conv_wino4w_kernel<3, 2> : cfg.NT == 2 ? conv_wino4w_kernel<2, 2> : conv_wino4w_kernel<1, 2>)
+      : mode == 1 ? (cfg.NT == 3 ? conv_wino4w_kernel<3, 1> : cfg.NT == 2 ? conv_wino4w_kernel<2, 1> : conv_wino4w_kernel<1, 1>)
                   : (cfg.NT == 3 ? conv_wino4w_kernel<3, 0> : cfg.NT == 2 ? conv_wino4w_kernel<2, 0> : conv_wino4w_kernel<1, 0>);
   if (lds > 64 * 1024) {
-    static thread_local bool configured[12] = {};
+    static thread_local bool configured[16] = {};
     if (!configured[cfg.NT + 4 * mode]) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       if (e != hipSuccess) { poco_set_error(std::string("hipFuncSetAttribute: ") + hipGetErrorString(e)); return POCO_ERR_HIP; }

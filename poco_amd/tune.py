@@ -159,8 +159,8 @@ def candidates(B, H, W, Cin, Cout, ks, stride, lds_cap=150 * 1024) -> List[Tuple
                     tot = max(3 * raw + 3 * u + 2 * v, 3 * raw + u + 4096)
                     if raw <= 1024 and tot * 16 <= 160 * 1024:
                         out.add((1, NT, 2, 4, R, ni, 8))
-                    # ALG 13 (whole-position MFMA waves, round 5): the same rings without the exchange area
-                    if raw <= 1024 and (3 * raw + 3 * u + 2 * v) * 16 <= 160 * 1024:
+                    # ALG 13 (whole-position MFMA waves, round 5; round 6: U in registers - LDS = raw ring + V only)
+                    if raw <= 1024:
                         out.add((1, NT, 2, 1, R, ni, 13))
             # ALG 8 with FLAT items (R = 4, NI = 0; round 4): 32 consecutive tiles of the flattened (image, tile row, tile column)
             # order per item, 6-row strip patch with slots skewed by pos / 16
@@ -170,7 +170,7 @@ def candidates(B, H, W, Cin, Cout, ks, stride, lds_cap=150 * 1024) -> List[Tuple
             u, v = NT * 576, 2 * 576
             if raw <= 1024 and max(3 * raw + 3 * u + 2 * v, 3 * raw + u + 4096) * 16 <= 160 * 1024:
                 out.add((1, NT, 2, 4, 4, 0, 8))
-            if raw <= 1024 and (3 * raw + 3 * u + 2 * v) * 16 <= 160 * 1024:
+            if raw <= 1024:
                 out.add((1, NT, 2, 1, 4, 0, 13))
             # ... over a MOSAIC of MS x MS images that share their zero borders (R = 4 MS): only where it saves tiles (14 x 14 planes:
             # 15 x 15 tiles per 4 x 4 images instead of 16 x 16)
@@ -183,6 +183,8 @@ def candidates(B, H, W, Cin, Cout, ks, stride, lds_cap=150 * 1024) -> List[Tuple
                 rawm = (nposm + nposm // 16 + 1 + 63) // 64 * 64
                 if rawm <= 1024 and max(3 * rawm + 3 * u + 2 * v, 3 * rawm + u + 4096) * 16 <= 160 * 1024:
                     out.add((1, NT, 2, 4, 4 * MS, 0, 8))
+                if rawm <= 1024:
+                    out.add((1, NT, 2, 1, 4 * MS, 0, 13))       # (round 6: ALG 13 walks mosaics too)
     return sorted(out)
 
 

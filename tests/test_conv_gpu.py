@@ -577,19 +577,20 @@ def test_conv_winograd_f4x4_whole_position_waves(case, nt, flat, cuda):
 @pytest.mark.parametrize("case", [(64, 14, 14, 32, 48, True), (33, 14, 14, 16, 16, False), (5, 7, 7, 32, 16, True), (19, 13, 9, 16, 32, True),
                                   (3, 28, 28, 16, 16, True), (1, 1, 1, 16, 16, False), (16, 14, 14, 64, 64, True)],
                          ids=lambda c: "x".join(map(str, c)))
-def test_conv_winograd_f4x4_mosaic_items(case, nt, ms, cuda):
+@pytest.mark.parametrize("alg", [8, 13])
+def test_conv_winograd_f4x4_mosaic_items(case, nt, ms, alg, cuda):
     """ALG 8 flat items over a MOSAIC (cfg R = 4 MS, NI = 0): MS x MS images share their one-pixel zero borders in one virtual plane
     (14 x 14 planes: 15 x 15 tiles per 4 x 4 images instead of 16 x 16), tiles straddle images and border lines, the last mosaic is
     partly empty when B is no multiple of MS^2.  Equal to the fp64 conv; pixels whose tile lies inside one image see the same
     arithmetic as with plain flat items, so the result differs from them by rounding only where the 4 x 4 tiling shifted."""
     from poco_amd import ops
     B, H, W, Cin, Cout, has_res = case
-    cfg = (1, nt, 2, 4, 4 * ms, 0, 8)
+    cfg = (1, nt, 2, 4, 4 * ms, 0, 8) if alg == 8 else (1, nt, 2, 1, 4 * ms, 0, 13)      # (round 6: ALG 13 walks mosaics too)
     TX = (ms * (W + 1) - 1 + 3) // 4
     fmax = (TX - 1 + 32 + TX - 1) // TX
     npos = 6 * (128 + 2 * fmax)
     raw = (npos + npos // 16 + 1 + 63) // 64 * 64
-    fits = raw <= 1024 and (3 * raw + 3 * nt * 576 + 4 * 576) * 16 <= 160 * 1024
+    fits = raw <= 1024 and (alg == 13 or (3 * raw + 3 * nt * 576 + 4 * 576) * 16 <= 160 * 1024)
     rng = np.random.default_rng(B * 17 + Cin + Cout + nt + ms)
     x = rng.standard_normal((B, H, W, Cin)).astype(np.float32)
     w = (rng.standard_normal((Cout, Cin, 3, 3)) / np.sqrt(9 * Cin)).astype(np.float32)
