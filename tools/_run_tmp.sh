@@ -1,8 +1,6 @@
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/r7g
-for vb in "hrnet_w48_cls-cliff 128" "hrnet_w48_cls-cliff 32" "hrnet_w48_cls-cliff 64" "hrnet_w32-pare 32"; do
-set -- $vb
-timeout 1500 python tools/w4w_tune.py $1 $2 --write 2>&1 | grep -v amdgpu.ids > gpurun_out/r7g/tune_$1_$2.log
-tail -2 gpurun_out/r7g/tune_$1_$2.log
+mkdir -p gpurun_out/r7h
+for vb in "hrnet_w48_cls-cliff 64 200" "hrnet_w48_cls-cliff 128 60" "hrnet_w48_cls-cliff 1 300" "hrnet_w32-pare 32 200" "resnet50-cliff 64 200" "hrnet_w48_cls-cliff 16 150"; do
+timeout 900 python tools/stress.py $vb 2>&1 | grep -v amdgpu.ids | tail -2 >> gpurun_out/r7h/stress.log
 done
-cp poco_amd/tuned/gfx950.json gpurun_out/r7g/gfx950.json
+cat gpurun_out/r7h/stress.log
