@@ -161,6 +161,11 @@ extern "C" int poco_tune_conv(int B, int H, int W, int Cin, int Cout, int ks, in
     poco_set_error("poco_tune_conv: bad arguments");
     return POCO_ERR_ARG;
   }
+  const bool with_res = iters < 0;                        // iters < 0: |iters| launches of the residual form
+  if (with_res) {
+    iters = -iters;
+    if (Cin != Cout || stride != 1) { poco_set_error("poco_tune_conv: iters < 0 (residual form) needs Cin == Cout and stride 1"); return POCO_ERR_ARG; }
+  }
   const int pad = (ks - 1) / 2;
   const int Ho = (H + 2 * pad - ks) / stride + 1, Wo = (W + 2 * pad - ks) / stride + 1;
   const size_t nin = (size_t)B * H * W * Cin, nout = (size_t)B * Ho * Wo * Cout;
@@ -228,11 +233,7 @@ extern "C" int poco_tune_conv(int B, int H, int W, int Cin, int Cout, int ks, in
   }
 #endif
   d.B = B; d.H = H; d.W = W; d.Cin = Cin; d.Cout = Cout; d.ks = ks; d.stride = stride; d.act = 1;
-  if (iters < 0) {                                        // time the residual form (conv2 of a BasicBlock: `out += x`): the input doubles as the residual
-    iters = -iters;
-    if (Cin != Cout || stride != 1) { poco_set_error("poco_tune_conv: iters < 0 (residual form) needs Cin == Cout and stride 1"); return POCO_ERR_ARG; }
-    d.res = din.p; d.res_cs = Cin; d.res_co = 0;
-  }
+  if (with_res) { d.res = din.p; d.res_cs = Cin; d.res_co = 0; }      // the residual form (conv2 of a BasicBlock: `out += x`): the input doubles as the residual
   hipEvent_t e0, e1;
   POCO_HIP_CHECK(hipEventCreate(&e0));
   POCO_HIP_CHECK(hipEventCreate(&e1));

@@ -77,6 +77,7 @@ int main(int argc, char** argv) {
     float ms[2] = {0.f, 0.f};
     if (tune(1, 8, 8, 15, 16, 3, 1, cfgs7, 2, 1, ms, 0) != 1 || !strstr(last_error(), "poco_tune_conv")) return 24;   /* Cin % 16 != 0 */
     if (tune(1, 8, 8, 16, 16, 3, 1, cfgs7, 0, 1, ms, 0) != 1) return 25;                                               /* ncfg < 1 */
+    if (tune(1, 8, 8, 16, 32, 3, 1, cfgs7, 2, -1, ms, 0) != 1 || !strstr(last_error(), "residual")) return 27;         /* residual form needs Cin == Cout */
   }
   if (create_ex("resnet50-cliff", 4, 1, "no_such_option=1", &h) == 0) return 16;     /* unknown build option is an error ... */
   if (strstr(last_error(), "no_such_option") == 0) return 17;                         /* ... that names it */
