@@ -1,6 +1,6 @@
 """Round 6: in-context pass over the 3x3 shapes that run on the split-K direct conv (ALG 5) at small batches: the <4, 4> form of the
 table against <1, 8> (cfg.R = 2: 16 pixels per block, 8 K steps in flight) and <2, 6> (cfg.R = 3), timed as hipGraph replays of the
-whole forward.   python tools/splitk_tune.py variant B [--write]"""
+whole forward.   python tools/splitk_tune.py variant B [--write] [--all-s2: also offer the split-K forms to every stride-2 3x3 shape, whatever it runs on]"""
 import json, sys, time
 from pathlib import Path
 import torch
@@ -36,7 +36,7 @@ for i, _ in enumerate(m.ops()):
     if d is None or d[4] != 3:
         continue
     cfg = tuple(m.conv_cfg(i, B))
-    if cfg[6] == 5:
+    if cfg[6] == 5 or ("--all-s2" in sys.argv and d[5] == 2):
         shapes.setdefault(tune.shape_key(B, *d[:6]), []).append(i)
 base = fwd_ms()
 print(f"{variant} B={B}: table {base:.4f} ms; {len(shapes)} split-K 3x3 shapes", flush=True)
@@ -44,9 +44,9 @@ cur_t, picked = base, {}
 for k, idxs in sorted(shapes.items(), key=lambda kv: -len(kv[1])):
     cur = tuple(m.conv_cfg(idxs[0], B))
     best, best_t = cur, cur_t
-    for form in (2, 3):
-        for wm in sorted({cur[2], 16, 8}):
-            c = (cur[0], cur[1], wm, cur[3], form, cur[5], 5)
+    for form in ((1, 2, 3) if cur[6] != 5 else (2, 3)):
+        for wm in (sorted({cur[2], 16, 8}) if cur[6] == 5 else (4, 8, 16)):
+            c = (cur[0], cur[1], wm, cur[3], form, cur[5], 5) if cur[6] == 5 else (1, 1, wm, 1, form, 1, 5)
             try:
                 for i in idxs:
                     m.set_conv_cfg(i, B, c)
